@@ -1,0 +1,259 @@
+/*
+ * wedm_hip.h — C-ABI of the MI355X batched Wire-EDM step.
+ *
+ * This is the drop-in boundary for ONE hot path of geduardo/SPARC (`wedm` 0.2.0):
+ * the per-microsecond physics step of `WireEDMEnv.step()`
+ * (reference src/wedm/envs/wire_edm.py:116-157 and the five module `update()`s it
+ * calls: modules/ignition.py:175-195, material.py:79-96, dielectric.py:82-163,
+ * wire.py:259-347 (+ the stencil wire.py:58-123), mechanics.py:79-114).
+ *
+ * The reference is pure Python and has no FFI; the binding a maintainer would add
+ * is a `ctypes.CDLL` load of `libwedm_hip.so`.  Every entry
+ * point below therefore cites the Python method it replaces.
+ *
+ * Conventions
+ *   - plain C, no C++/torch types; all pointers are DEVICE pointers unless noted;
+ *   - the caller owns every byte of state (torch tensors on the host side); the
+ *     library owns only the opaque handle and one small constant table;
+ *   - every call returns an int32 status (WEDM_OK or a negative wedm_status);
+ *     nothing throws across the boundary; wedm_last_error() gives the text;
+ *   - launches are asynchronous on the `hipStream_t` passed as `void* stream`
+ *     (NULL = the null stream); the library creates no streams and no threads;
+ *   - a handle is not thread-safe: one handle per device per process.
+ *
+ * State layout: struct-of-arrays, field-major, environment-minor.  Field `f` of
+ * environment `e` lives at  block[f * stride + e]  so that the 64 lanes of a
+ * wavefront (64 consecutive environments) read 64 consecutive elements.
+ * The wire temperature is  T[seg * stride + e]  (float32).
+ */
+#ifndef WEDM_HIP_H
+#define WEDM_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define WEDM_ABI_VERSION 1
+
+/* ------------------------------------------------------------------ status */
+typedef enum wedm_status {
+    WEDM_OK = 0,
+    WEDM_ERR_BAD_ARG = -1,     /* NULL pointer, non-positive size, bad enum      */
+    WEDM_ERR_NOT_BOUND = -2,   /* wedm_step/reset before wedm_bind_state         */
+    WEDM_ERR_HIP = -3,         /* a HIP runtime call failed (text in last_error) */
+    WEDM_ERR_NO_DEVICE = -4,   /* no gfx950 device visible                       */
+    WEDM_ERR_BAD_MODE = -5,    /* current_mode without crater data (material.py:108-113) */
+    WEDM_ERR_UNSUPPORTED = -6  /* n_seg exceeds what the fused kernel can stage  */
+} wedm_status;
+
+/* ------------------------------------------------------- float64 state rows
+ * One row per mutable Python-float attribute of EDMState (core/state.py:25-91)
+ * plus the module-private floats the reference keeps outside the state
+ * (dielectric.py:69-80, mechanics.py:60, wire.py:224,205).                   */
+enum wedm_f64_field {
+    WEDM_F_WORKPIECE_POS = 0,  /* state.workpiece_position        [um]   */
+    WEDM_F_WIRE_POS,           /* state.wire_position             [um]   */
+    WEDM_F_WIRE_VEL,           /* state.wire_velocity             [um/s] */
+    WEDM_F_PREV_ACCEL,         /* MechanicsModule.prev_accel (mechanics.py:60) */
+    WEDM_F_DEBRIS_VOLUME,      /* DielectricModule.debris_volume / state.debris_volume [mm^3] */
+    WEDM_F_DEBRIS_DENSITY,     /* state.debris_density                   */
+    WEDM_F_FLOW,               /* state.flow_rate == DielectricModule._last_flow_condition */
+    WEDM_F_LAST_GAP,           /* DielectricModule._last_gap_um (init -1)       */
+    WEDM_F_LAST_DENSITY,       /* DielectricModule._last_debris_density (init -1) */
+    WEDM_F_WIRE_LAST_FLOW,     /* WireModule._last_flow_condition (init 0)      */
+    WEDM_F_VOLTAGE,            /* state.voltage (None -> 0)              */
+    WEDM_F_CURRENT,            /* state.current (None -> 0)              */
+    WEDM_F_SPARK_Y,            /* state.spark_status[1]; NaN encodes None */
+    WEDM_F_LAST_CRATER,        /* state.last_crater_volume        [mm^3] */
+    WEDM_F_CAVITY,             /* state.cavity_volume             [mm^3] */
+    WEDM_F_TARGET_DELTA,       /* state.target_delta   (latched action)  */
+    WEDM_F_TARGET_VOLTAGE,     /* state.target_voltage (latched; 0 encodes None) */
+    WEDM_F_ON_TIME,            /* state.ON_time        (latched; 0 encodes None) */
+    WEDM_F_OFF_TIME,           /* state.OFF_time       (latched; 0 encodes None) */
+    WEDM_F_TARGET_POS,         /* state.target_position                  */
+    WEDM_F_UNWIND_VEL,         /* state.wire_unwinding_velocity          */
+    WEDM_F_H_BASE,             /* WireModule.h_eff_zone outside the zone (float32 value) */
+    WEDM_F_H_ZONE,             /* WireModule.h_eff_zone inside the zone  (float32 value) */
+    WEDM_F_TMAX,               /* max(T) after the last step (float32 value)    */
+    WEDM_F64_COUNT
+};
+
+/* --------------------------------------------------------- int32 state rows */
+enum wedm_i32_field {
+    WEDM_I_TIME = 0,           /* state.time                       [us] */
+    WEDM_I_SINCE_SERVO,        /* state.time_since_servo                */
+    WEDM_I_SINCE_OPEN_V,       /* state.time_since_open_voltage         */
+    WEDM_I_SINCE_IGNITION,     /* state.time_since_spark_ignition       */
+    WEDM_I_SINCE_SPARK_END,    /* state.time_since_spark_end            */
+    WEDM_I_SPARK_DUR,          /* state.spark_status[2]                 */
+    WEDM_I_RANDOM_SHORT_REM,   /* IgnitionModule.random_short_remaining */
+    WEDM_I_DEBRIS_SHORT_REM,   /* IgnitionModule.debris_short_remaining */
+    WEDM_I_TIME_CRITICAL,      /* state.time_in_critical_temp           */
+    WEDM_I_CURRENT_MODE,       /* state.current_mode: n for "I<n>", 0 encodes None */
+    WEDM_I_EPISODE,            /* resets seen by this environment (RNG counter word) */
+    WEDM_I_KEY_LO,             /* Philox key, low  32 bits of the reset seed */
+    WEDM_I_KEY_HI,             /* Philox key, high 32 bits of the reset seed */
+    WEDM_I_SPARK_COUNT,        /* fresh sparks since reset (len(crater_volumes_um3), material.py:133) */
+    WEDM_I32_COUNT
+};
+
+/* ---------------------------------------------------------- int8 state rows */
+enum wedm_i8_field {
+    WEDM_B_SPARK_STATE = 0,    /* state.spark_status[0]: 0 idle, 1 spark, -1 short, -2 rest */
+    WEDM_B_IS_SHORT,           /* state.is_short_circuit                */
+    WEDM_B_WIRE_BROKEN,        /* state.is_wire_broken                  */
+    WEDM_B_TARGET_REACHED,     /* state.is_target_distance_reached      */
+    WEDM_B_DONE,               /* terminated: the environment is frozen until reset */
+    WEDM_B_CTRL_STEP,          /* info["control_step"] of the LAST substep run */
+    WEDM_B_ERROR,              /* sticky: 1 = fresh spark with a mode that has no crater data */
+    WEDM_I8_COUNT
+};
+
+/* -------------------------------------- per-environment geometry (optional)
+ * BASELINE config 5: workpiece_height / wire_diameter differ per environment.
+ * When bound, these rows override the uniform values in wedm_params.       */
+enum wedm_geom_f64_field {
+    WEDM_G_HEIGHT = 0,         /* config.workpiece_height [mm]                       */
+    WEDM_G_KERF_BASE,          /* base_overcut + wire_diameter (material.py:158-160) */
+    WEDM_G_CAVITY_COEFF,       /* pi * r * h              (dielectric.py:62)         */
+    WEDM_G_K_COND,             /* k * S / dy              (wire.py:174-176)          */
+    WEDM_G_TUF,                /* dt / (rho c S dy)       (wire.py:195)              */
+    WEDM_G_A_SURF,             /* 2 pi r dy               (wire.py:171)              */
+    WEDM_G_S_AREA,             /* pi r^2                  (wire.py:170)              */
+    WEDM_G_JOULE_GEOM,         /* dy / S                  (wire.py:183)              */
+    WEDM_GEOM_F64_COUNT
+};
+enum wedm_geom_i32_field {
+    WEDM_GI_N_SEG = 0,         /* wire.py:149      */
+    WEDM_GI_ZONE_START,        /* wire.py:151,156  (plasma index base)  */
+    WEDM_GI_AZ_START,          /* wire.py:207      (h_eff zone start)   */
+    WEDM_GI_AZ_END,            /* wire.py:208      (h_eff zone end)     */
+    WEDM_GI_CONTACT_BOTTOM,    /* wire.py:239-248  */
+    WEDM_GI_CONTACT_TOP,       /* wire.py:242-251  */
+    WEDM_GEOM_I32_COUNT
+};
+
+/* ----------------------------------------------------------------- params
+ * Everything that is constant during a run.  Derived constants are computed by
+ * the HOST in the reference's own float arithmetic (Python floats) and passed in
+ * verbatim: the device never re-derives them (SURVEY.md §7 "floor-division
+ * geometry quirks").                                                        */
+#define WEDM_MAX_MODE 19
+
+typedef struct wedm_params {
+    /* EnvironmentConfig (core/env_config.py:17-35) */
+    int32_t servo_interval;       /* [us] */
+    int32_t dt_us;                /* [us] */
+    int32_t control_mode;         /* 0 = position, 1 = velocity (mechanics.py:62-67) */
+    int32_t per_env_geometry;     /* 0 = uniform values below, 1 = geometry rows bound */
+    double initial_gap;
+    double target_cutting_distance;
+
+    /* uniform geometry (WireModule.__init__, wire.py:143-257) */
+    int32_t n_seg, zone_start, az_start, az_end, contact_bottom, contact_top;
+    double workpiece_height, kerf_base, cavity_coeff;
+    double k_cond, tuf, a_surf, s_area, joule_geom;
+    double segment_len;           /* [mm] for plasma_idx = zone_start + int(y // segment_len) */
+
+    /* wire material + WireModuleParameters */
+    double spool_T, temp_ref, rho_elec, alpha_rho, rho_c;   /* rho_c = density * specific_heat */
+    double plasma_efficiency, base_convection, convection_velocity_factor, convection_flow_enhancement;
+    double critical_temperature, breaking_temperature;
+    double dielectric_temperature;
+
+    /* IgnitionModuleParameters (ignition.py:17-57) */
+    double base_critical_density, gap_coefficient, max_critical_density, hard_short_gap;
+    double sigmoid_steepness;
+    int32_t debris_short_duration, random_short_duration;
+    double random_short_min_gap, random_short_max_gap, random_short_max_probability;
+    double ignition_a, ignition_b, ignition_c, ln2;
+    double default_target_voltage, default_on_time, default_off_time, default_current;
+    double spark_voltage_factor;
+
+    /* DielectricModuleParameters (dielectric.py:15-31) */
+    double reference_gap, debris_obstruction_coeff, debris_removal_per_us;
+
+    /* MechanicsModuleParameters (mechanics.py:12-23), pre-multiplied as in mechanics.py:48-57 */
+    double dt_s, damping_coeff, stiffness_coeff, omega_n;
+    double max_acceleration, max_jerk_dt, max_speed;
+
+    /* tables: index n = mode "I<n>", n in 1..19; index 0 unused.
+     * mode_current: currents.json.  crater_*: area_corrected.json
+     * (ellipsoid_volume_half, ellipsoid_volume_std, depth); crater_valid[n] = 0
+     * where the reference raises ValueError (material.py:108-113).           */
+    double mode_current[WEDM_MAX_MODE + 1];
+    double crater_mean[WEDM_MAX_MODE + 1];
+    double crater_std[WEDM_MAX_MODE + 1];
+    double crater_depth[WEDM_MAX_MODE + 1];
+    int32_t crater_valid[WEDM_MAX_MODE + 1];
+
+    /* sharding: global id of local environment 0 (Philox counter word 2) */
+    uint32_t env_id_offset;
+    int32_t obs_dim;              /* columns of the obs matrix written at control steps (0 = none) */
+} wedm_params;
+
+typedef struct wedm_state_ptrs {
+    double* f64;        /* [WEDM_F64_COUNT][stride] */
+    int32_t* i32;       /* [WEDM_I32_COUNT][stride] */
+    int8_t* i8;         /* [WEDM_I8_COUNT ][stride] */
+    float* T;           /* [n_seg_max][stride]      */
+    float* obs;         /* [obs_dim][stride] or NULL */
+    int64_t stride;     /* >= num_envs, multiple of 64 recommended */
+} wedm_state_ptrs;
+
+typedef struct wedm_geom_ptrs {
+    const double* f64;  /* [WEDM_GEOM_F64_COUNT][stride] */
+    const int32_t* i32; /* [WEDM_GEOM_I32_COUNT][stride] */
+} wedm_geom_ptrs;
+
+/* Action leaves of WireEDMEnv.action_space (wire_edm.py:84-98), one value per env.
+ * float64 because `_apply_action` keeps the caller's precision (`float(x[0])`,
+ * wire_edm.py:162-170).                                                        */
+typedef struct wedm_action_ptrs {
+    const double* servo;           /* -> state.target_delta   */
+    const double* target_voltage;  /* -> state.target_voltage */
+    const double* on_time;         /* -> state.ON_time        */
+    const double* off_time;        /* -> state.OFF_time       */
+    const int32_t* current_mode;   /* -> state.current_mode "I<n>" */
+} wedm_action_ptrs;
+
+typedef struct wedm_ctx wedm_ctx;
+
+/* version of this header the library was built against */
+int32_t wedm_abi_version(void);
+
+/* replaces WireEDMEnv.__init__ (wire_edm.py:22-101): validates sizes, copies
+ * `params`, selects the device that is current at call time.                  */
+int32_t wedm_create(const wedm_params* params, int32_t num_envs, int32_t n_seg_max, wedm_ctx** out);
+int32_t wedm_destroy(wedm_ctx* ctx);
+
+/* replaces the EDMState() allocation (wire_edm.py:58,110): adopts caller-owned memory */
+int32_t wedm_bind_state(wedm_ctx* ctx, const wedm_state_ptrs* state);
+int32_t wedm_bind_geometry(wedm_ctx* ctx, const wedm_geom_ptrs* geom);
+
+/* replaces WireEDMEnv.reset (wire_edm.py:106-114) for the environments whose
+ * mask byte is non-zero (mask == NULL: all).  Re-keys their RNG with `seed`
+ * when reseed != 0, else bumps their episode counter.  Module-private state is
+ * reset too (documented deviation).                                */
+int32_t wedm_reset(wedm_ctx* ctx, const uint8_t* mask, uint64_t seed, int32_t reseed, void* stream);
+
+/* replaces `n_substeps` consecutive WireEDMEnv.step(action) calls
+ * (wire_edm.py:116-157) with the same action.  n_substeps == 1 is the
+ * reference's 1 us step.                                                      */
+int32_t wedm_step(wedm_ctx* ctx, int32_t n_substeps, const wedm_action_ptrs* action, void* stream);
+
+/* selects the kernel used by wedm_step: 0 = auto, 1 = global-memory stencil
+ * (one pass over T in HBM per substep), 2 = LDS-staged fused stencil.         */
+int32_t wedm_set_kernel(wedm_ctx* ctx, int32_t variant);
+
+/* name / launch geometry of the kernel the last wedm_step used (for profiles) */
+const char* wedm_last_kernel(wedm_ctx* ctx);
+
+const char* wedm_last_error(wedm_ctx* ctx);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* WEDM_HIP_H */

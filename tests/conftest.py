@@ -1,0 +1,29 @@
+"""pytest configuration: markers, repo root on sys.path, oracle build."""
+from __future__ import annotations
+
+import sys
+from pathlib import Path
+
+import pytest
+
+ROOT = Path(__file__).resolve().parents[1]
+if str(ROOT) not in sys.path:
+    sys.path.insert(0, str(ROOT))
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+@pytest.fixture(scope="session")
+def orc():
+    """The CPU oracle (test infrastructure), built on demand with oracle/Makefile."""
+    from oracle import oracle as o
+
+    o.lib()
+    return o
+
+
+@pytest.fixture(scope="session")
+def golden_dir():
+    return ROOT / "tests" / "golden"

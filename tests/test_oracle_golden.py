@@ -1,0 +1,120 @@
+"""Pins the CPU oracle against the reference's own outputs (tests/golden, made by
+tools/gen_golden.py from the reference).  Bit-exact in math mode LIBM."""
+from __future__ import annotations
+
+import json
+
+import numpy as np
+import pytest
+
+from tests._golden import Fixture, replay
+
+NATIVE = [
+    "f1_config1_native", "f1_config1_f32action", "f2_single_spark", "f5_hard_short", "f5_debris_short",
+    "f5_random_short", "f5_collision", "f5_target_reached", "f5_critical_temp", "f5_wire_break",
+    "f5_action_latch", "f5_zero_fallbacks", "f6_velocity_mode", "f6_limits", "f7_gap_controller",
+]
+PHILOX = [f"f3_philox_env{i}" for i in (0, 1, 2, 3, 777, 65535)] + ["f3_philox_config3_env5"] + [
+    f"f8_geometry_{i}" for i in range(4)
+]
+
+
+@pytest.mark.parametrize("name", NATIVE)
+def test_oracle_replays_reference_bit_exact(orc, golden_dir, name):
+    """Reference's own NumPy PCG64 draws replayed into the oracle: every recorded
+    integer, float64 scalar and float32 temperature must be identical."""
+    fx = Fixture(golden_dir / f"{name}.npz")
+    bad, _ = replay(fx, math_mode=orc.MATH_LIBM)
+    assert not bad, "\n".join(bad[:20])
+
+
+@pytest.mark.parametrize("name", PHILOX)
+def test_oracle_philox_matches_injected_reference(orc, golden_dir, name):
+    """The reference consumed the build's Philox variates (injection shim); the oracle
+    generates the same variates itself and must reproduce the reference exactly."""
+    fx = Fixture(golden_dir / f"{name}.npz")
+    bad, _ = replay(fx, math_mode=orc.MATH_LIBM)
+    assert not bad, "\n".join(bad[:20])
+
+
+def test_known_answers_from_survey(orc, golden_dir):
+    """SURVEY.md §8c F1 known answers, recorded independently of this build."""
+    fx = Fixture(golden_dir / "f1_config1_native.npz")
+    bad, env = replay(fx)
+    assert not bad
+    assert env.c.n_seg == 400
+    states = fx.int_row("spark_state")
+    assert {int(k): int(v) for k, v in zip(*np.unique(states, return_counts=True))} == {0: 9004, 1: 36, -2: 960}
+    assert env.workpiece_position == 50.006647428091696
+    T = env.temperature()
+    assert float(T.max()) == 301.2557067871094 and int(T.argmax()) == 166
+    assert float(T.mean(dtype=np.float32)) == pytest.approx(293.6468200683594, abs=1e-4)
+    assert env.debris_volume == 4.965168720421775e-05
+    assert (float(env.h_base), float(env.h_zone)) == (15400.0, 30800.0)
+
+
+def test_single_spark_known_answers(orc, golden_dir):
+    """plasma index 273, T at t=50 and t=1000."""
+    fx = Fixture(golden_dir / "f2_single_spark.npz")
+    bad, env = replay(fx)
+    assert not bad
+    snaps = dict(zip(fx.T_snap_steps.tolist(), fx.T_snaps))
+    t50 = snaps[49]  # after the 50th step
+    assert [float(x) for x in t50[272:275]] == [293.2237243652344, 300.46075439453125, 293.2237243652344]
+    T = env.temperature()
+    assert [float(x) for x in T[272:275]] == [296.1844787597656, 297.6618957519531, 296.1844787597656]
+    assert (float(env.h_base), float(env.h_zone)) == (14000.0, 14896.0)
+
+
+def test_invalid_mode_flags_where_reference_raises(orc, golden_dir):
+    """material.py:108-113 raises ValueError at the first fresh spark with an even
+    mode; the oracle sets its error flag on exactly that step."""
+    fx = Fixture(golden_dir / "f5_invalid_mode.npz")
+    step_raised, _msg = fx.meta["raised"]
+    bad, env = replay(fx)
+    # the aborted step drew u_debris, u_random, u_ignite, y before material.update raised
+    assert bad == [f"draw trace: consumed {len(fx.draws) - 4} of {len(fx.draws)}"]
+    assert env.error == 0
+    from tests._golden import action_for
+
+    orc.step(env, action_for(fx, fx.n_steps - 1))
+    assert env.error & 1 and fx.n_steps == step_raised
+
+
+def test_portable_math_mode_stays_within_stated_tolerance(orc, golden_dir):
+    """PORTABLE math (what the GPU computes) vs the reference: decisions identical,
+    float64 state within 1e-12 relative, temperatures within 1e-4 K."""
+    for name in ("f1_config1_native", "f5_debris_short", "f3_philox_env0", "f7_gap_controller"):
+        fx = Fixture(golden_dir / f"{name}.npz")
+        bad, _ = replay(fx, math_mode=orc.MATH_PORTABLE, exact_floats=False, float_rtol=1e-12, T_atol=1e-4)
+        assert not bad, name + "\n" + "\n".join(bad[:20])
+
+
+def test_numba_typing_of_the_stencil_is_within_tolerance(orc, golden_dir):
+    """float64-intermediate stencil (how real Numba types wire.py:58-123) vs the
+    float32 path the stubbed reference runs: |dT| <= 1.3e-4 K over 10 000 steps."""
+    fx = Fixture(golden_dir / "f1_config1_native.npz")
+    bad, _ = replay(fx, stencil_mode=orc.STENCIL_F64, exact_floats=False, float_rtol=1e-6, T_atol=1.3e-4,
+                    skip_floats=("tmax",))
+    assert not bad, "\n".join(bad[:20])
+
+
+def test_geometry_table(orc, golden_dir):
+    """F4: derived constants of WireModule/Dielectric/Mechanics constructors."""
+    z = np.load(golden_dir / "f4_geometry_table.npz")
+    cols = json.loads(str(z["columns"]))
+    import ctypes as C
+
+    for row in z["table"]:
+        r = dict(zip(cols, row))
+        cfg = orc.default_config(workpiece_height=r["h"], wire_diameter=r["d"], segment_len=r["seg"],
+                                 buffer_len_bottom=r["buf_bottom"], buffer_len_top=r["buf_top"],
+                                 contact_offset_bottom=r["off_bottom"], contact_offset_top=r["off_top"])
+        c = orc.Consts()
+        assert orc.lib().wedm_oracle_derive(C.byref(cfg), C.byref(c)) == 0
+        for k in ("n_seg", "zone_start", "zone_end", "az_start", "az_end", "contact_bottom", "contact_top"):
+            assert getattr(c, k) == int(r[k]), (k, r)
+        for k in ("k_cond", "tuf", "a_surf", "s_area", "joule_geom", "critical_temperature",
+                  "breaking_temperature", "cavity_coeff", "debris_removal_per_us", "damping_coeff",
+                  "stiffness_coeff", "max_jerk_dt", "dt_s"):
+            assert getattr(c, k) == r[k], (k, getattr(c, k), r[k], r)

@@ -1,0 +1,437 @@
+#!/usr/bin/env python
+"""Generate tests/golden/*.npz by running the REFERENCE itself (build container only).
+
+The reference (/root/reference, pure Python) is imported with the two in-memory
+stubs of tools/ref_harness.py and driven through the scenarios
+below.  Every scenario records, per 1-us step, what `WireEDMEnv.step()` left in
+`env.state` and in the module-private fields, plus the exact sequence of random
+variates the reference drew (`env.np_random` is wrapped by a recorder).
+
+Two RNG sources:
+  native : the reference's own NumPy Generator(PCG64) seeded by reset(seed=...).
+           Fixtures carry the draw trace so the oracle can REPLAY it.
+  philox : `env.np_random` is replaced by a shim that returns the build's
+           Philox4x32-10 variates by slot (computed by oracle/, whose Philox is
+           pinned by Random123 known-answer vectors in tests/).  The reference,
+           the oracle and the GPU then consume identical variates.
+
+Fixtures are data only (inputs + recorded outputs).  Run:
+    python tools/gen_golden.py            # writes tests/golden/*.npz
+"""
+from __future__ import annotations
+
+import json
+import math
+import sys
+from pathlib import Path
+
+import numpy as np
+
+ROOT = Path(__file__).resolve().parents[1]
+sys.path.insert(0, str(ROOT))
+sys.path.insert(0, str(ROOT / "tools"))
+
+import ref_harness  # noqa: E402
+
+wedm = ref_harness.import_reference()
+from oracle import oracle as orc  # noqa: E402  (only for the Philox shim's variates)
+
+OUT = ROOT / "tests" / "golden"
+
+FLOAT_FIELDS = (
+    "workpiece_position", "wire_position", "wire_velocity", "voltage", "current", "spark_y",
+    "debris_volume", "debris_density", "flow_rate", "cavity_volume", "last_crater_volume",
+    "prev_accel", "tmax", "h_base", "h_zone", "diel_last_gap", "diel_last_density", "wire_last_flow",
+)
+INT_FIELDS = (
+    "time", "time_since_servo", "spark_state", "spark_dur", "is_short_circuit",
+    "random_short_remaining", "debris_short_remaining", "time_in_critical_temp",
+    "is_wire_broken", "is_target_reached", "terminated", "ctrl_step", "n_draws",
+    "time_since_spark_ignition", "time_since_spark_end", "time_since_open_voltage",
+)
+
+
+class RecordingRNG:
+    """Wraps the reference's Generator and logs every variate it hands out."""
+
+    def __init__(self, gen):
+        self.gen = gen
+        self.trace = []
+        self.n_step = 0
+
+    def begin_step(self, t):
+        self.n_step = 0
+
+    def _log(self, v):
+        self.trace.append(float(v))
+        self.n_step += 1
+        return v
+
+    def random(self):
+        return self._log(self.gen.random())
+
+    def uniform(self, low, high):
+        return self._log(self.gen.uniform(low, high))
+
+    def normal(self, loc, scale):
+        return self._log(self.gen.normal(loc, scale))
+
+
+class PhiloxShim(RecordingRNG):
+    """`env.np_random` stand-in returning the build's Philox variates by slot.
+
+    Per step the reference calls `.random()` at most three times in a fixed order
+    (debris roll, random-short roll, ignition roll: ignition.py:233,239,327), so
+    the call position identifies the slot."""
+
+    def __init__(self, seed, env_id, episode=0):
+        super().__init__(None)
+        self.seed, self.env_id, self.episode = seed, env_id, episode
+        self.t = 0
+        self.n_random = 0
+
+    def begin_step(self, t):
+        self.n_step = 0
+        self.n_random = 0
+        self.t = t
+
+    def random(self):
+        slot = self.n_random
+        self.n_random += 1
+        u = orc.uniform_pair(self.seed, self.env_id, self.episode, self.t, 0 if slot < 2 else 1)
+        return self._log(u[slot & 1])
+
+    def uniform(self, low, high):
+        u = orc.uniform_pair(self.seed, self.env_id, self.episode, self.t, 1)
+        return self._log(low + (high - low) * u[1])  # NumPy: low + (high-low)*next_double
+
+    def normal(self, loc, scale):
+        z, _ = orc.std_normal(self.seed, self.env_id, self.episode, self.t)
+        return self._log(loc + scale * z)  # NumPy: loc + scale*standard_normal
+
+
+def make_action(servo, tv, mode, on, off, dtype=np.float64):
+    return {
+        "servo": np.array([servo], dtype=dtype),
+        "generator_control": {
+            "target_voltage": np.array([tv], dtype=dtype),
+            "current_mode": np.array([mode], dtype=np.int32),
+            "ON_time": np.array([on], dtype=dtype),
+            "OFF_time": np.array([off], dtype=dtype),
+        },
+    }
+
+
+def action_row(a):
+    g = a["generator_control"]
+    return [float(a["servo"][0]), float(g["target_voltage"][0]), float(g["ON_time"][0]),
+            float(g["OFF_time"][0]), float(int(g["current_mode"][0]))]
+
+
+def snapshot(env, terminated, ctrl, n_draws):
+    s = env.state
+    T = s.wire_temperature
+    y = s.spark_status[1]
+    f = {
+        "workpiece_position": s.workpiece_position, "wire_position": s.wire_position,
+        "wire_velocity": s.wire_velocity,
+        "voltage": 0.0 if s.voltage is None else s.voltage,
+        "current": 0.0 if s.current is None else s.current,
+        "spark_y": math.nan if y is None else y,
+        "debris_volume": env.dielectric.debris_volume, "debris_density": s.debris_density,
+        "flow_rate": s.flow_rate, "cavity_volume": s.cavity_volume,
+        "last_crater_volume": s.last_crater_volume, "prev_accel": env.mechanics.prev_accel,
+        "tmax": float(np.max(T)) if len(T) else math.nan,
+        "h_base": float(env.wire.h_eff_zone[0]),
+        "h_zone": float(env.wire.h_eff_zone[env.wire.actual_zone_start]),
+        "diel_last_gap": env.dielectric._last_gap_um,
+        "diel_last_density": env.dielectric._last_debris_density,
+        "wire_last_flow": env.wire._last_flow_condition,
+    }
+    i = {
+        "time": s.time, "time_since_servo": s.time_since_servo, "spark_state": int(s.spark_status[0]),
+        "spark_dur": int(s.spark_status[2]), "is_short_circuit": int(s.is_short_circuit),
+        "random_short_remaining": env.ignition.random_short_remaining,
+        "debris_short_remaining": env.ignition.debris_short_remaining,
+        "time_in_critical_temp": s.time_in_critical_temp, "is_wire_broken": int(s.is_wire_broken),
+        "is_target_reached": int(s.is_target_distance_reached), "terminated": int(terminated),
+        "ctrl_step": int(ctrl), "n_draws": n_draws,
+        "time_since_spark_ignition": s.time_since_spark_ignition,
+        "time_since_spark_end": s.time_since_spark_end,
+        "time_since_open_voltage": s.time_since_open_voltage,
+    }
+    return f, i
+
+
+def run_scenario(name, *, n_steps, seed=0, config=None, control_mode="position", ignition=None,
+                 wire=None, material=None, dielectric=None, mechanics=None, rng="native", env_id=0,
+                 state_init=None, module_init=None, T_init=None, action=None, action_schedule=None,
+                 controller=None, forced=None, disable_ignition=False, t_snap_every=None,
+                 float_stride=1, stop_on_terminate=True, note=""):
+    """Run one scenario on the reference and write tests/golden/<name>.npz."""
+    config = dict(config or {})
+    mods = {"ignition": dict(ignition or {}), "wire": dict(wire or {}), "material": dict(material or {}),
+            "dielectric": dict(dielectric or {}), "mechanics": dict(mechanics or {})}
+    env = ref_harness.quiet(
+        wedm.WireEDMEnv,
+        mechanics_control_mode=control_mode,
+        config=wedm.EnvironmentConfig(**config),
+        ignition_params=wedm.IgnitionModuleParameters(**mods["ignition"]),
+        wire_params=wedm.WireModuleParameters(**mods["wire"]),
+        material_params=wedm.MaterialModuleParameters(**mods["material"]),
+        dielectric_params=wedm.DielectricModuleParameters(**mods["dielectric"]),
+        mechanics_params=wedm.MechanicsModuleParameters(**mods["mechanics"]),
+    )
+    env.reset(seed=seed)
+    if rng == "native":
+        rec = RecordingRNG(env.np_random)
+    else:
+        rec = PhiloxShim(seed, env_id)
+    env.np_random = rec
+
+    for k, v in (state_init or {}).items():
+        setattr(env.state, k, v)
+    for k, v in (module_init or {}).items():
+        mod, attr = k.split(".")
+        setattr(getattr(env, mod), attr, v)
+    if T_init is not None:
+        # the reference allocates T lazily in the first wire.update (wire.py:264-269)
+        env.state.wire_temperature = np.full(env.wire.n_segments, env.wire.params.spool_T, dtype=np.float32)
+        for lo, hi, val in T_init:
+            env.state.wire_temperature[lo:hi] = val
+    if disable_ignition:
+        env.ignition.update = lambda state, dt=None: None
+
+    actions, action_idx = [], []
+    cur_action = action
+    floats = {k: [] for k in FLOAT_FIELDS}
+    ints = {k: [] for k in INT_FIELDS}
+    float_steps = []
+    t_snaps, t_snap_steps = [], []
+    forced_rows = []
+    raised = None
+
+    for step in range(n_steps):
+        if action_schedule is not None:
+            for at, act in action_schedule:
+                if at == step:
+                    cur_action = act
+        if controller is not None and (step == 0 or ints["ctrl_step"][-1]):
+            cur_action = controller(env)
+        row = action_row(cur_action)
+        if not actions or actions[-1] != row:
+            actions.append(row)
+        action_idx.append(len(actions) - 1)
+
+        if forced is not None:
+            st, y, dur, V, I = forced(step)
+            env.state.spark_status = [st, None if (isinstance(y, float) and math.isnan(y)) else y, dur]
+            env.state.voltage = V
+            env.state.current = I
+            forced_rows.append([st, y, dur, V, I])
+
+        rec.begin_step(env.state.time)
+        try:
+            obs, reward, terminated, truncated, info = env.step(cur_action)
+        except ValueError as exc:
+            raised = (step, str(exc))
+            break
+        ctrl = info.get("control_step", False)  # early return on wire break has no key
+        f, i = snapshot(env, terminated, ctrl, rec.n_step)
+        for k in INT_FIELDS:
+            ints[k].append(i[k])
+        if step % float_stride == 0 or step == n_steps - 1 or terminated:
+            float_steps.append(step)
+            for k in FLOAT_FIELDS:
+                floats[k].append(f[k])
+        if t_snap_every and ((step + 1) % t_snap_every == 0 or terminated):
+            t_snaps.append(env.state.wire_temperature.copy())
+            t_snap_steps.append(step)
+        if terminated and stop_on_terminate:
+            break
+
+    if not t_snaps and len(env.state.wire_temperature):
+        t_snaps.append(env.state.wire_temperature.copy())
+        t_snap_steps.append(len(ints["time"]) - 1)
+
+    meta = {
+        "name": name, "note": note, "seed": seed, "rng": rng, "env_id": env_id,
+        "control_mode": control_mode, "config": config, "modules": mods,
+        "state_init": state_init or {}, "module_init": module_init or {},
+        "T_init": T_init or [], "disable_ignition": disable_ignition, "n_steps_run": len(ints["time"]),
+        "n_seg": int(env.wire.n_segments), "zone": [int(env.wire.zone_start), int(env.wire.zone_end)],
+        "contacts": [int(env.wire.contact_bottom_idx), int(env.wire.contact_top_idx)],
+        "raised": raised, "numpy": np.__version__,
+        "float_fields": FLOAT_FIELDS, "int_fields": INT_FIELDS,
+    }
+    arrays = {
+        "meta": np.array(json.dumps(meta)),
+        "actions": np.array(actions, dtype=np.float64).reshape(-1, 5),
+        "action_idx": np.array(action_idx, dtype=np.int32),
+        "draws": np.array(rec.trace, dtype=np.float64),
+        "float_steps": np.array(float_steps, dtype=np.int32),
+        "floats": np.array([floats[k] for k in FLOAT_FIELDS], dtype=np.float64),
+        "ints": np.array([ints[k] for k in INT_FIELDS], dtype=np.int32),
+        "T_snaps": np.array(t_snaps, dtype=np.float32),
+        "T_snap_steps": np.array(t_snap_steps, dtype=np.int32),
+    }
+    if forced_rows:
+        arrays["forced"] = np.array(forced_rows, dtype=np.float64)
+    OUT.mkdir(parents=True, exist_ok=True)
+    np.savez_compressed(OUT / f"{name}.npz", **arrays)
+    hist = {int(v): int(c) for v, c in zip(*np.unique(arrays["ints"][INT_FIELDS.index("spark_state")], return_counts=True))}
+    print(f"{name:28s} steps={meta['n_steps_run']:6d} draws={len(rec.trace):6d} n_seg={meta['n_seg']} "
+          f"states={hist} raised={raised is not None} "
+          f"size={(OUT / (name + '.npz')).stat().st_size // 1024} KiB")
+    return env
+
+
+# ------------------------------------------------------------------ scenarios
+QUICKSTART = make_action(0.1, 80.0, 5, 3.0, 80.0)  # examples/quickstart.py:25-33
+
+
+def gap_controller(desired_gap=5.0):
+    """experiments/run_simulation.py:24-56 (position and velocity branches)."""
+
+    def controller(env):
+        gap = env.state.workpiece_position - env.state.wire_position
+        error = gap - desired_gap
+        if env.mechanics.control_mode == "position":
+            delta = error * 0.1
+        else:
+            delta = float(np.clip(error * 50.0, -1000.0, 1000.0))
+        return make_action(delta, 80.0, 7, 2.0, 33.0, dtype=np.float32)
+
+    return controller
+
+
+def single_spark_forced(spark_time=50, duration=2, loc=25.0, ocv=80.0):
+    """experiments/single_spark_animation.py:209-251."""
+
+    def forced(step):
+        t = step + 1
+        if spark_time <= t < spark_time + duration:
+            return 1, loc, 1, ocv * 0.3, 60.0
+        return 0, math.nan, 0, ocv, 0.0
+
+    return forced
+
+
+def main():
+    # F1 — BASELINE config 1: brass 0.25 mm wire, seed 0, quickstart action, 10 000 us
+    run_scenario("f1_config1_native", n_steps=10000, seed=0, config={"wire_diameter": 0.25},
+                 action=QUICKSTART, t_snap_every=1000, float_stride=7,
+                 note="BASELINE.json configs[0]; native PCG64 stream, float64 action arrays")
+    run_scenario("f1_config1_f32action", n_steps=4000, seed=0, config={"wire_diameter": 0.25},
+                 action=make_action(0.1, 80.0, 5, 3.0, 80.0, dtype=np.float32), t_snap_every=2000,
+                 float_stride=7, note="same with float32 action leaves (action_space dtype)")
+
+    # F2 — single-spark known-answer test, no RNG
+    run_scenario("f2_single_spark", n_steps=1000, seed=42,
+                 state_init={"workpiece_position": 50.0, "wire_position": 40.0, "target_position": 5000.0,
+                             "wire_unwinding_velocity": 0.0, "dielectric_temperature": 293.15},
+                 T_init=[(0, None, 293.15)], disable_ignition=True, forced=single_spark_forced(),
+                 action=make_action(0.0, 80.0, 13, 2.0, 1000.0, dtype=np.float32),
+                 t_snap_every=50, note="experiments/single_spark_animation.py scenario")
+
+    # F3 — Philox-injected runs (reference consumes the build's variates), several env ids
+    for env_id in (0, 1, 2, 3, 777, 65535):
+        run_scenario(f"f3_philox_env{env_id}", n_steps=6000, seed=1234, rng="philox", env_id=env_id,
+                     state_init={"workpiece_position": 25.0, "wire_position": 10.0, "target_position": 5000.0},
+                     action=QUICKSTART, t_snap_every=2000, float_stride=5,
+                     note="gap 15 um start: frequent sparks; Philox key 1234")
+    run_scenario("f3_philox_config3_env5", n_steps=4000, seed=99, rng="philox", env_id=5,
+                 wire={"segment_len": 0.625},
+                 state_init={"workpiece_position": 22.0, "wire_position": 10.0, "target_position": 5000.0},
+                 action=make_action(0.05, 100.0, 9, 2.0, 20.0), t_snap_every=1000, float_stride=5,
+                 note="BASELINE config 3 grid: segment_len 0.625 -> 128 segments")
+
+    # F5 — edge paths
+    run_scenario("f5_hard_short", n_steps=400, seed=3,
+                 state_init={"workpiece_position": 11.0, "wire_position": 10.0, "target_position": 5000.0},
+                 action=make_action(-0.5, 80.0, 5, 3.0, 80.0), note="gap < 2 um: 51-step shorts, state -1 pulses")
+    run_scenario("f5_debris_short", n_steps=3000, seed=4,
+                 state_init={"workpiece_position": 20.0, "wire_position": 10.0, "target_position": 5000.0},
+                 module_init={"dielectric.debris_volume": 0.0316},
+                 action=make_action(0.0, 80.0, 5, 3.0, 80.0), float_stride=3,
+                 note="debris density ~0.5 at gap 10: sigmoid short model, np.exp branch of fast_exp")
+    run_scenario("f5_random_short", n_steps=3000, seed=5, ignition={"random_short_max_probability": 0.004},
+                 state_init={"workpiece_position": 30.0, "wire_position": 10.0, "target_position": 5000.0},
+                 action=QUICKSTART, float_stride=3, note="random gap-dependent shorts enabled")
+    run_scenario("f5_collision", n_steps=200, seed=6,
+                 state_init={"workpiece_position": 50.0, "wire_position": 149.5, "wire_velocity": 20000.0,
+                             "target_position": 5000.0},
+                 action=make_action(1.0, 80.0, 5, 3.0, 80.0), note="wire > workpiece + 100 -> broken")
+    run_scenario("f5_target_reached", n_steps=4000, seed=7,
+                 state_init={"workpiece_position": 25.0, "wire_position": 10.0, "target_position": 25.002},
+                 action=QUICKSTART, note="workpiece_position >= target_position after a few craters")
+    run_scenario("f5_critical_temp", n_steps=300, seed=8, T_init=[(180, 181, 1502.0), (300, 304, 1100.0)],
+                 action=QUICKSTART, t_snap_every=100, note="hot cells below break: time_in_critical_temp counter")
+    run_scenario("f5_wire_break", n_steps=50, seed=9, T_init=[(180, 186, 1600.0)],
+                 action=QUICKSTART, t_snap_every=1, note="Tmax > 1500 K: early return before mechanics/clocks")
+    sched = [(0, make_action(0.1, 80.0, 5, 3.0, 80.0)), (250, make_action(0.3, 60.0, 7, 2.0, 40.0)),
+             (1000, make_action(-0.2, 120.0, 9, 4.0, 20.0)), (1001, make_action(0.5, 90.0, 3, 1.0, 10.0)),
+             (1500, make_action(0.0, 70.0, 11, 2.5, 33.0)), (2001, make_action(0.25, 100.0, 13, 2.0, 50.0))]
+    run_scenario("f5_action_latch", n_steps=3200, seed=10, action_schedule=sched,
+                 state_init={"workpiece_position": 25.0, "wire_position": 10.0, "target_position": 5000.0},
+                 float_stride=3, note="action latched only at calls 1001, 2001, 3001; non-integer ON time")
+    run_scenario("f5_zero_fallbacks", n_steps=2600, seed=11, action=make_action(0.1, 0.0, 5, 0.0, 0.0),
+                 state_init={"workpiece_position": 25.0, "wire_position": 10.0, "target_position": 5000.0},
+                 float_stride=3, note="0.0 target_voltage/ON/OFF fall back to defaults (`x or default`)")
+    run_scenario("f5_invalid_mode", n_steps=3000, seed=12, action=make_action(0.1, 80.0, 2, 3.0, 80.0),
+                 state_init={"workpiece_position": 20.0, "wire_position": 10.0, "target_position": 5000.0},
+                 float_stride=50, note="even mode: ValueError at the first fresh spark after the latch")
+
+    # F6 — velocity-mode mechanics
+    run_scenario("f6_velocity_mode", n_steps=3000, seed=13, control_mode="velocity",
+                 action=make_action(200.0, 80.0, 5, 3.0, 80.0), float_stride=3,
+                 note="first-order velocity servo")
+    run_scenario("f6_limits", n_steps=1500, seed=14, action=make_action(1.0, 80.0, 5, 3.0, 80.0),
+                 mechanics={"max_acceleration": 2.0e3, "max_jerk": 5.0e6, "max_speed": 1.5},
+                 float_stride=1, note="acceleration, jerk and speed clips all active")
+
+    # F7 — run_simulation.py driver: gap P-controller on the control step
+    run_scenario("f7_gap_controller", n_steps=12000, seed=0, controller=gap_controller(),
+                 state_init={"workpiece_position": 70.0, "wire_position": 10.0, "target_position": 5000.0,
+                             "dielectric_temperature": 293.15},
+                 t_snap_every=4000, float_stride=9,
+                 note="experiments/run_simulation.py:173-297 with the gap controller (float32 leaves)")
+
+    # geometry variants (BASELINE config 5 shapes), short Philox runs
+    for i, (h, d) in enumerate(((10.0, 0.10), (15.0, 0.25), (30.0, 0.30), (12.3, 0.15))):
+        run_scenario(f"f8_geometry_{i}", n_steps=2500, seed=2024, rng="philox", env_id=100 + i,
+                     config={"workpiece_height": h, "wire_diameter": d},
+                     state_init={"workpiece_position": 24.0, "wire_position": 10.0, "target_position": 5000.0},
+                     action=make_action(0.1, 80.0, (1, 7, 15, 17)[i], 3.0, 40.0), t_snap_every=2500,
+                     float_stride=5, note=f"h={h} d={d}")
+
+    # F4 — geometry table straight from WireModule.__init__
+    rows = []
+    for h in (5.0, 10.0, 12.3, 15.0, 20.0, 25.0, 30.0, 47.7):
+        for seg in (0.1, 0.2, 0.25, 0.3, 0.5, 0.625, 1.0):
+            for d in (0.1, 0.2, 0.25, 0.3):
+                for bb, bt, cb, ct in ((30.0, 30.0, 10.0, 10.0), (20.0, 35.0, 5.0, 12.5), (8.0, 8.0, 10.0, 10.0)):
+                    env = ref_harness.quiet(
+                        wedm.WireEDMEnv, config=wedm.EnvironmentConfig(workpiece_height=h, wire_diameter=d),
+                        wire_params=wedm.WireModuleParameters(segment_len=seg, buffer_len_bottom=bb,
+                                                              buffer_len_top=bt, contact_offset_bottom=cb,
+                                                              contact_offset_top=ct))
+                    w = env.wire
+                    rows.append([h, seg, d, bb, bt, cb, ct, w.n_segments, w.zone_start, w.zone_end,
+                                 w.actual_zone_start, w.actual_zone_end, w.contact_bottom_idx, w.contact_top_idx,
+                                 w.k_cond_coeff, w.temp_update_factor, w.A, w.S, w.joule_geom_factor,
+                                 w.critical_temperature, w.breaking_temperature,
+                                 env.dielectric.cavity_volume_coeff, env.dielectric.debris_removal_per_us,
+                                 env.mechanics.damping_coeff, env.mechanics.stiffness_coeff,
+                                 env.mechanics.max_jerk_dt, env.mechanics.dt])
+    cols = ["h", "seg", "d", "buf_bottom", "buf_top", "off_bottom", "off_top", "n_seg", "zone_start", "zone_end",
+            "az_start", "az_end", "contact_bottom", "contact_top", "k_cond", "tuf", "a_surf", "s_area",
+            "joule_geom", "critical_temperature", "breaking_temperature", "cavity_coeff",
+            "debris_removal_per_us", "damping_coeff", "stiffness_coeff", "max_jerk_dt", "dt_s"]
+    np.savez_compressed(OUT / "f4_geometry_table.npz", table=np.array(rows, dtype=np.float64),
+                        columns=np.array(json.dumps(cols)))
+    print(f"f4_geometry_table rows={len(rows)}")
+
+
+if __name__ == "__main__":
+    main()
