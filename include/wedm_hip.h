@@ -192,6 +192,9 @@ typedef struct wedm_params {
     /* sharding: global id of local environment 0 (Philox counter word 2) */
     uint32_t env_id_offset;
     int32_t obs_dim;              /* columns of the obs matrix written at control steps (0 = none) */
+    int32_t disable_ignition;     /* 1: skip IgnitionModule.update — the monkeypatch of
+                                     experiments/single_spark_animation.py:218-223 (spark forced by the caller) */
+    int32_t reserved0;
 } wedm_params;
 
 typedef struct wedm_state_ptrs {
@@ -252,6 +255,16 @@ int32_t wedm_set_kernel(wedm_ctx* ctx, int32_t variant);
 const char* wedm_last_kernel(wedm_ctx* ctx);
 
 const char* wedm_last_error(wedm_ctx* ctx);
+
+/* sizeof(wedm_params) the library was compiled with (layout cross-check for bindings) */
+int64_t wedm_sizeof_params(void);
+
+/* TEST HOOK: evaluates one of the device math primitives the physics relies on,
+ * element-wise on device arrays, so tests can compare them bit for bit with the CPU.
+ * kind: 0 exp, 1 log, 2 correctly-rounded cube, 3 sqrt, 4 Python floor-division
+ * a // b, 5 a / b, 6 Philox uniform pair (u0 + 2*u1) at (time=a, env=b),
+ * 7 Philox polar normal at (time=a, env=b).  Key 0x9abcdef012345678, episode 3.   */
+int32_t wedm_debug_math(int32_t kind, const double* a, const double* b, double* out, int32_t n, void* stream);
 
 #ifdef __cplusplus
 }

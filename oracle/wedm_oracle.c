@@ -1046,6 +1046,7 @@ int32_t wedm_oracle_step_batch(const wedm_params* p, const wedm_state_ptrs* s, c
         v->math_mode = math_mode;
         v->stencil_mode = stencil_mode;
         v->rng.mode = WEDM_ORACLE_RNG_PHILOX;
+        v->disable_ignition = p->disable_ignition;
 #ifdef _OPENMP
 #pragma omp for schedule(static)
 #endif

@@ -167,6 +167,7 @@ class Params(C.Structure):
         ("mode_current", _tab), ("crater_mean", _tab), ("crater_std", _tab), ("crater_depth", _tab),
         ("crater_valid", _itab),
         ("env_id_offset", C.c_uint32), ("obs_dim", _i),
+        ("disable_ignition", _i), ("reserved0", _i),
     ]
 
 

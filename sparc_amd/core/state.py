@@ -1,0 +1,110 @@
+"""``BatchedEDMState`` — the reference's ``EDMState`` (core/state.py:25-91) with a
+leading batch dimension, stored struct-of-arrays for the kernels.
+
+Three field-major blocks hold every mutable scalar (float64 / int32 / int8) and
+one ``[n_seg][stride]`` float32 block holds the wire temperature, environment-minor,
+so that a wavefront's 64 lanes read 64 consecutive elements.  Attribute access keeps
+the reference's names: ``state.workpiece_position`` is a length-``num_envs`` tensor
+view into the float64 block; assigning to it writes through
+(``state.workpiece_position = 70.0`` works like it does on the reference's state).
+"""
+from __future__ import annotations
+
+import torch
+
+from .. import _abi
+from .._abi import F64, I8, I32
+
+# reference attribute name -> (block, row)
+_FIELDS = {
+    "workpiece_position": ("f64", F64.WORKPIECE_POS), "wire_position": ("f64", F64.WIRE_POS),
+    "wire_velocity": ("f64", F64.WIRE_VEL), "wire_unwinding_velocity": ("f64", F64.UNWIND_VEL),
+    "voltage": ("f64", F64.VOLTAGE), "current": ("f64", F64.CURRENT),
+    "target_voltage": ("f64", F64.TARGET_VOLTAGE), "ON_time": ("f64", F64.ON_TIME),
+    "OFF_time": ("f64", F64.OFF_TIME), "target_delta": ("f64", F64.TARGET_DELTA),
+    "target_position": ("f64", F64.TARGET_POS),
+    "debris_volume": ("f64", F64.DEBRIS_VOLUME), "debris_density": ("f64", F64.DEBRIS_DENSITY),
+    "debris_concentration": ("f64", F64.DEBRIS_DENSITY),  # legacy alias, dielectric.py:159
+    "cavity_volume": ("f64", F64.CAVITY), "flow_rate": ("f64", F64.FLOW),
+    "last_crater_volume": ("f64", F64.LAST_CRATER), "spark_location": ("f64", F64.SPARK_Y),
+    "wire_max_temperature": ("f64", F64.TMAX),
+    # module-private state of the reference, exposed for inspection / scenario setup
+    "prev_accel": ("f64", F64.PREV_ACCEL), "dielectric_last_gap": ("f64", F64.LAST_GAP),
+    "dielectric_last_density": ("f64", F64.LAST_DENSITY), "wire_last_flow": ("f64", F64.WIRE_LAST_FLOW),
+    "h_eff_base": ("f64", F64.H_BASE), "h_eff_zone": ("f64", F64.H_ZONE),
+    "time": ("i32", I32.TIME), "time_since_servo": ("i32", I32.SINCE_SERVO),
+    "time_since_open_voltage": ("i32", I32.SINCE_OPEN_V),
+    "time_since_spark_ignition": ("i32", I32.SINCE_IGNITION),
+    "time_since_spark_end": ("i32", I32.SINCE_SPARK_END), "spark_duration": ("i32", I32.SPARK_DUR),
+    "random_short_remaining": ("i32", I32.RANDOM_SHORT_REM),
+    "debris_short_remaining": ("i32", I32.DEBRIS_SHORT_REM),
+    "time_in_critical_temp": ("i32", I32.TIME_CRITICAL), "current_mode": ("i32", I32.CURRENT_MODE),
+    "episode": ("i32", I32.EPISODE), "spark_count": ("i32", I32.SPARK_COUNT),
+    "spark_state": ("i8", I8.SPARK_STATE),
+    "is_short_circuit": ("b", I8.IS_SHORT), "is_wire_broken": ("b", I8.WIRE_BROKEN),
+    "is_target_distance_reached": ("b", I8.TARGET_REACHED), "done": ("b", I8.DONE),
+    "control_step": ("b", I8.CTRL_STEP), "error": ("b", I8.ERROR),
+}
+
+
+class BatchedEDMState:
+    def __init__(self, num_envs: int, n_seg_max: int, obs_dim: int, device):
+        stride = (num_envs + 63) // 64 * 64
+        object.__setattr__(self, "num_envs", num_envs)
+        object.__setattr__(self, "n_seg_max", n_seg_max)
+        object.__setattr__(self, "stride", stride)
+        object.__setattr__(self, "device", device)
+        kw = dict(device=device)
+        object.__setattr__(self, "f64", torch.zeros((_abi.F64_COUNT, stride), dtype=torch.float64, **kw))
+        object.__setattr__(self, "i32", torch.zeros((_abi.I32_COUNT, stride), dtype=torch.int32, **kw))
+        object.__setattr__(self, "i8", torch.zeros((_abi.I8_COUNT, stride), dtype=torch.int8, **kw))
+        object.__setattr__(self, "b", self.i8.view(torch.bool))  # zero-copy 0/1 view of the flags
+        object.__setattr__(self, "T", torch.zeros((n_seg_max, stride), dtype=torch.float32, **kw))
+        object.__setattr__(self, "obs", torch.zeros((max(obs_dim, 1), stride), dtype=torch.float32, **kw))
+
+    # ------------------------------------------------------------------ views
+    def _view(self, name: str) -> torch.Tensor:
+        block, row = _FIELDS[name]
+        return getattr(self, block)[int(row), : self.num_envs]
+
+    def __getattr__(self, name: str):
+        if name in _FIELDS:
+            return self._view(name)
+        raise AttributeError(name)
+
+    def __setattr__(self, name: str, value) -> None:
+        if name in _FIELDS:
+            view = self._view(name)
+            if torch.is_tensor(value):
+                view.copy_(value.to(view.device))
+            else:
+                view.copy_(torch.as_tensor(value, dtype=view.dtype, device=view.device).expand_as(view))
+        elif name == "wire_temperature":
+            self.wire_temperature.copy_(torch.as_tensor(value, dtype=torch.float32, device=self.device))
+        else:
+            raise AttributeError(f"BatchedEDMState has no writable field {name!r}")
+
+    @property
+    def wire_temperature(self) -> torch.Tensor:
+        """``[num_envs, n_seg]`` view (strided: storage is segment-major)."""
+        return self.T[:, : self.num_envs].t()
+
+    @property
+    def spark_status(self):
+        """(state int8[N], y float64[N] with NaN for None, duration int32[N])."""
+        return self._view("spark_state"), self._view("spark_location"), self._view("spark_duration")
+
+    def pointers(self, with_obs: bool) -> _abi.StatePtrs:
+        return _abi.StatePtrs(self.f64.data_ptr(), self.i32.data_ptr(), self.i8.data_ptr(), self.T.data_ptr(),
+                              self.obs.data_ptr() if with_obs else None, self.stride)
+
+    def field_names(self):
+        return tuple(_FIELDS)
+
+    def clone_blocks(self):
+        """Host copies of the raw blocks (used by checkpointing and by the parity tests)."""
+        return {k: getattr(self, k).detach().cpu().clone() for k in ("f64", "i32", "i8", "T", "obs")}
+
+    def load_blocks(self, blocks) -> None:
+        for k in ("f64", "i32", "i8", "T", "obs"):
+            getattr(self, k).copy_(blocks[k].to(self.device))

@@ -1,0 +1,541 @@
+// wedm_device.h — per-lane physics of one Wire-EDM microsecond on gfx950 (CDNA4).
+//
+// One lane owns one environment's scalar state in registers (float64, exactly the
+// reference's Python-float arithmetic) and walks its wire temperature (float32)
+// through an accessor (global memory or LDS).  The five reference modules
+// (ignition -> material -> dielectric -> wire -> mechanics, wire_edm.py:123-132)
+// are fused: everything before the stencil produces six float32 coefficients, the
+// stencil makes ONE pass over the wire, everything after consumes max(T).
+//
+// Bit-exactness rules (compile with -ffp-contract=off -fno-fast-math):
+//   * float64 expressions keep CPython's left-to-right order, no FMA contraction;
+//   * `x**2` is x*x, `x**3` a correctly rounded cube (two explicit fma's), exp/log
+//     are the table-free IEEE-basic-ops versions below — the same expression trees
+//     the CPU oracle evaluates in its PORTABLE math mode;
+//   * the stencil is float32 op-for-op as the reference evaluates wire.py:58-123
+//     under NumPy-2 scalar promotion (every Python float operand cast to float32).
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/wedm_hip.h"
+
+namespace wedm {
+
+// ---------------------------------------------------------------- small helpers
+__device__ __forceinline__ double bits2d(uint64_t u) { return __longlong_as_double((long long)u); }
+__device__ __forceinline__ uint64_t d2bits(double d) { return (uint64_t)__double_as_longlong(d); }
+
+// exp(x) from IEEE basic operations (ln2 hi/lo reduction + degree-5 minimax)
+__device__ __forceinline__ double portable_exp(double x) {
+    const double ln2hi = 6.93147180369123816490e-01, ln2lo = 1.90821492927058770002e-10;
+    const double invln2 = 1.44269504088896338700e+00;
+    const double P1 = 1.66666666666666019037e-01, P2 = -2.77777777770155933842e-03;
+    const double P3 = 6.61375632143793436117e-05, P4 = -1.65339022054652515390e-06;
+    const double P5 = 4.13813679705723846039e-08;
+    if (x != x) return x;
+    if (x > 709.0) return __builtin_huge_val();
+    if (x < -708.0) return 0.0;
+    double hi = x, lo = 0.0;
+    int k = 0;
+    double ax = __builtin_fabs(x);
+    if (ax > 0.34657359027997264) {
+        k = (int)(invln2 * x + (x < 0 ? -0.5 : 0.5));
+        hi = x - (double)k * ln2hi;
+        lo = (double)k * ln2lo;
+        x = hi - lo;
+    } else if (ax < 3.725290298461914e-09) {
+        return 1.0 + x;
+    }
+    double t = x * x;
+    double c = x - t * (P1 + t * (P2 + t * (P3 + t * (P4 + t * P5))));
+    if (k == 0) return 1.0 - ((x * c) / (c - 2.0) - x);
+    double y = 1.0 - ((lo - (x * c) / (2.0 - c)) - hi);
+    return y * bits2d((uint64_t)(k + 1023) << 52);
+}
+
+// log(x) for positive normal x (only use: the polar method's s in (0,1))
+__device__ __forceinline__ double portable_log(double x) {
+    const double ln2hi = 6.93147180369123816490e-01, ln2lo = 1.90821492927058770002e-10;
+    const double Lg1 = 6.666666666666735130e-01, Lg2 = 3.999999999940941908e-01;
+    const double Lg3 = 2.857142874366239149e-01, Lg4 = 2.222219843214978396e-01;
+    const double Lg5 = 1.818357216161805012e-01, Lg6 = 1.531383769920937332e-01;
+    const double Lg7 = 1.479819860511658591e-01;
+    uint64_t ux = d2bits(x);
+    uint32_t hx = (uint32_t)(ux >> 32);
+    int k = (int)(hx >> 20) - 1023;
+    hx &= 0x000fffffu;
+    uint32_t i = (hx + 0x95f64u) & 0x100000u;
+    ux = ((uint64_t)(hx | (i ^ 0x3ff00000u)) << 32) | (ux & 0xffffffffu);
+    k += (int)(i >> 20);
+    double f = bits2d(ux) - 1.0;
+    double dk = (double)k;
+    double hfsq = 0.5 * f * f;
+    double s = f / (2.0 + f);
+    double z = s * s;
+    double w = z * z;
+    double t1 = w * (Lg2 + w * (Lg4 + w * Lg6));
+    double t2 = z * (Lg1 + w * (Lg3 + w * (Lg5 + w * Lg7)));
+    double R = t2 + t1;
+    return dk * ln2hi - ((hfsq - (s * (hfsq + R) + dk * ln2lo)) - f);
+}
+
+// correctly rounded x^3 (double-double product; `(g/g_ref)**3`, dielectric.py:118)
+__device__ __forceinline__ double cube_cr(double x) {
+    double p = x * x, e = __builtin_fma(x, x, -p);
+    double q = p * x, eq = __builtin_fma(p, x, -q);
+    return q + (eq + e * x);
+}
+
+// CPython float `//` (float_divmod); wire.py:290-294 `int(y_spark // segment_len)`
+__device__ __forceinline__ double py_floordiv(double vx, double wx) {
+    double mod = fmod(vx, wx);
+    double div = (vx - mod) / wx;
+    if (mod != 0.0) {
+        if ((wx < 0) != (mod < 0)) {
+            mod += wx;
+            div -= 1.0;
+        }
+    }
+    double fd;
+    if (div != 0.0) {
+        fd = floor(div);
+        if (div - fd > 0.5) fd += 1.0;
+    } else {
+        fd = __builtin_copysign(0.0, vx / wx);
+    }
+    return fd;
+}
+
+// ------------------------------------------------------------------------- RNG
+// Philox4x32-10, counter {time, episode, global env id, stream}, key = reset seed.
+// Counter-based: a variate is a pure function of (seed, env, episode, time, slot),
+// so results do not depend on launch geometry, fusion depth or sharding.
+struct U2 { double a, b; };
+
+__device__ __forceinline__ U2 philox_pair(uint32_t key0, uint32_t key1, uint32_t time, uint32_t episode,
+                                           uint32_t gid, uint32_t stream) {
+    uint32_t c0 = time, c1 = episode, c2 = gid, c3 = stream, k0 = key0, k1 = key1;
+#pragma unroll
+    for (int r = 0; r < 10; ++r) {
+        uint32_t hi0 = __umulhi(0xD2511F53u, c0), lo0 = 0xD2511F53u * c0;
+        uint32_t hi1 = __umulhi(0xCD9E8D57u, c2), lo1 = 0xCD9E8D57u * c2;
+        uint32_t n0 = hi1 ^ c1 ^ k0, n2 = hi0 ^ c3 ^ k1;
+        c0 = n0; c1 = lo1; c2 = n2; c3 = lo0;
+        k0 += 0x9E3779B9u;
+        k1 += 0xBB67AE85u;
+    }
+    U2 u;
+    u.a = ((double)(c0 >> 5) * 67108864.0 + (double)(c1 >> 6)) / 9007199254740992.0;
+    u.b = ((double)(c2 >> 5) * 67108864.0 + (double)(c3 >> 6)) / 9007199254740992.0;
+    return u;
+}
+
+// Marsaglia polar method on Philox streams 2, 3, ... (material.py:127's N(0,1))
+__device__ __forceinline__ double philox_std_normal(uint32_t key0, uint32_t key1, uint32_t time,
+                                                    uint32_t episode, uint32_t gid) {
+    for (uint32_t j = 0; j < 64; ++j) {
+        U2 u = philox_pair(key0, key1, time, episode, gid, 2u + j);
+        double v1 = 2.0 * u.a - 1.0, v2 = 2.0 * u.b - 1.0;
+        double s = v1 * v1 + v2 * v2;
+        if (s < 1.0 && s != 0.0) return v1 * sqrt(-2.0 * portable_log(s) / s);
+    }
+    return 0.0;
+}
+
+// ------------------------------------------------------------- per-lane state
+struct Env {
+    double wp, x, v, prev_a;
+    double debris, rho, flow, last_gap, last_rho, wire_last_flow;
+    double V, I, y, last_crater, cavity;
+    double tdelta, tvolt, on, off, tpos, unwind;
+    double ipk;  // peak current of the latched mode (ignition.py:98-113); derived, not stored
+    float h_base, h_zone, tmax;
+    int32_t time, tss, tsov, tsi, tse, dur, rnd_rem, deb_rem, tcrit, mode, episode, sparks;
+    uint32_t key0, key1;
+    int32_t state;
+    int32_t is_short, broken, reached, done, ctrl, err;
+};
+
+struct Geom {
+    double h, kerf_base, cavity_coeff, s_area, joule_geom;
+    float k, tuf, A;
+    int32_t n_seg, zone_start, az_start, az_end, cb, ct;
+};
+
+// float32 coefficients the scalar prelude hands to the stencil pass
+struct Coef {
+    float jf;        // joule_factor (wire.py:98), 0 when I^2 <= 1e-6
+    float q;         // plasma heat (wire.py:298)
+    float conv_base; // h_eff * A outside the zone (wire.py:109)
+    float conv_zone; // h_eff * A inside the zone
+    float adv;       // advection coefficient (wire.py:304-312)
+    int32_t joule_on, adv_on, pidx;
+};
+
+struct Tables {  // device copies of wedm_params' per-mode tables
+    const double* mode_current;
+    const double* crater_mean;
+    const double* crater_std;
+    const double* crater_depth;
+    const int32_t* crater_valid;
+};
+
+#define WEDM_ROW(ptr, row) ((ptr) + (int64_t)(row) * stride + e)
+
+__device__ __forceinline__ double peak_current(const wedm_params& p, const Tables& tb, int32_t mode) {
+    return (mode >= 1 && mode <= WEDM_MAX_MODE) ? tb.mode_current[mode] : p.default_current;
+}
+
+__device__ __forceinline__ void load_env(const wedm_state_ptrs& s, int64_t e, Env& v) {
+    const int64_t stride = s.stride;
+    v.wp = *WEDM_ROW(s.f64, WEDM_F_WORKPIECE_POS); v.x = *WEDM_ROW(s.f64, WEDM_F_WIRE_POS);
+    v.v = *WEDM_ROW(s.f64, WEDM_F_WIRE_VEL); v.prev_a = *WEDM_ROW(s.f64, WEDM_F_PREV_ACCEL);
+    v.debris = *WEDM_ROW(s.f64, WEDM_F_DEBRIS_VOLUME); v.rho = *WEDM_ROW(s.f64, WEDM_F_DEBRIS_DENSITY);
+    v.flow = *WEDM_ROW(s.f64, WEDM_F_FLOW); v.last_gap = *WEDM_ROW(s.f64, WEDM_F_LAST_GAP);
+    v.last_rho = *WEDM_ROW(s.f64, WEDM_F_LAST_DENSITY); v.wire_last_flow = *WEDM_ROW(s.f64, WEDM_F_WIRE_LAST_FLOW);
+    v.V = *WEDM_ROW(s.f64, WEDM_F_VOLTAGE); v.I = *WEDM_ROW(s.f64, WEDM_F_CURRENT);
+    v.y = *WEDM_ROW(s.f64, WEDM_F_SPARK_Y); v.last_crater = *WEDM_ROW(s.f64, WEDM_F_LAST_CRATER);
+    v.cavity = *WEDM_ROW(s.f64, WEDM_F_CAVITY); v.tdelta = *WEDM_ROW(s.f64, WEDM_F_TARGET_DELTA);
+    v.tvolt = *WEDM_ROW(s.f64, WEDM_F_TARGET_VOLTAGE); v.on = *WEDM_ROW(s.f64, WEDM_F_ON_TIME);
+    v.off = *WEDM_ROW(s.f64, WEDM_F_OFF_TIME); v.tpos = *WEDM_ROW(s.f64, WEDM_F_TARGET_POS);
+    v.unwind = *WEDM_ROW(s.f64, WEDM_F_UNWIND_VEL);
+    v.h_base = (float)*WEDM_ROW(s.f64, WEDM_F_H_BASE); v.h_zone = (float)*WEDM_ROW(s.f64, WEDM_F_H_ZONE);
+    v.tmax = (float)*WEDM_ROW(s.f64, WEDM_F_TMAX);
+    v.time = *WEDM_ROW(s.i32, WEDM_I_TIME); v.tss = *WEDM_ROW(s.i32, WEDM_I_SINCE_SERVO);
+    v.tsov = *WEDM_ROW(s.i32, WEDM_I_SINCE_OPEN_V); v.tsi = *WEDM_ROW(s.i32, WEDM_I_SINCE_IGNITION);
+    v.tse = *WEDM_ROW(s.i32, WEDM_I_SINCE_SPARK_END); v.dur = *WEDM_ROW(s.i32, WEDM_I_SPARK_DUR);
+    v.rnd_rem = *WEDM_ROW(s.i32, WEDM_I_RANDOM_SHORT_REM); v.deb_rem = *WEDM_ROW(s.i32, WEDM_I_DEBRIS_SHORT_REM);
+    v.tcrit = *WEDM_ROW(s.i32, WEDM_I_TIME_CRITICAL); v.mode = *WEDM_ROW(s.i32, WEDM_I_CURRENT_MODE);
+    v.episode = *WEDM_ROW(s.i32, WEDM_I_EPISODE);
+    v.key0 = (uint32_t)*WEDM_ROW(s.i32, WEDM_I_KEY_LO); v.key1 = (uint32_t)*WEDM_ROW(s.i32, WEDM_I_KEY_HI);
+    v.sparks = *WEDM_ROW(s.i32, WEDM_I_SPARK_COUNT);
+    v.state = *WEDM_ROW(s.i8, WEDM_B_SPARK_STATE); v.is_short = *WEDM_ROW(s.i8, WEDM_B_IS_SHORT);
+    v.broken = *WEDM_ROW(s.i8, WEDM_B_WIRE_BROKEN); v.reached = *WEDM_ROW(s.i8, WEDM_B_TARGET_REACHED);
+    v.done = *WEDM_ROW(s.i8, WEDM_B_DONE); v.ctrl = *WEDM_ROW(s.i8, WEDM_B_CTRL_STEP);
+    v.err = *WEDM_ROW(s.i8, WEDM_B_ERROR);
+}
+
+__device__ __forceinline__ void store_env(const wedm_state_ptrs& s, int64_t e, const Env& v) {
+    const int64_t stride = s.stride;
+    *WEDM_ROW(s.f64, WEDM_F_WORKPIECE_POS) = v.wp; *WEDM_ROW(s.f64, WEDM_F_WIRE_POS) = v.x;
+    *WEDM_ROW(s.f64, WEDM_F_WIRE_VEL) = v.v; *WEDM_ROW(s.f64, WEDM_F_PREV_ACCEL) = v.prev_a;
+    *WEDM_ROW(s.f64, WEDM_F_DEBRIS_VOLUME) = v.debris; *WEDM_ROW(s.f64, WEDM_F_DEBRIS_DENSITY) = v.rho;
+    *WEDM_ROW(s.f64, WEDM_F_FLOW) = v.flow; *WEDM_ROW(s.f64, WEDM_F_LAST_GAP) = v.last_gap;
+    *WEDM_ROW(s.f64, WEDM_F_LAST_DENSITY) = v.last_rho; *WEDM_ROW(s.f64, WEDM_F_WIRE_LAST_FLOW) = v.wire_last_flow;
+    *WEDM_ROW(s.f64, WEDM_F_VOLTAGE) = v.V; *WEDM_ROW(s.f64, WEDM_F_CURRENT) = v.I;
+    *WEDM_ROW(s.f64, WEDM_F_SPARK_Y) = v.y; *WEDM_ROW(s.f64, WEDM_F_LAST_CRATER) = v.last_crater;
+    *WEDM_ROW(s.f64, WEDM_F_CAVITY) = v.cavity; *WEDM_ROW(s.f64, WEDM_F_TARGET_DELTA) = v.tdelta;
+    *WEDM_ROW(s.f64, WEDM_F_TARGET_VOLTAGE) = v.tvolt; *WEDM_ROW(s.f64, WEDM_F_ON_TIME) = v.on;
+    *WEDM_ROW(s.f64, WEDM_F_OFF_TIME) = v.off;
+    *WEDM_ROW(s.f64, WEDM_F_H_BASE) = (double)v.h_base; *WEDM_ROW(s.f64, WEDM_F_H_ZONE) = (double)v.h_zone;
+    *WEDM_ROW(s.f64, WEDM_F_TMAX) = (double)v.tmax;
+    *WEDM_ROW(s.i32, WEDM_I_TIME) = v.time; *WEDM_ROW(s.i32, WEDM_I_SINCE_SERVO) = v.tss;
+    *WEDM_ROW(s.i32, WEDM_I_SINCE_OPEN_V) = v.tsov; *WEDM_ROW(s.i32, WEDM_I_SINCE_IGNITION) = v.tsi;
+    *WEDM_ROW(s.i32, WEDM_I_SINCE_SPARK_END) = v.tse; *WEDM_ROW(s.i32, WEDM_I_SPARK_DUR) = v.dur;
+    *WEDM_ROW(s.i32, WEDM_I_RANDOM_SHORT_REM) = v.rnd_rem; *WEDM_ROW(s.i32, WEDM_I_DEBRIS_SHORT_REM) = v.deb_rem;
+    *WEDM_ROW(s.i32, WEDM_I_TIME_CRITICAL) = v.tcrit; *WEDM_ROW(s.i32, WEDM_I_CURRENT_MODE) = v.mode;
+    *WEDM_ROW(s.i32, WEDM_I_SPARK_COUNT) = v.sparks;
+    *WEDM_ROW(s.i8, WEDM_B_SPARK_STATE) = (int8_t)v.state; *WEDM_ROW(s.i8, WEDM_B_IS_SHORT) = (int8_t)v.is_short;
+    *WEDM_ROW(s.i8, WEDM_B_WIRE_BROKEN) = (int8_t)v.broken; *WEDM_ROW(s.i8, WEDM_B_TARGET_REACHED) = (int8_t)v.reached;
+    *WEDM_ROW(s.i8, WEDM_B_DONE) = (int8_t)v.done; *WEDM_ROW(s.i8, WEDM_B_CTRL_STEP) = (int8_t)v.ctrl;
+    *WEDM_ROW(s.i8, WEDM_B_ERROR) = (int8_t)v.err;
+}
+
+__device__ __forceinline__ void load_geom(const wedm_params& p, const wedm_geom_ptrs& gp, int64_t stride,
+                                          int64_t e, Geom& g) {
+    if (p.per_env_geometry) {
+        g.h = *WEDM_ROW(gp.f64, WEDM_G_HEIGHT); g.kerf_base = *WEDM_ROW(gp.f64, WEDM_G_KERF_BASE);
+        g.cavity_coeff = *WEDM_ROW(gp.f64, WEDM_G_CAVITY_COEFF);
+        g.k = (float)*WEDM_ROW(gp.f64, WEDM_G_K_COND); g.tuf = (float)*WEDM_ROW(gp.f64, WEDM_G_TUF);
+        g.A = (float)*WEDM_ROW(gp.f64, WEDM_G_A_SURF); g.s_area = *WEDM_ROW(gp.f64, WEDM_G_S_AREA);
+        g.joule_geom = *WEDM_ROW(gp.f64, WEDM_G_JOULE_GEOM);
+        g.n_seg = *WEDM_ROW(gp.i32, WEDM_GI_N_SEG); g.zone_start = *WEDM_ROW(gp.i32, WEDM_GI_ZONE_START);
+        g.az_start = *WEDM_ROW(gp.i32, WEDM_GI_AZ_START); g.az_end = *WEDM_ROW(gp.i32, WEDM_GI_AZ_END);
+        g.cb = *WEDM_ROW(gp.i32, WEDM_GI_CONTACT_BOTTOM); g.ct = *WEDM_ROW(gp.i32, WEDM_GI_CONTACT_TOP);
+    } else {
+        g.h = p.workpiece_height; g.kerf_base = p.kerf_base; g.cavity_coeff = p.cavity_coeff;
+        g.k = (float)p.k_cond; g.tuf = (float)p.tuf; g.A = (float)p.a_surf; g.s_area = p.s_area;
+        g.joule_geom = p.joule_geom;
+        g.n_seg = p.n_seg; g.zone_start = p.zone_start; g.az_start = p.az_start; g.az_end = p.az_end;
+        g.cb = p.contact_bottom; g.ct = p.contact_top;
+    }
+}
+
+// --------------------------------------------------- scalar prelude (modules 1-4a)
+// wire_edm.py:117-121 latch, ignition.py:175-319, material.py:79-174,
+// dielectric.py:82-163, wire.py:271-312.  Returns the stencil coefficients.
+__device__ __forceinline__ Coef scalar_prelude(const wedm_params& p, const Geom& g, const Tables& tb,
+                                               const wedm_action_ptrs& act, int64_t e, uint32_t gid, Env& s) {
+    // ---- control-step latch (wire_edm.py:117-121,162-170)
+    s.ctrl = s.tss >= p.servo_interval;
+    if (s.ctrl) {
+        s.tdelta = act.servo[e];
+        s.tvolt = act.target_voltage[e];
+        s.mode = act.current_mode[e];
+        s.on = act.on_time[e];
+        s.off = act.off_time[e];
+        s.tss = 0;
+        s.ipk = peak_current(p, tb, s.mode);
+    }
+    const uint32_t t = (uint32_t)s.time, ep = (uint32_t)s.episode;
+
+    if (!p.disable_ignition) {
+    // ---- short-circuit detection (ignition.py:197-245)
+    {
+        double d = s.wp - s.x;
+        double gap = d > 0.0 ? d : 0.0;
+        if (s.rnd_rem > 0) {
+            s.rnd_rem -= 1;
+            s.is_short = 1;
+        } else if (s.deb_rem > 0) {
+            s.deb_rem -= 1;
+            s.is_short = 1;
+        } else {
+            double p_d;  // ignition.py:115-146
+            if (gap < p.hard_short_gap) {
+                p_d = 1.0;
+            } else {
+                double crit = p.base_critical_density + p.gap_coefficient * gap;
+                crit = crit < p.max_critical_density ? crit : p.max_critical_density;
+                double ex = -p.sigmoid_steepness * (s.rho - crit);
+                if (ex > 500) p_d = 0.0;
+                else if (ex < -500) p_d = 1.0;
+                else p_d = 1.0 / (1.0 + portable_exp(ex));
+            }
+            double p_r;
+            if (gap >= p.random_short_max_gap) p_r = 0.0;
+            else if (gap <= p.random_short_min_gap) p_r = p.random_short_max_probability;
+            else
+                p_r = (1.0 - (gap - p.random_short_min_gap) / (p.random_short_max_gap - p.random_short_min_gap)) *
+                      p.random_short_max_probability;
+            U2 u = philox_pair(s.key0, s.key1, t, ep, gid, 0u);
+            if (u.a < p_d) {
+                s.deb_rem = p.debris_short_duration;
+                s.is_short = 1;
+            } else if (u.b < p_r) {
+                s.rnd_rem = p.random_short_duration;
+                s.is_short = 1;
+            } else {
+                s.is_short = 0;
+            }
+        }
+    }
+    if (s.is_short) s.V = 0.0;
+
+    // `x or default` getters (ignition.py:329-343)
+    const double Vt = s.tvolt != 0.0 ? s.tvolt : p.default_target_voltage;
+    const double on = s.on != 0.0 ? s.on : p.default_on_time;
+    const double off = s.off != 0.0 ? s.off : p.default_off_time;
+    const double Ipk = s.ipk;
+
+    // ---- spark state machine (ignition.py:186-195, 247-319)
+    if (s.state == 0) {
+        s.I = 0.0;
+        if (s.is_short) {
+            s.state = -1; s.y = __builtin_nan(""); s.dur = 0;
+            s.I = Ipk;
+        } else {
+            s.V = Vt;
+            double gap = s.wp - s.x;  // unclamped (ignition.py:353)
+            double lam = p.ln2 / (p.ignition_a * (gap * gap) + p.ignition_b * gap + p.ignition_c);
+            U2 u = philox_pair(s.key0, s.key1, t, ep, gid, 1u);
+            if (u.a < lam) {
+                s.y = 0.0 + (g.h - 0.0) * u.b;  // Generator.uniform(0, h)
+                s.state = 1; s.dur = 0;
+                s.V = Vt * p.spark_voltage_factor;
+                s.I = Ipk;
+            }
+        }
+    } else if (s.state == 1) {
+        s.dur += 1;
+        if ((double)s.dur >= on) {
+            s.state = -2; s.I = 0.0;
+            if (!s.is_short) s.V = 0.0;
+        } else {
+            s.I = Ipk;
+            if (!s.is_short) s.V = Vt * p.spark_voltage_factor;
+        }
+    } else if (s.state == -1) {
+        s.dur += 1;
+        if ((double)s.dur >= on) { s.state = -2; s.I = 0.0; }
+        else s.I = Ipk;
+    } else {  // -2 rest
+        s.dur += 1;
+        if ((double)s.dur >= on + off) {
+            s.state = 0; s.y = __builtin_nan(""); s.dur = 0; s.I = 0.0;
+            if (!s.is_short) s.V = Vt;
+        } else {
+            s.I = 0.0;
+            if (!s.is_short) s.V = 0.0;
+        }
+    }
+    }  // !disable_ignition
+    const bool fresh = (s.state == 1) && (s.dur == 0);  // material.py:83, dielectric.py:95
+
+    // ---- material removal (material.py:79-174)
+    if (fresh) {
+        int m = s.mode == 0 ? 1 : s.mode;  // None -> "I1" (material.py:104-105)
+        if (m < 1 || m > WEDM_MAX_MODE || !tb.crater_valid[m]) { s.err = 1; m = 1; }
+        double z = philox_std_normal(s.key0, s.key1, t, ep, gid);
+        double vol = tb.crater_mean[m] + tb.crater_std[m] * z;
+        if (!(vol > 0)) vol = 0;
+        s.sparks += 1;
+        double crater = vol / 1e9;
+        s.last_crater = crater;
+        if (crater > 0) {
+            double kerf = g.kerf_base + tb.crater_depth[m] / 1000.0;
+            double dx = 0.0;
+            if (kerf > 0 && g.h > 0) dx = crater / (kerf * g.h) * 1000.0;
+            s.wp += dx;
+        }
+    } else {
+        s.last_crater = 0.0;
+    }
+
+    // ---- dielectric / debris (dielectric.py:82-163)
+    {
+        double d = s.wp - s.x;
+        double gap_um = d > 0.001 ? d : 0.001;
+        s.cavity = g.cavity_coeff * (gap_um * 0.001);
+        if (fresh && s.last_crater > 0) s.debris += s.last_crater;
+        if (s.cavity > 0) {
+            double q = s.debris / s.cavity;
+            s.rho = q < 1.0 ? q : 1.0;
+        } else {
+            s.rho = 0.0;
+        }
+        if (__builtin_fabs(gap_um - s.last_gap) > 0.01 || __builtin_fabs(s.rho - s.last_rho) > 0.001) {
+            double cube = cube_cr(gap_um / p.reference_gap);
+            double gap_factor = cube < 1.0 ? cube : 1.0;
+            double kd = p.debris_obstruction_coeff * s.rho;
+            double df;
+            if (kd < 2.0) df = kd < 0.5 ? (1 - 0.5 * kd) / (1 + 0.5 * kd) : portable_exp(-kd);
+            else df = portable_exp(-p.debris_obstruction_coeff * s.rho);
+            s.flow = gap_factor * df;
+            s.last_gap = gap_um;
+            s.last_rho = s.rho;
+        }
+        if (s.flow > 0.001 && s.debris > 0.001) {
+            double nv = s.debris - p.debris_removal_per_us * s.flow;
+            s.debris = nv > 0.0 ? nv : 0.0;
+        }
+    }
+
+    // ---- wire prelude (wire.py:271-312, 349-374)
+    Coef c;
+    {
+        const double I = s.I, I2 = I * I;
+        if (__builtin_fabs(s.flow - s.wire_last_flow) > 0.01) {
+            double ve = p.convection_velocity_factor * s.unwind;
+            ve = ve > -0.9 ? ve : -0.9;
+            double hb = p.base_convection * (1.0 + ve);
+            double fl = 0.1 * p.base_convection;
+            hb = fl > hb ? fl : hb;
+            double he = hb * (1.0 + p.convection_flow_enhancement * s.flow);
+            s.h_base = (float)hb;
+            s.h_zone = (float)he;
+            s.wire_last_flow = s.flow;
+        }
+        c.pidx = -1;
+        c.q = 0.0f;
+        if (s.state == 1 && s.y == s.y) {
+            int idx = p.segment_len != 0 ? g.zone_start + (int)py_floordiv(s.y, p.segment_len) : g.zone_start;
+            if (idx >= 0 && idx < g.n_seg) {
+                c.pidx = idx;
+                c.q = (float)(p.plasma_efficiency * s.V * I);
+            }
+        }
+        double adv = 0.0;
+        if (__builtin_fabs(s.unwind) > 1e-6) adv = p.rho_c * __builtin_fabs(s.unwind) * g.s_area;
+        c.adv_on = __builtin_fabs(adv) > 1e-9;
+        c.adv = (float)adv;
+        c.joule_on = I2 > 1e-6;
+        c.jf = (float)(g.joule_geom * I2 * p.rho_elec);
+        c.conv_base = s.h_base * g.A;
+        c.conv_zone = s.h_zone * g.A;
+    }
+    return c;
+}
+
+// one cell of wire.py:58-123, float32 op for op; tm1/tc/tp1 are OLD temperatures
+__device__ __forceinline__ float stencil_cell(int i, int n_seg, float tm1, float tc, float tp1, const Geom& g,
+                                              const Coef& c, float tref, float alpha, float tdiel) {
+    float d;
+    if (i < n_seg - 1) {
+        float t2 = 2.0f * tc;
+        float a = tm1 - t2;
+        d = g.k * (a + tp1);
+    } else {
+        d = g.k * (tm1 - tc);
+    }
+    if (c.joule_on && i >= g.cb && i <= g.ct) {
+        float rho_T = 1.0f + alpha * (tc - tref);
+        d = d + c.jf * rho_T;
+    }
+    if (i == c.pidx) d = d + c.q;
+    bool in_zone = (i >= g.az_start) && (i < g.az_end);
+    float conv = in_zone ? c.conv_zone : c.conv_base;
+    d = d - conv * (tc - tdiel);
+    if (c.adv_on) d = d + c.adv * (tm1 - tc);
+    return tc + d * g.tuf;
+}
+
+// ------------------------------------------- scalar epilogue (modules 4b, 5, env)
+// wire.py:376-388, wire_edm.py:129-146,172-179, mechanics.py:79-114
+__device__ __forceinline__ void scalar_epilogue(const wedm_params& p, Env& s, float tmax) {
+    s.tmax = tmax;
+    if (tmax > (float)p.critical_temperature) s.tcrit += 1;
+    else s.tcrit = 0;
+    if (tmax > (float)p.breaking_temperature) s.broken = 1;
+    if (s.broken) {  // early return before mechanics and clocks
+        s.done = 1;
+        return;
+    }
+    {
+        double x = s.x, v = s.v, a_nom;
+        if (p.control_mode == 0) {
+            double x_error = x - (x + s.tdelta);
+            a_nom = p.damping_coeff * v + p.stiffness_coeff * x_error;
+        } else {
+            a_nom = -p.omega_n * (v - s.tdelta);
+        }
+        if (a_nom > p.max_acceleration) a_nom = p.max_acceleration;
+        else if (a_nom < -p.max_acceleration) a_nom = -p.max_acceleration;
+        double da = a_nom - s.prev_a;
+        if (da > p.max_jerk_dt) da = p.max_jerk_dt;
+        else if (da < -p.max_jerk_dt) da = -p.max_jerk_dt;
+        double a = s.prev_a + da;
+        s.prev_a = a;
+        v += a * p.dt_s;
+        if (v > p.max_speed) v = p.max_speed;
+        else if (v < -p.max_speed) v = -p.max_speed;
+        x += v * p.dt_s;
+        s.v = v;
+        s.x = x;
+    }
+    s.time += p.dt_us;
+    s.tss += p.dt_us;
+    s.tsov += p.dt_us;
+    if (s.state == 1) { s.tsi += p.dt_us; s.tse = 0; }
+    else { s.tse += p.dt_us; s.tsi = 0; }
+    if (s.x > s.wp + 100) { s.broken = 1; s.done = 1; }
+    else if (s.wp >= s.tpos) { s.reached = 1; s.done = 1; }
+}
+
+__device__ __forceinline__ void write_obs(const wedm_params& p, const wedm_state_ptrs& st, int64_t e, const Env& s) {
+    if (!st.obs || p.obs_dim < 8) return;
+    const int64_t stride = st.stride;
+    float* o = st.obs + e;
+    o[0 * stride] = (float)(s.wp - s.x);
+    o[1 * stride] = (float)s.v;
+    o[2 * stride] = (float)s.V;
+    o[3 * stride] = (float)s.I;
+    o[4 * stride] = (float)s.state;
+    o[5 * stride] = (float)s.rho;
+    o[6 * stride] = (float)s.flow;
+    o[7 * stride] = s.tmax;
+}
+
+}  // namespace wedm

@@ -1,0 +1,329 @@
+"""Batched ``WireEDMEnv`` — the reference's Gymnasium surface
+(envs/wire_edm.py:16-201) with a leading batch dimension, advanced by one fused HIP
+kernel on an MI355X.
+
+Same constructor keywords, same ``reset(seed=, options=)`` / ``step(action)`` tuples,
+same ``EnvironmentConfig`` and ``*ModuleParameters``; additionally ``num_envs`` and
+``device``.  Every per-environment scalar of the reference becomes a length-N tensor
+(``env.state.workpiece_position`` ...), ``terminated``/``truncated`` are ``bool[N]``,
+``info`` carries the reference's five keys as tensors.
+
+Documented deviations from the single-environment reference:
+  * ``reset`` also resets module-private state (short timers, debris, caches,
+    ``prev_accel``); the reference leaks it across episodes;
+  * a terminated environment is frozen until it is reset;
+  * a ``current_mode`` without crater data raises ``ValueError`` when the action is
+    passed to ``step`` (the reference raises at the first fresh spark after the latch);
+  * ``obs`` is a fixed float32 vector (the reference returns ``{}``), refreshed at
+    control steps; ``reward`` is 0 as in the reference;
+  * randomness is a counter-based Philox4x32-10 stream per environment, not NumPy's
+    PCG64: same distributions, different variates for the same seed.
+"""
+from __future__ import annotations
+
+import os
+from types import SimpleNamespace
+from typing import Any, Callable, Dict, Optional
+
+import numpy as np
+import torch
+
+from .. import _abi
+from ..core import derive
+from ..core.env_config import EnvironmentConfig
+from ..core.material_db import get_material_db
+from ..core.state import BatchedEDMState
+from ..core.tables import CRATER, MODE_CURRENT, VALID_CRATER_MODES
+from ..modules.parameters import (
+    DielectricModuleParameters,
+    IgnitionModuleParameters,
+    MaterialModuleParameters,
+    MechanicsModuleParameters,
+    WireModuleParameters,
+)
+
+
+class Box:
+    """Minimal stand-in for ``gymnasium.spaces.Box`` (gymnasium is optional)."""
+
+    def __init__(self, low, high, shape, dtype=np.float32):
+        self.low, self.high, self.shape, self.dtype = low, high, tuple(shape), np.dtype(dtype)
+
+    def sample(self, rng: Optional[np.random.Generator] = None):
+        rng = rng or np.random.default_rng()
+        if np.issubdtype(self.dtype, np.integer):
+            return rng.integers(int(self.low), int(self.high) + 1, size=self.shape).astype(self.dtype)
+        return rng.uniform(self.low, self.high, size=self.shape).astype(self.dtype)
+
+    def __repr__(self):
+        return f"Box({self.low}, {self.high}, {self.shape}, {self.dtype})"
+
+
+class DictSpace(dict):
+    """Minimal stand-in for ``gymnasium.spaces.Dict``."""
+
+    def sample(self, rng: Optional[np.random.Generator] = None):
+        return {k: v.sample(rng) for k, v in self.items()}
+
+
+class DeviceAction:
+    """An action already laid out for the kernel: five contiguous length-N device
+    tensors (float64 x4, int32).  Build it once with ``env.make_action`` and pass it
+    to ``step`` to avoid per-step host->device conversion."""
+
+    __slots__ = ("servo", "target_voltage", "on_time", "off_time", "current_mode", "ptrs")
+
+    def __init__(self, servo, target_voltage, on_time, off_time, current_mode):
+        self.servo, self.target_voltage, self.on_time, self.off_time = servo, target_voltage, on_time, off_time
+        self.current_mode = current_mode
+        self.ptrs = _abi.ActionPtrs(servo.data_ptr(), target_voltage.data_ptr(), on_time.data_ptr(),
+                                    off_time.data_ptr(), current_mode.data_ptr())
+
+
+class WireEDMEnv:
+    """Main-cut Wire-EDM environment, N environments in lock-step (1 us base step,
+    1 ms control step).  See the module docstring."""
+
+    metadata = {"render_modes": ["human"], "render_fps": 300}
+
+    def __init__(
+        self,
+        *,
+        num_envs: int = 1,
+        device: Any = None,
+        render_mode: Optional[str] = None,
+        mechanics_control_mode: str = "position",
+        config: Optional[EnvironmentConfig] = None,
+        ignition_params: Optional[IgnitionModuleParameters] = None,
+        wire_params: Optional[WireModuleParameters] = None,
+        material_params: Optional[MaterialModuleParameters] = None,
+        dielectric_params: Optional[DielectricModuleParameters] = None,
+        mechanics_params: Optional[MechanicsModuleParameters] = None,
+        workpiece_height=None,
+        wire_diameter=None,
+        env_id_offset: int = 0,
+        disable_ignition: bool = False,
+        strict_actions: bool = True,
+        backend: Optional[Callable] = None,
+    ):
+        self.render_mode = render_mode
+        if mechanics_control_mode not in ["position", "velocity"]:
+            raise ValueError(f"mechanics_control_mode must be 'position' or 'velocity', got {mechanics_control_mode}")
+        self.mechanics_control_mode = mechanics_control_mode
+        if int(num_envs) <= 0:
+            raise ValueError("num_envs must be positive")
+        self.num_envs = int(num_envs)
+
+        self.config = config or EnvironmentConfig()
+        self.config.validate()
+        self.dt = self.config.dt
+        self.servo_interval = self.config.servo_interval
+
+        self.ignition_params = ignition_params or IgnitionModuleParameters()
+        self.wire_params = wire_params or WireModuleParameters()
+        self.material_params = material_params or MaterialModuleParameters()
+        self.dielectric_params = dielectric_params or DielectricModuleParameters()
+        self.mechanics_params = mechanics_params or MechanicsModuleParameters()
+        self.wire_material = get_material_db().get_wire_material(self.config.wire_material)
+
+        if device is None:
+            device = "cuda" if torch.cuda.is_available() else "cpu"
+        self.device = torch.device(device)
+        if self.device.type == "cuda" and self.device.index is None:
+            self.device = torch.device("cuda", torch.cuda.current_device())
+        self.np_random = np.random.default_rng()
+        self.strict_actions = bool(strict_actions)
+        self.env_id_offset = int(env_id_offset)
+
+        # ---- geometry: uniform (reference behaviour) or one (h, d) pair per environment
+        stride = (self.num_envs + 63) // 64 * 64
+        self.per_env_geometry = workpiece_height is not None or wire_diameter is not None
+        if self.per_env_geometry:
+            h = np.broadcast_to(np.asarray(self.config.workpiece_height if workpiece_height is None
+                                           else _to_numpy(workpiece_height), dtype=np.float64), (self.num_envs,))
+            d = np.broadcast_to(np.asarray(self.config.wire_diameter if wire_diameter is None
+                                           else _to_numpy(wire_diameter), dtype=np.float64), (self.num_envs,))
+            gf, gi, n_seg_max = derive.geometry_rows(h, d, self.wire_params, self.wire_material,
+                                                     self.material_params, stride)
+            self.geometry = None
+            self._geom_f64 = torch.from_numpy(gf).to(self.device)
+            self._geom_i32 = torch.from_numpy(gi).to(self.device)
+            self.n_segments = n_seg_max
+        else:
+            self.geometry = derive.derive_geometry(self.config.workpiece_height, self.config.wire_diameter,
+                                                   self.wire_params, self.wire_material, self.material_params)
+            self.n_segments = self.geometry.n_seg
+        self.params = derive.build_params(
+            self.config, mechanics_control_mode, self.ignition_params, self.wire_params, self.material_params,
+            self.dielectric_params, self.mechanics_params, self.wire_material, geometry=self.geometry,
+            env_id_offset=self.env_id_offset, obs_dim=_abi.OBS_DIM, disable_ignition=disable_ignition)
+
+        # ---- state (caller-owned memory) + backend
+        self.state = BatchedEDMState(self.num_envs, self.n_segments, _abi.OBS_DIM, self.device)
+        if backend is None:
+            from .._lib import HipBackend
+
+            backend = HipBackend
+        self._backend = backend(self.params, self.num_envs, self.n_segments, self.device)
+        self._backend.bind_state(self.state.pointers(with_obs=True))
+        if self.per_env_geometry:
+            self._backend.bind_geometry(_abi.GeomPtrs(self._geom_f64.data_ptr(), self._geom_i32.data_ptr()))
+
+        # lightweight views where the reference exposes module objects
+        self.ignition = SimpleNamespace(params=self.ignition_params)
+        self.wire = SimpleNamespace(params=self.wire_params, n_segments=self.n_segments,
+                                    wire_material=self.wire_material, geometry=self.geometry)
+        self.material = SimpleNamespace(params=self.material_params, crater_data=CRATER, currents_data=MODE_CURRENT)
+        self.dielectric = SimpleNamespace(params=self.dielectric_params)
+        self.mechanics = SimpleNamespace(params=self.mechanics_params, control_mode=mechanics_control_mode)
+        self.modules = {"ignition": self.ignition, "material": self.material, "dielectric": self.dielectric,
+                        "wire": self.wire, "mechanics": self.mechanics}
+
+        # ---- spaces (wire_edm.py:84-101); obs is this build's fixed vector
+        self.action_space = DictSpace({
+            "servo": Box(-1.0, 1.0, (1,), np.float32),
+            "generator_control": DictSpace({
+                "target_voltage": Box(0.0, 200.0, (1,), np.float32),
+                "current_mode": Box(1, 19, (1,), np.int32),
+                "ON_time": Box(0.0, 5.0, (1,), np.float32),
+                "OFF_time": Box(0.0, 100.0, (1,), np.float32),
+            }),
+        })
+        self.observation_space = Box(-np.inf, np.inf, (_abi.OBS_DIM,), np.float32)
+        self.single_action_space = self.action_space
+        self.single_observation_space = self.observation_space
+
+        self._reward = torch.zeros(self.num_envs, dtype=torch.float32, device=self.device)
+        self._truncated = torch.zeros(self.num_envs, dtype=torch.bool, device=self.device)
+        self._mask_buf = None
+        self._seed = int.from_bytes(os.urandom(8), "little")
+        self._backend.reset(None, self._seed, True)
+
+    # ------------------------------------------------------------------ Gym API
+    def reset(self, *, seed: Optional[int] = None, options: Optional[Dict[str, Any]] = None):
+        """``WireEDMEnv.reset`` (wire_edm.py:106-114).  ``options={"mask": bool[N]}``
+        resets only the selected environments."""
+        mask_ptr = None
+        if options and options.get("mask") is not None:
+            mask = torch.as_tensor(options["mask"]).to(self.device).reshape(-1).to(torch.uint8).contiguous()
+            if mask.numel() != self.num_envs:
+                raise ValueError("options['mask'] must have one entry per environment")
+            self._mask_buf = mask  # keep alive until the launch has consumed it
+            mask_ptr = mask.data_ptr()
+        if seed is not None:
+            self._seed = int(seed)
+            self.np_random = np.random.default_rng(seed)
+            self._backend.reset(mask_ptr, self._seed, True)
+        else:
+            self._backend.reset(mask_ptr, self._seed, False)
+        return self._get_obs(), {}
+
+    def step(self, action):
+        """One 1-us physics step for every environment (wire_edm.py:116-157)."""
+        return self.step_many(action, 1)
+
+    def step_many(self, action, n_substeps: int):
+        """``n_substeps`` consecutive ``step(action)`` calls in ONE fused kernel launch."""
+        act = self._prepare_action(action)
+        self._last_action = act  # keep the tensors alive while the launch is in flight
+        self._backend.step(int(n_substeps), act.ptrs)
+        st = self.state
+        info = {
+            "wire_broken": st.is_wire_broken,
+            "target_reached": st.is_target_distance_reached,
+            "spark_state": st.spark_state,
+            "time": st.time,
+            "control_step": st.control_step,
+        }
+        return self._get_obs(), self._reward, st.done, self._truncated, info
+
+    def step_control(self, action):
+        """One control interval (``servo_interval`` physics steps, default 1000)."""
+        return self.step_many(action, self.servo_interval // self.dt)
+
+    def close(self) -> None:
+        self._backend.close()
+
+    # ------------------------------------------------------------------ helpers
+    def make_action(self, servo=0.0, target_voltage=80.0, current_mode=5, ON_time=3.0, OFF_time=80.0) -> DeviceAction:
+        return self._prepare_action({
+            "servo": servo,
+            "generator_control": {"target_voltage": target_voltage, "current_mode": current_mode,
+                                  "ON_time": ON_time, "OFF_time": OFF_time},
+        })
+
+    def _leaf(self, value, dtype) -> torch.Tensor:
+        if torch.is_tensor(value):
+            t = value.to(device=self.device, dtype=dtype).reshape(-1)
+        else:
+            arr = np.asarray(value)
+            t = torch.from_numpy(np.ascontiguousarray(arr.reshape(-1))).to(device=self.device, dtype=dtype)
+        if t.numel() == 1:
+            t = t.expand(self.num_envs)
+        elif t.numel() != self.num_envs:
+            raise ValueError(f"action leaf has {t.numel()} values, expected 1 or num_envs={self.num_envs}")
+        return t.contiguous()
+
+    def _prepare_action(self, action) -> DeviceAction:
+        if isinstance(action, DeviceAction):
+            return action
+        gc = action["generator_control"]
+        mode = gc["current_mode"]
+        if self.strict_actions:
+            self._validate_modes(mode)
+        return DeviceAction(
+            self._leaf(action["servo"], torch.float64),
+            self._leaf(gc["target_voltage"], torch.float64),
+            self._leaf(gc["ON_time"], torch.float64),
+            self._leaf(gc["OFF_time"], torch.float64),
+            self._leaf(mode, torch.int32),
+        )
+
+    def _validate_modes(self, mode) -> None:
+        """Mirror of material.py:108-113: modes without crater data are an error."""
+        vals = mode.detach().cpu().numpy() if torch.is_tensor(mode) else np.asarray(mode)
+        bad = sorted({int(v) for v in np.unique(vals.reshape(-1)) if int(v) not in VALID_CRATER_MODES})
+        if bad:
+            raise ValueError(
+                f"Current mode I{bad[0]} is not available in crater data. "
+                f"Available modes: {[f'I{m}' for m in VALID_CRATER_MODES]}"
+            )
+
+    def _get_obs(self) -> torch.Tensor:
+        """``float32[num_envs, 8]``: gap, wire_velocity, voltage, current, spark_state,
+        debris_density, flow_rate, max wire temperature — as of each environment's last
+        control step (the reference's ``_get_obs`` is a TODO, wire_edm.py:181-183)."""
+        return self.state.obs[:, : self.num_envs].t()
+
+    def check_errors(self) -> None:
+        """Synchronising check of the sticky per-environment error flag."""
+        if bool(self.state.error.any().item()):
+            idx = int(torch.nonzero(self.state.error)[0].item())
+            raise ValueError(f"environment {idx}: fresh spark with a current mode that has no crater data")
+
+    def set_kernel(self, variant: int) -> None:
+        """0 = auto, 1 = global-memory stencil, 2 = LDS-staged fused stencil."""
+        self._backend.set_kernel(variant)
+
+    def zone_mean_temperature(self) -> torch.Tensor:
+        """Mean wire temperature over the workpiece zone (wire.py:390-398), per environment."""
+        if self.geometry is None:
+            raise NotImplementedError("zone mean needs uniform geometry")
+        g = self.geometry
+        lo, hi = g.az_start, g.az_end
+        T = self.state.T[:, : self.num_envs]
+        if hi > lo:
+            return T[lo:hi].mean(dim=0)
+        return T[: g.n_seg].mean(dim=0)
+
+    @property
+    def workpiece_height(self) -> float:
+        return self.config.workpiece_height
+
+    @property
+    def wire_diameter(self) -> float:
+        return self.config.wire_diameter
+
+
+def _to_numpy(x):
+    return x.detach().cpu().numpy() if torch.is_tensor(x) else np.asarray(x)

@@ -1,0 +1,70 @@
+"""A backend that drives ``sparc_amd.WireEDMEnv`` with the CPU oracle on CPU tensors.
+
+TEST SEAM ONLY: it lives under tests/, is injected explicitly
+(``WireEDMEnv(..., device="cpu", backend=OracleBackend)``) and is never selected by the
+product, whose only backend is the HIP library.  It lets the CPU suite exercise the
+host logic (action plumbing, state views, sharding) and gives the GPU tests the
+reference result for the same SoA blocks.
+"""
+from __future__ import annotations
+
+import ctypes as C
+
+import numpy as np
+
+from oracle import oracle as orc
+from sparc_amd import _abi
+
+
+class OracleBackend:
+    name = "oracle"
+    math_mode = orc.MATH_PORTABLE
+    stencil_mode = orc.STENCIL_F32
+    n_threads = 0
+
+    def __init__(self, params, num_envs, n_seg_max, device):
+        assert device.type == "cpu", "the oracle backend works on host memory"
+        self.params = params
+        self.num_envs = num_envs
+        self.n_seg_max = n_seg_max
+        self.state = None
+        self.geom = _abi.GeomPtrs(None, None)
+        self._L = orc.lib()
+
+    def bind_state(self, ptrs):
+        self.state = ptrs
+
+    def bind_geometry(self, ptrs):
+        self.geom = ptrs
+
+    def reset(self, mask_ptr, seed, reseed):
+        rc = self._L.wedm_oracle_reset_batch(C.byref(self.params), C.byref(self.state), self.num_envs,
+                                             mask_ptr, seed & (2**64 - 1), 1 if reseed else 0)
+        assert rc == 0, rc
+        # like wedm_reset: all n_seg_max temperature rows at the spool temperature, obs zeroed
+        stride = self.state.stride
+        T = np.ctypeslib.as_array(C.cast(self.state.T, C.POINTER(C.c_float)), shape=(self.n_seg_max, stride))
+        obs = np.ctypeslib.as_array(C.cast(self.state.obs, C.POINTER(C.c_float)),
+                                    shape=(self.params.obs_dim, stride))
+        if mask_ptr is None:
+            T[:, : self.num_envs] = np.float32(self.params.spool_T)
+            obs[:, : self.num_envs] = 0
+        else:
+            m = np.ctypeslib.as_array(C.cast(mask_ptr, C.POINTER(C.c_uint8)), shape=(self.num_envs,)).astype(bool)
+            T[:, : self.num_envs][:, m] = np.float32(self.params.spool_T)
+            obs[:, : self.num_envs][:, m] = 0
+
+    def step(self, n_substeps, action):
+        rc = self._L.wedm_oracle_step_batch(C.byref(self.params), C.byref(self.state), C.byref(self.geom),
+                                            C.byref(action), self.num_envs, n_substeps, self.math_mode,
+                                            self.stencil_mode, self.n_threads)
+        assert rc == 0, rc
+
+    def set_kernel(self, variant):
+        pass
+
+    def last_kernel(self):
+        return "oracle"
+
+    def close(self):
+        pass

@@ -1,0 +1,354 @@
+"""Parity of the HIP path (through the C-ABI) with the CPU oracle, on a real MI355X.
+
+Every comparison is BIT-EXACT over all state blocks (float64 scalars, int32/int8
+state, float32 wire temperatures, observations): the kernels evaluate the same IEEE
+expression trees as the oracle's PORTABLE math mode, which tests/test_oracle_golden.py
+ties to the reference (exact decisions, <=1e-12 relative on float64 state, <=1e-4 K)."""
+from __future__ import annotations
+
+import ctypes as C
+import json
+
+import numpy as np
+import pytest
+import torch
+
+from sparc_amd import (EnvironmentConfig, IgnitionModuleParameters, MechanicsModuleParameters, WireEDMEnv,
+                       WireModuleParameters)
+from tests._compare import assert_blocks_equal, block_diffs
+from tests._oracle_backend import OracleBackend
+
+pytestmark = pytest.mark.gpu
+
+
+def make_pair(n, **kw):
+    gpu = WireEDMEnv(num_envs=n, device="cuda:0", **kw)
+    cpu = WireEDMEnv(num_envs=n, device="cpu", backend=OracleBackend, **kw)
+    return gpu, cpu
+
+
+def both(envs, fn):
+    for e in envs:
+        fn(e)
+
+
+def check(gpu, cpu, n):
+    torch.cuda.synchronize()
+    assert_blocks_equal(gpu.state.clone_blocks(), cpu.state.clone_blocks(), n)
+
+
+def close_gap(env, wp=25.0, x=10.0, target=5000.0):
+    env.state.workpiece_position = wp
+    env.state.wire_position = x
+    env.state.target_position = target
+
+
+def test_native_library_is_the_one_running():
+    env = WireEDMEnv(num_envs=64, device="cuda:0")
+    assert env._backend.name == "hip"
+    env.reset(seed=1)
+    env.step(env.make_action())
+    assert "wedm_step_global" in env._backend.last_kernel()
+    env.step_many(env.make_action(), 10)
+    assert "wedm_step_lds" in env._backend.last_kernel()
+
+
+@pytest.mark.parametrize("kind", [0, 1, 2, 3, 4, 5, 6, 7])
+def test_device_math_primitives_match_cpu_bit_for_bit(orc, kind):
+    """exp/log/cube are IEEE-basic-op expression trees; sqrt, division and fmod-based
+    floor division must be correctly rounded on the device; Philox must match."""
+    from sparc_amd import _lib
+
+    L = _lib.load()
+    rng = np.random.default_rng(kind)
+    n = 1 << 16
+    if kind == 0:
+        a = rng.uniform(-600, 600, n); b = np.zeros(n)
+    elif kind == 1:
+        a = np.concatenate([rng.uniform(0, 1, n // 2), 2.0 ** rng.uniform(-104, 0, n // 2)]); b = np.zeros(n)
+    elif kind == 2:
+        a = rng.uniform(0, 8, n); b = np.zeros(n)
+    elif kind == 3:
+        a = np.concatenate([rng.uniform(0, 4, n // 2), 10.0 ** rng.uniform(-30, 30, n // 2)]); b = np.zeros(n)
+    elif kind == 4:
+        a = rng.uniform(0, 40, n); b = rng.choice([0.1, 0.2, 0.25, 0.3, 0.5, 0.625, 1.0], n)
+        a[:64] = np.arange(64) * 0.2  # exact-multiple edge cases
+        b[:64] = 0.2
+    elif kind == 5:
+        a = rng.uniform(-1e3, 1e3, n); b = rng.uniform(1e-3, 1e3, n)
+    else:
+        a = rng.integers(0, 2**31, n).astype(np.float64); b = rng.integers(0, 2**31, n).astype(np.float64)
+    ta, tb = torch.from_numpy(a).cuda(), torch.from_numpy(b).cuda()
+    out = torch.empty(n, dtype=torch.float64, device="cuda")
+    assert L.wedm_debug_math(kind, ta.data_ptr(), tb.data_ptr(), out.data_ptr(), n, None) == 0
+    torch.cuda.synchronize()
+    got = out.cpu().numpy()
+    o = orc.lib()
+    if kind == 0:
+        want = np.array([o.wedm_oracle_exp(x, orc.MATH_PORTABLE) for x in a])
+    elif kind == 1:
+        want = np.array([o.wedm_oracle_log(x, orc.MATH_PORTABLE) for x in a])
+    elif kind == 2:
+        want = np.array([o.wedm_oracle_cube(x, orc.MATH_PORTABLE) for x in a])
+    elif kind == 3:
+        want = np.sqrt(a)
+    elif kind == 4:
+        want = np.array([o.wedm_oracle_py_floordiv(x, y) for x, y in zip(a, b)])
+        assert np.array_equal(want, np.array([x // y for x, y in zip(a.tolist(), b.tolist())]))
+    elif kind == 5:
+        want = a / b
+    elif kind == 6:
+        want = np.array([(lambda u: u[0] + 2.0 * u[1])(orc.uniform_pair(0x9abcdef012345678, int(y), 3, int(x), 1))
+                         for x, y in zip(a[:4096], b[:4096])])
+        got = got[:4096]
+    else:
+        want = np.array([orc.std_normal(0x9abcdef012345678, int(y), 3, int(x))[0] for x, y in zip(a[:4096], b[:4096])])
+        got = got[:4096]
+    assert np.array_equal(got.view(np.uint64), want.view(np.uint64)), \
+        f"kind {kind}: {np.count_nonzero(got.view(np.uint64) != want.view(np.uint64))} of {len(want)} differ"
+
+
+@pytest.mark.parametrize("variant", [1, 2])
+def test_default_config_fused_matches_oracle(variant):
+    """BASELINE config 2 shape (S=400): 3 control intervals, both kernels."""
+    n = 320
+    gpu, cpu = make_pair(n)
+    gpu.set_kernel(variant)
+    both((gpu, cpu), lambda e: (e.reset(seed=1234), close_gap(e)))
+    for env in (gpu, cpu):
+        a = env.make_action(0.1, 80.0, 5, 3.0, 80.0)
+        for _ in range(3):
+            env.step_many(a, 1000)
+    check(gpu, cpu, n)
+    assert int(gpu.state.spark_count.sum()) > 100
+
+
+def test_single_microsecond_steps_with_changing_actions():
+    """The reference's own call pattern: one step() per microsecond, action latched
+    only at control steps (wire_edm.py:117-121)."""
+    n = 100  # not a multiple of 64
+    gpu, cpu = make_pair(n)
+    both((gpu, cpu), lambda e: (e.reset(seed=5), close_gap(e, 22.0, 10.0)))
+    rng = np.random.default_rng(0)
+    modes = rng.choice([1, 3, 5, 7, 9, 11, 13, 15, 17], size=(3, n)).astype(np.int32)
+    servo = rng.uniform(-0.5, 0.5, size=(3, n))
+    for step in range(2300):
+        k = step // 900
+        act = {"servo": servo[k], "generator_control": {
+            "target_voltage": np.float32(60 + 20 * k), "current_mode": modes[k],
+            "ON_time": np.array([2.5]), "OFF_time": np.array([10.0 + 15 * k])}}
+        og, rg, tg, ug, ig = gpu.step(act)
+        oc, rc, tc, uc, ic = cpu.step(act)
+    check(gpu, cpu, n)
+    assert torch.equal(ig["control_step"].cpu(), ic["control_step"])
+    assert torch.equal(tg.cpu(), tc)
+
+
+def test_config3_grid_128_segments():
+    """BASELINE config 3: segment_len 0.625 -> 128 segments."""
+    n = 1024
+    kw = dict(wire_params=WireModuleParameters(segment_len=0.625))
+    gpu, cpu = make_pair(n, **kw)
+    assert gpu.n_segments == 128
+    both((gpu, cpu), lambda e: (e.reset(seed=99), close_gap(e, 22.0, 10.0)))
+    for env in (gpu, cpu):
+        a = env.make_action(0.05, 100.0, 9, 2.0, 20.0)
+        env.step_many(a, 1)
+        env.step_many(a, 2499)
+    check(gpu, cpu, n)
+
+
+def test_per_environment_geometry_config5():
+    """BASELINE config 5: per-env workpiece_height / wire_diameter / current_mode."""
+    n = 192
+    rng = np.random.default_rng(2024)
+    h = rng.uniform(10.0, 30.0, n)
+    d = rng.choice([0.10, 0.15, 0.20, 0.25, 0.30], n)
+    mode = rng.choice([1, 3, 5, 7, 9, 11, 13, 15, 17], n).astype(np.int32)
+    kw = dict(workpiece_height=h, wire_diameter=d, config=EnvironmentConfig(target_cutting_distance=5000.0))
+    gpu, cpu = make_pair(n, **kw)
+    assert gpu.n_segments == cpu.n_segments and 350 <= gpu.n_segments <= 450
+    both((gpu, cpu), lambda e: (e.reset(seed=2024), close_gap(e, 24.0, 10.0)))
+    for variant in (1, 2):
+        gpu.set_kernel(variant)
+        for env in (gpu, cpu):
+            a = env.make_action(0.1, 80.0, mode, 3.0, 40.0)
+            env.step_many(a, 1100)
+        check(gpu, cpu, n)
+
+
+SCENARIOS = {
+    "hard_short": dict(init=lambda e: close_gap(e, 11.0, 10.0), action=(-0.5, 80.0, 5, 3.0, 80.0), steps=400),
+    "debris_short": dict(init=lambda e: (close_gap(e, 20.0, 10.0), setattr(e.state, "debris_volume", 0.0316)),
+                         action=(0.0, 80.0, 5, 3.0, 80.0), steps=3000),
+    "random_short": dict(kw=dict(ignition_params=IgnitionModuleParameters(random_short_max_probability=0.004)),
+                         init=lambda e: close_gap(e, 30.0, 10.0), action=(0.1, 80.0, 5, 3.0, 80.0), steps=3000),
+    "collision": dict(init=lambda e: (close_gap(e, 50.0, 149.5), setattr(e.state, "wire_velocity", 20000.0)),
+                      action=(1.0, 80.0, 5, 3.0, 80.0), steps=200),
+    "target_reached": dict(init=lambda e: close_gap(e, 25.0, 10.0, 25.002), action=(0.1, 80.0, 5, 3.0, 80.0), steps=4000),
+    "velocity_mode": dict(kw=dict(mechanics_control_mode="velocity"), init=lambda e: None,
+                          action=(200.0, 80.0, 5, 3.0, 80.0), steps=3000),
+    "limits": dict(kw=dict(mechanics_params=MechanicsModuleParameters(max_acceleration=2.0e3, max_jerk=5.0e6, max_speed=1.5)),
+                   init=lambda e: None, action=(1.0, 80.0, 5, 3.0, 80.0), steps=1500),
+    "zero_fallbacks": dict(init=lambda e: close_gap(e), action=(0.1, 0.0, 5, 0.0, 0.0), steps=2600),
+    "no_unwinding": dict(init=lambda e: (close_gap(e), setattr(e.state, "wire_unwinding_velocity", 0.0)),
+                         action=(0.1, 80.0, 13, 2.0, 30.0), steps=2000),
+}
+
+
+@pytest.mark.parametrize("name", sorted(SCENARIOS))
+def test_edge_scenarios_match_oracle(name):
+    """The reference's edge paths, 128 environments each."""
+    sc = SCENARIOS[name]
+    n = 128
+    gpu, cpu = make_pair(n, **sc.get("kw", {}))
+    both((gpu, cpu), lambda e: (e.reset(seed=31), sc["init"](e)))
+    for env in (gpu, cpu):
+        a = env.make_action(*sc["action"])
+        done = 0
+        while done < sc["steps"]:
+            k = min(777, sc["steps"] - done)
+            env.step_many(a, k)
+            done += k
+    check(gpu, cpu, n)
+    if name in ("collision", "target_reached"):
+        assert bool(gpu.state.done.any())
+
+
+def test_wire_break_early_return():
+    """Tmax > 1500 K: the step returns before mechanics and clocks (wire_edm.py:129-130)."""
+    n = 64
+    gpu, cpu = make_pair(n)
+    for env in (gpu, cpu):
+        env.reset(seed=9)
+        T = env.state.wire_temperature
+        T[: n // 2, 180:186] = 1600.0   # breaks at the first step
+        T[n // 2:, 180:181] = 1502.0    # only enters the critical band
+        env.step_many(env.make_action(), 50)
+    check(gpu, cpu, n)
+    assert gpu.state.is_wire_broken[: n // 2].all() and not gpu.state.is_wire_broken[n // 2:].any()
+    assert (gpu.state.time[: n // 2] == 0).all() and (gpu.state.time[n // 2:] == 50).all()
+
+
+def test_partial_reset_and_episode_streams():
+    n = 128
+    gpu, cpu = make_pair(n)
+    mask = np.zeros(n, dtype=bool)
+    mask[::3] = True
+    for env in (gpu, cpu):
+        env.reset(seed=77)
+        close_gap(env)
+        a = env.make_action()
+        env.step_many(a, 1500)
+        env.reset(options={"mask": mask})       # new episode, same key -> different stream
+        env.state.workpiece_position[torch.as_tensor(mask)] = 25.0
+        env.state.wire_position[torch.as_tensor(mask)] = 10.0
+        env.step_many(a, 1500)
+    check(gpu, cpu, n)
+    assert (gpu.state.time[torch.as_tensor(mask).cuda()] == 1500).all()
+    assert (gpu.state.episode[torch.as_tensor(mask).cuda()] == 1).all()
+
+
+def test_invalid_mode_raises_on_host_like_the_reference():
+    env = WireEDMEnv(num_envs=64, device="cuda:0")
+    env.reset(seed=0)
+    with pytest.raises(ValueError, match="not available in crater data"):
+        env.step(env.make_action(current_mode=2))
+
+
+def test_single_spark_known_answer_on_gpu(golden_dir):
+    """F2 (experiments/single_spark_animation.py): ignition disabled, spark forced from
+    the host before each microsecond; T must equal the reference's recorded field."""
+    from tests._golden import Fixture
+
+    fx = Fixture(golden_dir / "f2_single_spark.npz")
+    env = WireEDMEnv(num_envs=64, device="cuda:0", disable_ignition=True)
+    env.reset(seed=42)
+    env.state.workpiece_position = 50.0
+    env.state.wire_position = 40.0
+    env.state.target_position = 5000.0
+    env.state.wire_unwinding_velocity = 0.0
+    snaps = dict(zip(fx.T_snap_steps.tolist(), fx.T_snaps))
+    act = env.make_action(0.0, 80.0, 13, 2.0, 1000.0)
+    for step in range(fx.n_steps):
+        st, y, dur, V, I = fx.forced[step]
+        env.state.spark_state = int(st)
+        env.state.spark_location = float(y)
+        env.state.spark_duration = int(dur)
+        env.state.voltage = float(V)
+        env.state.current = float(I)
+        env.step(act)
+        if step in snaps:
+            T = env.state.wire_temperature[7].cpu().numpy()
+            assert np.array_equal(T, snaps[step]), f"step {step}: max |dT| {np.abs(T - snaps[step]).max()}"
+    assert float(env.state.wire_position[0]) == float(fx.float_row("wire_position")[-1])
+
+
+def test_reference_fixtures_with_injected_philox_on_gpu(golden_dir):
+    """F3: the REFERENCE consumed this build's Philox variates (tools/gen_golden.py);
+    environments 0,1,2,3,777,65535 of a 65 536-wide batch must reproduce its per-step
+    discrete state exactly and its floats to the stated tolerance."""
+    from tests._golden import Fixture
+
+    ids = [0, 1, 2, 3, 777, 65535]
+    fxs = [Fixture(golden_dir / f"f3_philox_env{i}.npz") for i in ids]
+    n = 65536
+    env = WireEDMEnv(num_envs=n, device="cuda:0")
+    env.reset(seed=1234)
+    close_gap(env, 25.0, 10.0, 5000.0)
+    act = env.make_action(0.1, 80.0, 5, 3.0, 80.0)
+    idx = torch.tensor(ids, device="cuda")
+    steps = fxs[0].n_steps
+    rec_state = torch.empty((steps, len(ids)), dtype=torch.int8, device="cuda")
+    rec_i32 = torch.empty((steps, 3, len(ids)), dtype=torch.int32, device="cuda")
+    rec_f64 = torch.empty((steps, 6, len(ids)), dtype=torch.float64, device="cuda")
+    st = env.state
+    for step in range(steps):
+        env.step(act)
+        rec_state[step] = st.spark_state[idx]
+        rec_i32[step, 0] = st.spark_duration[idx]
+        rec_i32[step, 1] = st.time[idx]
+        rec_i32[step, 2] = st.debris_short_remaining[idx]
+        for j, name in enumerate(("workpiece_position", "wire_position", "wire_velocity", "debris_volume",
+                                  "flow_rate", "wire_max_temperature")):
+            rec_f64[step, j] = getattr(st, name)[idx]
+    rs, ri, rf = rec_state.cpu().numpy(), rec_i32.cpu().numpy(), rec_f64.cpu().numpy()
+    for c, fx in enumerate(fxs):
+        assert np.array_equal(rs[:, c], fx.int_row("spark_state")), f"env {ids[c]} spark_state"
+        assert np.array_equal(ri[:, 0, c], fx.int_row("spark_dur"))
+        assert np.array_equal(ri[:, 1, c], fx.int_row("time"))
+        assert np.array_equal(ri[:, 2, c], fx.int_row("debris_short_remaining"))
+        fs = fx.float_steps
+        for j, name in enumerate(("workpiece_position", "wire_position", "wire_velocity")):
+            assert np.array_equal(rf[fs, j, c], fx.float_row(name)), f"env {ids[c]} {name} not bit-exact"
+        np.testing.assert_allclose(rf[fs, 3, c], fx.float_row("debris_volume"), rtol=1e-12, atol=0)
+        np.testing.assert_allclose(rf[fs, 4, c], fx.float_row("flow_rate"), rtol=1e-12, atol=0)
+        np.testing.assert_allclose(rf[fs, 5, c], fx.float_row("tmax"), rtol=0, atol=1e-4)
+        T = env.state.wire_temperature[ids[c]].cpu().numpy()
+        assert np.abs(T - fx.T_snaps[-1]).max() <= 1e-4
+
+
+def test_full_size_fusion_and_sharding_invariance():
+    """BASELINE batch (65 536 envs, 128 segments): properties that hold at any size.
+      * fusion: step_many(1000) == 1000 x step() bit for bit (LDS kernel vs global kernel);
+      * sharding: the upper half computed alone with env_id_offset reproduces itself."""
+    n = 65536
+    kw = dict(wire_params=WireModuleParameters(segment_len=0.625))
+    a_env = WireEDMEnv(num_envs=n, device="cuda:0", **kw)
+    b_env = WireEDMEnv(num_envs=n, device="cuda:0", **kw)
+    half = WireEDMEnv(num_envs=n // 2, device="cuda:0", env_id_offset=n // 2, **kw)
+    for env in (a_env, b_env, half):
+        env.reset(seed=4321)
+        close_gap(env, 22.0, 10.0)
+    act = a_env.make_action(0.1, 80.0, 5, 3.0, 80.0)
+    a_env.step_many(act, 1000)
+    a_env.step_many(act, 300)
+    for _ in range(1300):
+        b_env.step(act)
+    half.step_many(half.make_action(0.1, 80.0, 5, 3.0, 80.0), 1300)
+    torch.cuda.synchronize()
+    A, B, H = a_env.state.clone_blocks(), b_env.state.clone_blocks(), half.state.clone_blocks()
+    assert_blocks_equal(A, B, n)
+    upper = {k: v[:, n // 2: n] for k, v in A.items()}
+    assert_blocks_equal(H, upper, n // 2)
+    assert int(a_env.state.spark_count.sum()) > 10000
