@@ -1,0 +1,194 @@
+#!/usr/bin/env python
+"""Headline benchmark: env-steps/s of the batched Wire-EDM step on MI355X.
+
+    python bench.py --gpus 1 --steps 20 --warmup 2
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+        --master-port P bench.py --gpus N --steps K --warmup W
+
+One bench "step" = one control interval = ``--substeps`` (default 1000) physics
+microseconds for every environment, i.e. one fused kernel launch per rank, followed
+(N > 1) by the RCCL all-gather of the control-step observations.  Workload at any N:
+BASELINE.json configs[2] per GPU (num_envs 65 536, 128-segment wire grid,
+segment_len 0.625), fresh reset, constant quickstart action ->
+weak scaling.  ``--workload config2`` selects num_envs 4096 / 400 segments instead.
+
+Prints ONE JSON line (rank 0).  ``roofline`` prices the dominant kernel against the
+8 TB/s HBM peak with the ALGORITHMIC bytes of SURVEY.md §8d, B(S) = 8*S + 208 per
+env-step; ``cpu_baseline`` times the CPU oracle (oracle/, OpenMP) on this host.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+from pathlib import Path
+
+ROOT = Path(__file__).resolve().parent
+sys.path.insert(0, str(ROOT))
+
+HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+
+
+def algorithmic_bytes_per_env_step(n_seg: int) -> int:
+    """read+write T (2*4*S) + read+write the 96-B scalar block + 16 B action."""
+    return 8 * n_seg + 208
+
+
+def parse_args():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--substeps", type=int, default=1000, help="physics microseconds per bench step")
+    ap.add_argument("--workload", choices=["config3", "config2", "config4"], default="config3")
+    ap.add_argument("--num-envs", type=int, default=0, help="override environments per GPU")
+    ap.add_argument("--kernel", type=int, default=0, help="0 auto, 1 global-memory, 2 LDS-fused")
+    ap.add_argument("--cpu-seconds", type=float, default=12.0, help="target wall time of the cpu_baseline leg")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--traffic", type=float, default=None,
+                    help="measured HBM bytes per launch from a separate rocprofv3 --pmc pass (else null)")
+    return ap.parse_args()
+
+
+def workload(args):
+    from sparc_amd import WireModuleParameters
+
+    if args.workload == "config3":
+        n, wire, name = 65536, WireModuleParameters(segment_len=0.625), "BASELINE configs[2]"
+    elif args.workload == "config2":
+        n, wire, name = 4096, WireModuleParameters(), "BASELINE configs[1]"
+    else:
+        n, wire, name = 32768, WireModuleParameters(), "BASELINE configs[3] (per-GPU shard)"
+    if args.num_envs:
+        n = args.num_envs
+    return n, wire, name
+
+
+def cpu_baseline(wire_params, n_sub, target_seconds):
+    """Time the CPU oracle on a bounded sample of the same workload (all host cores)."""
+    from oracle import oracle as orc
+    from sparc_amd import WireEDMEnv
+    from tests._oracle_backend import OracleBackend
+
+    threads = int(orc.lib().wedm_oracle_max_threads())
+
+    def run(n_envs, subs):
+        env = WireEDMEnv(num_envs=n_envs, device="cpu", backend=OracleBackend, wire_params=wire_params)
+        env.reset(seed=1234)
+        act = env.make_action(0.1, 80.0, 5, 3.0, 80.0)
+        t0 = time.perf_counter()
+        env.step_many(act, subs)
+        return time.perf_counter() - t0
+
+    probe_envs = 64 * threads
+    dt = run(probe_envs, 200)
+    rate = probe_envs * 200 / dt
+    n_envs = max(probe_envs, int(rate * target_seconds / n_sub) // (64 * threads) * (64 * threads))
+    n_envs = min(n_envs, 65536)
+    dt = run(n_envs, n_sub)
+    return {
+        "value": n_envs * n_sub / dt, "unit": "env-steps/s", "cores": threads, "kind": "port",
+        "sample": f"{n_envs} envs x {n_sub} us of the same workload, OpenMP static over envs, {dt:.1f} s",
+    }
+
+
+def main():
+    args = parse_args()
+    import torch
+    import torch.distributed as dist
+
+    from sparc_amd import WireEDMEnv
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus > 1 and world == 1:
+        raise SystemExit("--gpus N > 1 must be launched with torch.distributed.run (one rank per GPU)")
+    torch.cuda.set_device(local_rank)
+    device = torch.device("cuda", local_rank)
+    if world > 1:
+        dist.init_process_group("nccl", device_id=device)
+
+    n_local, wire, wl_name = workload(args)
+    n_sub = args.substeps
+    env = WireEDMEnv(num_envs=n_local, device=device, wire_params=wire, env_id_offset=rank * n_local)
+    env.set_kernel(args.kernel)
+    env.reset(seed=1234)
+    act = env.make_action(0.1, 80.0, 5, 3.0, 80.0)
+    S = env.n_segments
+    obs_local = env.state.obs[:, :n_local]
+    gathered = torch.empty((world,) + tuple(obs_local.shape), dtype=obs_local.dtype, device=device) if world > 1 else None
+
+    def one_step():
+        env.step_many(act, n_sub)
+        if world > 1:  # observations of every shard, once per control step, over xGMI
+            dist.all_gather_into_tensor(gathered, obs_local.contiguous())
+
+    for _ in range(args.warmup):
+        one_step()
+
+    # ---- timed region: exactly K steps between barrier + synchronize
+    starts = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps)]
+    ends = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps)]
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        starts[i].record()          # torch's current stream == the stream wedm_step launches on
+        env.step_many(act, n_sub)
+        ends[i].record()
+        if world > 1:
+            dist.all_gather_into_tensor(gathered, obs_local.contiguous())
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        tmax = torch.tensor([elapsed], dtype=torch.float64, device=device)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        elapsed = float(tmax.item())
+    kernel_ms = sum(s.elapsed_time(e) for s, e in zip(starts, ends)) / args.steps
+
+    done = int(env.state.done.sum().item())
+    sparks = int(env.state.spark_count.sum().item())
+    if rank == 0:
+        total_env_steps = world * n_local * n_sub * args.steps
+        value = total_env_steps / elapsed
+        bytes_per_launch = n_local * n_sub * algorithmic_bytes_per_env_step(S)
+        achieved = bytes_per_launch / (kernel_ms * 1e-3) / 1e9
+        out = {
+            "metric": "env-steps/sec at batch 65536", "value": value, "unit": "env-steps/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f32 wire temperature + f64 scalar state", "data": "synthetic",
+            "config": {
+                "workload": f"{wl_name}: num_envs={n_local} per GPU, n_segments={S}, fresh reset(seed=1234), "
+                            f"constant action servo 0.1 / 80 V / I5 / ON 3 / OFF 80",
+                "substeps_per_step": n_sub, "global_num_envs": world * n_local,
+                "parallelism": f"env-sharded x{world}, obs all-gather per control step" if world > 1 else "single GPU",
+                "kernel": env._backend.last_kernel(),
+            },
+            "roofline": {
+                "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "frac": achieved / HBM_PEAK_GBS, "traffic": args.traffic,
+                "kernel_ms": kernel_ms, "algorithmic_bytes_per_launch": bytes_per_launch,
+                "note": "algorithmic bytes B(S)=8S+208 per env-step x envs x substeps per launch; the fused "
+                        "kernel keeps T in LDS, so physical HBM traffic is ~1/substeps of this",
+            },
+            "check": {"envs_done": done, "sparks": sparks},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(wire, n_sub, args.cpu_seconds)
+            out["cpu_baseline"]["reference_python"] = (
+                "1 209 env-steps/s, 1 core: the Python reference itself (Numba stubbed), measured in the build "
+                "container (BASELINE.md); it cannot travel to the GPU box")
+        print(json.dumps(out))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()
