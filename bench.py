@@ -44,7 +44,8 @@ def parse_args():
     ap.add_argument("--substeps", type=int, default=1000, help="physics microseconds per bench step")
     ap.add_argument("--workload", choices=["config3", "config2", "config4"], default="config3")
     ap.add_argument("--num-envs", type=int, default=0, help="override environments per GPU")
-    ap.add_argument("--kernel", type=int, default=0, help="0 auto, 1 global-memory, 2 LDS-fused")
+    ap.add_argument("--kernel", type=int, default=0, help="0 auto, 1 global-memory, 2 LDS predicated, 3 LDS fused")
+    ap.add_argument("--lanes", type=int, default=0, help="lanes per environment in kernel 3 (0 auto)")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="target wall time of the cpu_baseline leg")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--traffic", type=float, default=None,
@@ -114,7 +115,7 @@ def main():
     n_local, wire, wl_name = workload(args)
     n_sub = args.substeps
     env = WireEDMEnv(num_envs=n_local, device=device, wire_params=wire, env_id_offset=rank * n_local)
-    env.set_kernel(args.kernel)
+    env.set_kernel(args.kernel, args.lanes)
     env.reset(seed=1234)
     act = env.make_action(0.1, 80.0, 5, 3.0, 80.0)
     S = env.n_segments

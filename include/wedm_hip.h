@@ -247,9 +247,14 @@ int32_t wedm_reset(wedm_ctx* ctx, const uint8_t* mask, uint64_t seed, int32_t re
  * reference's 1 us step.                                                      */
 int32_t wedm_step(wedm_ctx* ctx, int32_t n_substeps, const wedm_action_ptrs* action, void* stream);
 
-/* selects the kernel used by wedm_step: 0 = auto, 1 = global-memory stencil
- * (one pass over T in HBM per substep), 2 = LDS-staged fused stencil.         */
+/* selects the kernel used by wedm_step: 0 = auto, 1 = global-memory stencil (one pass
+ * over T in HBM per substep), 2 = LDS-staged predicated stencil (any geometry),
+ * 3 = LDS-staged fused stencil with a wave-uniform segment table (uniform geometry).
+ * All variants produce bit-identical results.                                        */
 int32_t wedm_set_kernel(wedm_ctx* ctx, int32_t variant);
+
+/* lanes that share one environment in kernel 3: 0 = auto, or 1, 2, 4, 8, 16 */
+int32_t wedm_set_lanes(wedm_ctx* ctx, int32_t lanes);
 
 /* name / launch geometry of the kernel the last wedm_step used (for profiles) */
 const char* wedm_last_kernel(wedm_ctx* ctx);
@@ -262,7 +267,7 @@ int64_t wedm_sizeof_params(void);
 /* TEST HOOK: evaluates one of the device math primitives the physics relies on,
  * element-wise on device arrays, so tests can compare them bit for bit with the CPU.
  * kind: 0 exp, 1 log, 2 correctly-rounded cube, 3 sqrt, 4 Python floor-division
- * a // b, 5 a / b, 6 Philox uniform pair (u0 + 2*u1) at (time=a, env=b),
+ * a // b, 5 a / b, 6 the four Philox step uniforms (u0 + 2 u1 + 4 u2 + 8 u3) at (time=a, env=b),
  * 7 Philox polar normal at (time=a, env=b).  Key 0x9abcdef012345678, episode 3.   */
 int32_t wedm_debug_math(int32_t kind, const double* a, const double* b, double* out, int32_t n, void* stream);
 

@@ -162,6 +162,8 @@ def lib() -> C.CDLL:
     L.wedm_oracle_philox4x32_10.restype = None
     L.wedm_oracle_uniform_pair.argtypes = [C.c_uint64, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.POINTER(_d)]
     L.wedm_oracle_uniform_pair.restype = None
+    L.wedm_oracle_step_uniforms.argtypes = [C.c_uint64, C.c_uint32, C.c_uint32, C.c_uint32, C.POINTER(_d)]
+    L.wedm_oracle_step_uniforms.restype = None
     L.wedm_oracle_std_normal.argtypes = [C.c_uint64, C.c_uint32, C.c_uint32, C.c_uint32, C.POINTER(_i)]
     L.wedm_oracle_std_normal.restype = _d
     for name in ("wedm_oracle_exp", "wedm_oracle_log", "wedm_oracle_cube"):
@@ -216,6 +218,12 @@ def uniform_pair(seed, env_id, episode, time, stream):
     o = (_d * 2)()
     lib().wedm_oracle_uniform_pair(seed, env_id, episode, time, stream, o)
     return o[0], o[1]
+
+
+def step_uniforms(seed, env_id, episode, time):
+    o = (_d * 4)()
+    lib().wedm_oracle_step_uniforms(seed, env_id, episode, time, o)
+    return tuple(o)
 
 
 def std_normal(seed, env_id, episode, time):

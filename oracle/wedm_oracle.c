@@ -145,10 +145,13 @@ static double oracle_square(double x, int32_t math_mode) {
 /* ------------------------------------------------------------------- RNG
  * Philox4x32-10 (Salmon et al., "Parallel random numbers: as easy as 1, 2, 3",
  * SC'11).  Counter = {time, episode, global env id, stream}, key = 64-bit seed.
- * Streams: 0 -> {u_debris_short, u_random_short}; 1 -> {u_ignite, u_spark_y};
- *          2+j -> pair j of the polar method for the crater normal.
- * A double uses 53 bits of two words exactly like NumPy's 32-bit bit generators:
- * ((a >> 5) * 2^26 + (b >> 6)) / 2^53.                                        */
+ *   stream 0    : ONE call per microsecond gives the four uniforms a step can need:
+ *                 word 0 debris-short roll, word 1 random-short roll, word 2
+ *                 ignition roll, word 3 spark location.  u = (w + 0.5) * 2^-32,
+ *                 strictly inside (0,1): a probability below 2^-33 never fires.
+ *   stream 1+j  : pair j of the polar method for the crater normal, 53-bit doubles
+ *                 built like NumPy's 32-bit bit generators:
+ *                 ((a >> 5) * 2^26 + (b >> 6)) / 2^53.                          */
 void wedm_oracle_philox4x32_10(const uint32_t ctr[4], const uint32_t key[2], uint32_t out[4]) {
     uint32_t c0 = ctr[0], c1 = ctr[1], c2 = ctr[2], c3 = ctr[3];
     uint32_t k0 = key[0], k1 = key[1];
@@ -166,12 +169,24 @@ void wedm_oracle_philox4x32_10(const uint32_t ctr[4], const uint32_t key[2], uin
     out[0] = c0; out[1] = c1; out[2] = c2; out[3] = c3;
 }
 
-void wedm_oracle_uniform_pair(uint64_t seed, uint32_t env_id, uint32_t episode, uint32_t time,
-                              uint32_t stream, double out[2]) {
+static void philox_words(uint64_t seed, uint32_t env_id, uint32_t episode, uint32_t time, uint32_t stream,
+                         uint32_t w[4]) {
     uint32_t ctr[4] = {time, episode, env_id, stream};
     uint32_t key[2] = {(uint32_t)seed, (uint32_t)(seed >> 32)};
-    uint32_t w[4];
     wedm_oracle_philox4x32_10(ctr, key, w);
+}
+
+/* the four per-step uniforms (stream 0) */
+void wedm_oracle_step_uniforms(uint64_t seed, uint32_t env_id, uint32_t episode, uint32_t time, double out[4]) {
+    uint32_t w[4];
+    philox_words(seed, env_id, episode, time, 0u, w);
+    for (int i = 0; i < 4; ++i) out[i] = ((double)w[i] + 0.5) * 2.3283064365386963e-10; /* 2^-32 */
+}
+
+void wedm_oracle_uniform_pair(uint64_t seed, uint32_t env_id, uint32_t episode, uint32_t time,
+                              uint32_t stream, double out[2]) {
+    uint32_t w[4];
+    philox_words(seed, env_id, episode, time, stream, w);
     out[0] = ((double)(w[0] >> 5) * 67108864.0 + (double)(w[1] >> 6)) / 9007199254740992.0;
     out[1] = ((double)(w[2] >> 5) * 67108864.0 + (double)(w[3] >> 6)) / 9007199254740992.0;
 }
@@ -181,7 +196,7 @@ double wedm_oracle_std_normal(uint64_t seed, uint32_t env_id, uint32_t episode, 
                               int32_t* n_pairs) {
     for (uint32_t j = 0; j < 64; ++j) {
         double u[2];
-        wedm_oracle_uniform_pair(seed, env_id, episode, time, 2u + j, u);
+        wedm_oracle_uniform_pair(seed, env_id, episode, time, 1u + j, u);
         double v1 = 2.0 * u[0] - 1.0, v2 = 2.0 * u[1] - 1.0;
         double s = v1 * v1 + v2 * v2;
         if (s < 1.0 && s != 0.0) {
@@ -208,19 +223,18 @@ static double rng_replay_next(wedm_oracle_env* env) {
 static double rng_random(wedm_oracle_env* env, int slot) {
     if (env->rng.mode == WEDM_ORACLE_RNG_REPLAY) return rng_replay_next(env);
     env->rng.draws_this_step++;
-    double u[2];
-    wedm_oracle_uniform_pair(env->rng.seed, env->rng.env_id, env->rng.episode, (uint32_t)env->time,
-                             slot < 2 ? 0u : 1u, u);
-    return u[slot & 1];
+    double u[4];
+    wedm_oracle_step_uniforms(env->rng.seed, env->rng.env_id, env->rng.episode, (uint32_t)env->time, u);
+    return u[slot];
 }
 /* env.np_random.uniform(0, workpiece_height), ignition.py:261-263.
  * NumPy: low + (high - low) * next_double. */
 static double rng_uniform_y(wedm_oracle_env* env) {
     if (env->rng.mode == WEDM_ORACLE_RNG_REPLAY) return rng_replay_next(env);
     env->rng.draws_this_step++;
-    double u[2];
-    wedm_oracle_uniform_pair(env->rng.seed, env->rng.env_id, env->rng.episode, (uint32_t)env->time, 1u, u);
-    return 0.0 + (env->c.workpiece_height - 0.0) * u[1];
+    double u[4];
+    wedm_oracle_step_uniforms(env->rng.seed, env->rng.env_id, env->rng.episode, (uint32_t)env->time, u);
+    return 0.0 + (env->c.workpiece_height - 0.0) * u[3];
 }
 /* env.np_random.normal(mean, std), material.py:127.  NumPy: loc + scale * z. */
 static double rng_normal(wedm_oracle_env* env, double mean, double std) {

@@ -175,6 +175,7 @@ int32_t wedm_oracle_step(wedm_oracle_env* env, const wedm_oracle_action* action)
 
 /* RNG pieces, exported for known-answer tests and for the fixture generator */
 void wedm_oracle_philox4x32_10(const uint32_t ctr[4], const uint32_t key[2], uint32_t out[4]);
+void wedm_oracle_step_uniforms(uint64_t seed, uint32_t env_id, uint32_t episode, uint32_t time, double out[4]);
 void wedm_oracle_uniform_pair(uint64_t seed, uint32_t env_id, uint32_t episode, uint32_t time,
                               uint32_t stream, double out[2]);
 double wedm_oracle_std_normal(uint64_t seed, uint32_t env_id, uint32_t episode, uint32_t time,

@@ -54,6 +54,8 @@ def load() -> C.CDLL:
     L.wedm_step.restype = C.c_int32
     L.wedm_set_kernel.argtypes = [ctx, C.c_int32]
     L.wedm_set_kernel.restype = C.c_int32
+    L.wedm_set_lanes.argtypes = [ctx, C.c_int32]
+    L.wedm_set_lanes.restype = C.c_int32
     L.wedm_last_error.argtypes = [ctx]
     L.wedm_last_error.restype = C.c_char_p
     L.wedm_last_kernel.argtypes = [ctx]
@@ -66,7 +68,7 @@ def load() -> C.CDLL:
 
 EXPORTS = (
     "wedm_abi_version", "wedm_create", "wedm_destroy", "wedm_bind_state", "wedm_bind_geometry",
-    "wedm_reset", "wedm_step", "wedm_set_kernel", "wedm_last_kernel", "wedm_last_error",
+    "wedm_reset", "wedm_step", "wedm_set_kernel", "wedm_set_lanes", "wedm_last_kernel", "wedm_last_error",
     "wedm_sizeof_params", "wedm_debug_math",
 )
 
@@ -114,6 +116,9 @@ class HipBackend:
 
     def set_kernel(self, variant: int) -> None:
         self._check(self._L.wedm_set_kernel(self._ctx, variant))
+
+    def set_lanes(self, lanes: int) -> None:
+        self._check(self._L.wedm_set_lanes(self._ctx, lanes))
 
     def last_kernel(self) -> str:
         return (self._L.wedm_last_kernel(self._ctx) or b"").decode()

@@ -112,31 +112,44 @@ __device__ __forceinline__ double py_floordiv(double vx, double wx) {
 // Philox4x32-10, counter {time, episode, global env id, stream}, key = reset seed.
 // Counter-based: a variate is a pure function of (seed, env, episode, time, slot),
 // so results do not depend on launch geometry, fusion depth or sharding.
-struct U2 { double a, b; };
+//   stream 0   : the four uniforms one microsecond can need (debris-short roll,
+//                random-short roll, ignition roll, spark location), u = (w+0.5)*2^-32;
+//   stream 1+j : 53-bit pair j of the polar method (crater normal).
+struct W4 { uint32_t x, y, z, w; };
 
-__device__ __forceinline__ U2 philox_pair(uint32_t key0, uint32_t key1, uint32_t time, uint32_t episode,
-                                           uint32_t gid, uint32_t stream) {
+__device__ __forceinline__ W4 philox4(uint32_t key0, uint32_t key1, uint32_t time, uint32_t episode,
+                                      uint32_t gid, uint32_t stream) {
     uint32_t c0 = time, c1 = episode, c2 = gid, c3 = stream, k0 = key0, k1 = key1;
 #pragma unroll
     for (int r = 0; r < 10; ++r) {
-        uint32_t hi0 = __umulhi(0xD2511F53u, c0), lo0 = 0xD2511F53u * c0;
-        uint32_t hi1 = __umulhi(0xCD9E8D57u, c2), lo1 = 0xCD9E8D57u * c2;
-        uint32_t n0 = hi1 ^ c1 ^ k0, n2 = hi0 ^ c3 ^ k1;
-        c0 = n0; c1 = lo1; c2 = n2; c3 = lo0;
+        // 64-bit products: one v_mad_u64_u32 each instead of a mul_lo + mul_hi pair
+        uint64_t p0 = (uint64_t)0xD2511F53u * c0;
+        uint64_t p1 = (uint64_t)0xCD9E8D57u * c2;
+        uint32_t n0 = (uint32_t)(p1 >> 32) ^ c1 ^ k0, n2 = (uint32_t)(p0 >> 32) ^ c3 ^ k1;
+        c0 = n0; c1 = (uint32_t)p1; c2 = n2; c3 = (uint32_t)p0;
         k0 += 0x9E3779B9u;
         k1 += 0xBB67AE85u;
     }
+    return W4{c0, c1, c2, c3};
+}
+
+__device__ __forceinline__ double u32_to_unit(uint32_t w) { return ((double)w + 0.5) * 2.3283064365386963e-10; }
+
+struct U2 { double a, b; };
+__device__ __forceinline__ U2 philox_pair(uint32_t key0, uint32_t key1, uint32_t time, uint32_t episode,
+                                           uint32_t gid, uint32_t stream) {
+    W4 w = philox4(key0, key1, time, episode, gid, stream);
     U2 u;
-    u.a = ((double)(c0 >> 5) * 67108864.0 + (double)(c1 >> 6)) / 9007199254740992.0;
-    u.b = ((double)(c2 >> 5) * 67108864.0 + (double)(c3 >> 6)) / 9007199254740992.0;
+    u.a = ((double)(w.x >> 5) * 67108864.0 + (double)(w.y >> 6)) / 9007199254740992.0;
+    u.b = ((double)(w.z >> 5) * 67108864.0 + (double)(w.w >> 6)) / 9007199254740992.0;
     return u;
 }
 
-// Marsaglia polar method on Philox streams 2, 3, ... (material.py:127's N(0,1))
+// Marsaglia polar method on Philox streams 1, 2, ... (material.py:127's N(0,1))
 __device__ __forceinline__ double philox_std_normal(uint32_t key0, uint32_t key1, uint32_t time,
                                                     uint32_t episode, uint32_t gid) {
     for (uint32_t j = 0; j < 64; ++j) {
-        U2 u = philox_pair(key0, key1, time, episode, gid, 2u + j);
+        U2 u = philox_pair(key0, key1, time, episode, gid, 1u + j);
         double v1 = 2.0 * u.a - 1.0, v2 = 2.0 * u.b - 1.0;
         double s = v1 * v1 + v2 * v2;
         if (s < 1.0 && s != 0.0) return v1 * sqrt(-2.0 * portable_log(s) / s);
@@ -283,44 +296,47 @@ __device__ __forceinline__ Coef scalar_prelude(const wedm_params& p, const Geom&
 
     if (!p.disable_ignition) {
     // ---- short-circuit detection (ignition.py:197-245)
-    {
+    // One Philox call serves the whole step, and only lanes that can use a variate pay
+    // for it: no short timer running and (a roll that can succeed, or an idle generator).
+    const bool timers = (s.rnd_rem > 0) || (s.deb_rem > 0);
+    double p_d = 0.0, p_r = 0.0;
+    if (!timers) {
         double d = s.wp - s.x;
         double gap = d > 0.0 ? d : 0.0;
-        if (s.rnd_rem > 0) {
-            s.rnd_rem -= 1;
-            s.is_short = 1;
-        } else if (s.deb_rem > 0) {
-            s.deb_rem -= 1;
-            s.is_short = 1;
+        if (gap < p.hard_short_gap) {  // ignition.py:115-146
+            p_d = 1.0;
         } else {
-            double p_d;  // ignition.py:115-146
-            if (gap < p.hard_short_gap) {
-                p_d = 1.0;
-            } else {
-                double crit = p.base_critical_density + p.gap_coefficient * gap;
-                crit = crit < p.max_critical_density ? crit : p.max_critical_density;
-                double ex = -p.sigmoid_steepness * (s.rho - crit);
-                if (ex > 500) p_d = 0.0;
-                else if (ex < -500) p_d = 1.0;
-                else p_d = 1.0 / (1.0 + portable_exp(ex));
-            }
-            double p_r;
-            if (gap >= p.random_short_max_gap) p_r = 0.0;
-            else if (gap <= p.random_short_min_gap) p_r = p.random_short_max_probability;
-            else
-                p_r = (1.0 - (gap - p.random_short_min_gap) / (p.random_short_max_gap - p.random_short_min_gap)) *
-                      p.random_short_max_probability;
-            U2 u = philox_pair(s.key0, s.key1, t, ep, gid, 0u);
-            if (u.a < p_d) {
-                s.deb_rem = p.debris_short_duration;
-                s.is_short = 1;
-            } else if (u.b < p_r) {
-                s.rnd_rem = p.random_short_duration;
-                s.is_short = 1;
-            } else {
-                s.is_short = 0;
-            }
+            double crit = p.base_critical_density + p.gap_coefficient * gap;
+            crit = crit < p.max_critical_density ? crit : p.max_critical_density;
+            double ex = -p.sigmoid_steepness * (s.rho - crit);
+            // every uniform is >= 2^-33, and 1/(1+e^ex) < 2^-33 for ex > 24: the roll cannot
+            // succeed, so the exponential need not be evaluated (same decision, exactly)
+            if (ex > 24.0) p_d = 0.0;
+            else if (ex < -500) p_d = 1.0;
+            else p_d = 1.0 / (1.0 + portable_exp(ex));
         }
+        if (gap >= p.random_short_max_gap) p_r = 0.0;
+        else if (gap <= p.random_short_min_gap) p_r = p.random_short_max_probability;
+        else
+            p_r = (1.0 - (gap - p.random_short_min_gap) / (p.random_short_max_gap - p.random_short_min_gap)) *
+                  p.random_short_max_probability;
+    }
+    W4 w{0u, 0u, 0u, 0u};
+    if (!timers && (p_d > 0.0 || p_r > 0.0 || s.state == 0)) w = philox4(s.key0, s.key1, t, ep, gid, 0u);
+    if (s.rnd_rem > 0) {
+        s.rnd_rem -= 1;
+        s.is_short = 1;
+    } else if (s.deb_rem > 0) {
+        s.deb_rem -= 1;
+        s.is_short = 1;
+    } else if (u32_to_unit(w.x) < p_d) {
+        s.deb_rem = p.debris_short_duration;
+        s.is_short = 1;
+    } else if (u32_to_unit(w.y) < p_r) {
+        s.rnd_rem = p.random_short_duration;
+        s.is_short = 1;
+    } else {
+        s.is_short = 0;
     }
     if (s.is_short) s.V = 0.0;
 
@@ -340,9 +356,8 @@ __device__ __forceinline__ Coef scalar_prelude(const wedm_params& p, const Geom&
             s.V = Vt;
             double gap = s.wp - s.x;  // unclamped (ignition.py:353)
             double lam = p.ln2 / (p.ignition_a * (gap * gap) + p.ignition_b * gap + p.ignition_c);
-            U2 u = philox_pair(s.key0, s.key1, t, ep, gid, 1u);
-            if (u.a < lam) {
-                s.y = 0.0 + (g.h - 0.0) * u.b;  // Generator.uniform(0, h)
+            if (u32_to_unit(w.z) < lam) {
+                s.y = 0.0 + (g.h - 0.0) * u32_to_unit(w.w);  // Generator.uniform(0, h)
                 s.state = 1; s.dur = 0;
                 s.V = Vt * p.spark_voltage_factor;
                 s.I = Ipk;

@@ -10,20 +10,46 @@
 //                      its half), runs n_substeps microseconds out of LDS + registers,
 //                      and writes everything back once.  No barriers: a lane only ever
 //                      touches its own LDS column.
+//   wedm_step_fused<L>: the throughput kernel for uniform geometry.  L lanes share one
+//                      environment: the wire is cut into L chunks, chunk c of environment
+//                      el lives in LDS column (el*L + c) as [cell j][256 lanes] (lane-linear
+//                      -> conflict-free), halos are read from the neighbour lane's column
+//                      before any store of the step (wave lock-step, no barrier).  The
+//                      scalar physics runs redundantly in the L lanes (bit-identical
+//                      inputs -> bit-identical results).  The wire walk follows a
+//                      host-built, wave-uniform SEGMENT TABLE: between two breakpoints
+//                      (contact / zone / boundary indices mapped into chunk space) every
+//                      lane applies the same formula, so the inner loop is 13 float32
+//                      VALU ops + 1 ds_read + 1 ds_write per cell with no per-cell
+//                      predicate; the plasma cell is patched outside the loop.
 //   wedm_reset_kernel: WireEDMEnv.reset for a masked subset.
 //
 // Build: hipcc --offload-arch=gfx950 -O3 -ffp-contract=off -fno-fast-math (see
 // __graft_entry__.build()).  -ffp-contract=off is part of the numerics contract.
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
 #include <cstdio>
 #include <cstring>
 #include <new>
+#include <set>
 #include <string>
 
 #include "wedm_device.h"
 
 using namespace wedm;
+
+// Wave-uniform description of one step's walk over a chunk of C cells (see
+// build_segments()).  Segment k covers chunk-local cells [j0[k], j0[k+1]).
+#define WEDM_MAX_SEGS 128
+struct SegTable {
+    int32_t n_segs;
+    int32_t C;                          // cells per chunk = ceil(n_seg / L)
+    int16_t j0[WEDM_MAX_SEGS + 1];
+    uint8_t fast[WEDM_MAX_SEGS];        // 1: every lane's cell is an interior cell (1 <= i <= n-2)
+    uint16_t zone[WEDM_MAX_SEGS];       // bit c: chunk c is inside the workpiece zone here
+    uint16_t joule[WEDM_MAX_SEGS];      // bit c: chunk c is between the contacts here
+};
 
 struct KArgs {
     wedm_params p;
@@ -34,6 +60,7 @@ struct KArgs {
     int32_t num_envs;
     int32_t n_substeps;
     int32_t n_seg_max;
+    const SegTable* segs;  // device copy of the table for the L in use (fused kernel only)
 };
 
 // ------------------------------------------------------------ T accessors
@@ -132,6 +159,188 @@ __global__ void __launch_bounds__(64) wedm_step_lds(const KArgs k) {
     store_env(k.s, e, s);
 }
 
+
+// ===================================================== fused kernel, L lanes / env
+__device__ __forceinline__ float fmax_gt(float a, float b) { return b > a ? b : a; }
+
+// Interior cells of one segment: identical formula in every lane, coefficients are
+// per-lane registers chosen once per segment.  JOULE / ADV are wave-uniform.
+template <bool JOULE, bool ADV>
+__device__ __forceinline__ void fast_segment(float* col, int j0, int j1, float& tm1, float& tc, float& tmax,
+                                             float k, float tuf, float conv, float tdiel, float adv, float jfe,
+                                             float alpha, float tref) {
+    auto cell = [&](float tp1) -> float {
+        float a = tm1 - (tc + tc);  // 2*T[i] is exact
+        float d = k * (a + tp1);
+        if (JOULE) {
+            float rho_T = 1.0f + alpha * (tc - tref);
+            d = d + jfe * rho_T;  // jfe == 0 in lanes outside the contacts: d + 0 == d
+        }
+        d = d - conv * (tc - tdiel);
+        if (ADV) d = d + adv * (tm1 - tc);
+        return tc + d * tuf;
+    };
+    int j = j0;
+    for (; j + 8 <= j1; j += 8) {
+        float nx[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) nx[u] = col[(j + 1 + u) * 256];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            float tn = cell(nx[u]);
+            col[(j + u) * 256] = tn;
+            tmax = fmax_gt(tmax, tn);
+            tm1 = tc;
+            tc = nx[u];
+        }
+    }
+    for (; j < j1; ++j) {
+        float tp1 = col[(j + 1) * 256];
+        float tn = cell(tp1);
+        col[j * 256] = tn;
+        tmax = fmax_gt(tmax, tn);
+        tm1 = tc;
+        tc = tp1;
+    }
+}
+
+template <int L>
+__global__ void __launch_bounds__(256) wedm_step_fused(const KArgs k) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    constexpr int EPB = 256 / L;  // environments per block
+    const int tid = threadIdx.x;
+    const int el = tid / L, c = tid % L;
+    const int64_t e0 = (int64_t)blockIdx.x * EPB;
+    const int64_t e = e0 + el;
+    const bool live = e < k.num_envs;
+    const SegTable* __restrict__ sg = k.segs;
+    const int C = sg->C;
+    const int n = k.p.n_seg;
+    const int64_t stride = k.s.stride;
+
+    // ---- stage the block's EPB wire columns: coalesced rows of T[seg][env] -> LDS
+    {
+        const int r = tid / EPB, sel = tid % EPB;  // L rows per iteration
+        int ci = 0, ji = r;                        // (chunk, cell) of row i = i0 + r
+        while (ji >= C) { ji -= C; ++ci; }
+        const bool ok = e0 + sel < k.num_envs;
+        const float* src = k.s.T + e0 + sel;
+        for (int i0 = 0; i0 < n; i0 += L) {
+            const int i = i0 + r;
+            if (i < n && ok) lds[ji * 256 + sel * L + ci] = src[(int64_t)i * stride];
+            ji += L;
+            while (ji >= C) { ji -= C; ++ci; }
+        }
+    }
+    __syncthreads();
+
+    Env s;
+    Geom g;
+    load_geom(k.p, k.g, stride, live ? e : 0, g);
+    if (live) load_env(k.s, e, s);
+    else s.done = 1;
+    if (!s.done) s.ipk = peak_current(k.p, k.tb, s.mode);
+    const uint32_t gid = k.p.env_id_offset + (uint32_t)e;
+
+    float* col = lds + tid;
+    const int cbase = c * C;
+    const float spool = (float)k.p.spool_T, tref = (float)k.p.temp_ref, alpha = (float)k.p.alpha_rho;
+    const float tdiel = (float)k.p.dielectric_temperature;
+    const int n_segs = sg->n_segs;
+
+    for (int it = 0; it < k.n_substeps; ++it) {
+        if (__all(s.done)) break;
+        Coef cf;
+        if (!s.done) cf = scalar_prelude(k.p, g, k.tb, k.a, e, gid, s);
+        else { cf.jf = 0.f; cf.q = 0.f; cf.conv_base = 0.f; cf.conv_zone = 0.f; cf.adv = 0.f; cf.joule_on = 0; cf.adv_on = 0; cf.pidx = -1; }
+
+        // ---- halos: OLD neighbour values, read before any lane of this wave stores
+        const float halo_l = (c > 0) ? col[(C - 1) * 256 - 1] : spool;
+        const float halo_r = (c < L - 1) ? col[1] : 0.0f;
+
+        // wave-uniform mode switches
+        const bool adv_all = __all(cf.adv_on || s.done), adv_none = !__any(cf.adv_on && !s.done);
+        // irregular waves (mixed advection, negative plasma heat, a frozen environment) take
+        // the predicated path for every cell; results are identical, only slower
+        const bool all_slow = !(adv_all || adv_none) || __any(cf.q < 0.0f) || __any(s.done);
+
+        // ---- plasma cell: computed from OLD values now, written after the walk
+        const bool owns = !s.done && cf.pidx >= 1 && cf.pidx >= cbase && cf.pidx < cbase + C;
+        float tpl = 0.0f;
+        if (__any(owns)) {
+            if (owns) {
+                const int jp = cf.pidx - cbase;
+                float tm = jp > 0 ? col[(jp - 1) * 256] : halo_l;
+                if (cf.pidx == 1) tm = spool;  // T[0] is held at the spool temperature (wire.py:83)
+                const float tcc = col[jp * 256];
+                const float tp = jp < C - 1 ? col[(jp + 1) * 256] : halo_r;
+                tpl = stencil_cell(cf.pidx, n, tm, tcc, tp, g, cf, tref, alpha, tdiel);
+            }
+        }
+
+        float tmax = spool;
+        float tm1 = halo_l;
+        float tc = col[0];
+        for (int kseg = 0; kseg < n_segs; ++kseg) {
+            const int j0 = sg->j0[kseg], j1 = sg->j0[kseg + 1];
+            const bool in_zone = (sg->zone[kseg] >> c) & 1;
+            const bool in_joule = (sg->joule[kseg] >> c) & 1;
+            if (sg->fast[kseg] && !all_slow) {
+                const float conv = in_zone ? cf.conv_zone : cf.conv_base;
+                const float jfe = (in_joule && cf.joule_on && !s.done) ? cf.jf : 0.0f;
+                const bool joule_any = __any(jfe != 0.0f);
+                if (joule_any) {
+                    if (adv_all) fast_segment<true, true>(col, j0, j1, tm1, tc, tmax, g.k, g.tuf, conv, tdiel, cf.adv, jfe, alpha, tref);
+                    else fast_segment<true, false>(col, j0, j1, tm1, tc, tmax, g.k, g.tuf, conv, tdiel, cf.adv, jfe, alpha, tref);
+                } else {
+                    if (adv_all) fast_segment<false, true>(col, j0, j1, tm1, tc, tmax, g.k, g.tuf, conv, tdiel, cf.adv, jfe, alpha, tref);
+                    else fast_segment<false, false>(col, j0, j1, tm1, tc, tmax, g.k, g.tuf, conv, tdiel, cf.adv, jfe, alpha, tref);
+                }
+            } else {
+                // boundary cells, chunk tails and irregular steps: fully predicated per lane
+                for (int j = j0; j < j1; ++j) {
+                    const int i = cbase + j;
+                    const float tp1 = (j < C - 1) ? col[(j + 1) * 256] : halo_r;
+                    float tn = spool;
+                    if (i >= 1 && i < n) tn = stencil_cell(i, n, tm1, tc, tp1, g, cf, tref, alpha, tdiel);
+                    if (i < n && !s.done) {
+                        col[j * 256] = tn;
+                        tmax = fmax_gt(tmax, tn);
+                    }
+                    tm1 = (i == 0) ? spool : tc;
+                    tc = tp1;
+                }
+            }
+        }
+        if (owns) {
+            col[(cf.pidx - cbase) * 256] = tpl;
+            tmax = fmax_gt(tmax, tpl);
+        }
+#pragma unroll
+        for (int m = 1; m < L; m <<= 1) tmax = fmax_gt(tmax, __shfl_xor(tmax, m));
+        if (!s.done) {
+            scalar_epilogue(k.p, s, tmax);
+            if (s.ctrl && c == 0) write_obs(k.p, k.s, e, s);
+        }
+    }
+
+    __syncthreads();
+    {
+        const int r = tid / EPB, sel = tid % EPB;
+        int ci = 0, ji = r;
+        while (ji >= C) { ji -= C; ++ci; }
+        const bool ok = e0 + sel < k.num_envs;
+        float* dst = k.s.T + e0 + sel;
+        for (int i0 = 0; i0 < n; i0 += L) {
+            const int i = i0 + r;
+            if (i < n && ok) dst[(int64_t)i * stride] = lds[ji * 256 + sel * L + ci];
+            ji += L;
+            while (ji >= C) { ji -= C; ++ci; }
+        }
+    }
+    if (live && c == 0) store_env(k.s, e, s);
+}
+
 __global__ void __launch_bounds__(256)
 wedm_reset_kernel(const wedm_params p, const wedm_state_ptrs s, int32_t num_envs, int32_t n_seg_max,
                   const uint8_t* mask, uint32_t key_lo, uint32_t key_hi, int32_t reseed) {
@@ -179,9 +388,9 @@ __global__ void wedm_debug_math_kernel(int32_t kind, const double* a, const doub
         case 3: r = sqrt(x); break;
         case 4: r = py_floordiv(x, y); break;
         case 5: r = x / y; break;
-        case 6: {  // a = seed-as-double bits are not needed: x = time, y = env id, key fixed
-            U2 u = philox_pair(0x12345678u, 0x9abcdef0u, (uint32_t)x, 3u, (uint32_t)y, 1u);
-            r = u.a + 2.0 * u.b;  // both words observable: u.a, u.b in [0,1)
+        case 6: {  // x = time, y = env id, key fixed; all four step uniforms observable
+            W4 w = philox4(0x12345678u, 0x9abcdef0u, (uint32_t)x, 3u, (uint32_t)y, 0u);
+            r = u32_to_unit(w.x) + 2.0 * u32_to_unit(w.y) + 4.0 * u32_to_unit(w.z) + 8.0 * u32_to_unit(w.w);
             break;
         }
         case 7: r = philox_std_normal(0x12345678u, 0x9abcdef0u, (uint32_t)x, 3u, (uint32_t)y); break;
@@ -201,7 +410,11 @@ struct wedm_ctx {
     void* tables_dev = nullptr;
     Tables tb{};
     int32_t variant = 0;
+    int32_t lanes = 0;                 // lanes per environment for the fused kernel (0 = auto)
     int lds_limit = 0;
+    SegTable* segs_dev = nullptr;      // [5] tables for L = 1, 2, 4, 8, 16
+    bool segs_ok[5] = {false, false, false, false, false};
+    int32_t segs_C[5] = {0, 0, 0, 0, 0};
     std::string err;
     std::string last_kernel;
 };
@@ -213,6 +426,56 @@ static int32_t fail(wedm_ctx* ctx, int32_t code, const std::string& msg) {
 static int32_t hip_fail(wedm_ctx* ctx, hipError_t e, const char* what) {
     return fail(ctx, WEDM_ERR_HIP, std::string(what) + ": " + hipGetErrorString(e));
 }
+
+
+// Segment table for L lanes per environment (uniform geometry).  Breakpoints are the
+// indices where the per-cell formula changes (cell 0 boundary condition, first/last
+// contact cell, zone start/end, last cell, end of wire), mapped into every chunk's local
+// coordinates; between two consecutive breakpoints all L chunks see constant flags.
+static bool build_segments(const wedm_params& p, int L, SegTable& t) {
+    std::memset(&t, 0, sizeof(t));
+    const int n = p.n_seg;
+    const int C = (n + L - 1) / L;
+    const int cb = p.contact_bottom, ct = p.contact_top, zs = p.az_start, ze = p.az_end;
+    std::set<int> bp = {0, C};
+    auto add = [&](int i_break) {
+        for (int c = 0; c < L; ++c) {
+            int j = i_break - c * C;
+            if (j > 0 && j < C) bp.insert(j);
+        }
+    };
+    add(1); add(n - 1); add(n); add(cb); add(ct + 1);
+    if (zs < ze) { add(zs); add(ze); }
+    if (C - 1 > 0) bp.insert(C - 1);
+    if ((int)bp.size() - 1 > WEDM_MAX_SEGS) return false;
+    t.C = C;
+    int k = 0;
+    for (auto it = bp.begin(); std::next(it) != bp.end(); ++it, ++k) {
+        const int a = *it, b = *std::next(it);
+        t.j0[k] = (int16_t)a;
+        t.j0[k + 1] = (int16_t)b;
+        bool fast = b <= C - 1;  // the chunk's last cell takes its right neighbour from a halo register
+        uint16_t zone = 0, joule = 0;
+        for (int c = 0; c < L; ++c) {
+            const int i0 = c * C + a, i1 = c * C + b - 1;
+            if (i0 < 1 || i1 > n - 2) fast = false;
+            if (zs < ze && i0 >= zs && i1 < ze) zone |= (uint16_t)(1u << c);
+            if (i0 >= cb && i1 <= ct) joule |= (uint16_t)(1u << c);
+        }
+        t.fast[k] = fast ? 1 : 0;
+        t.zone[k] = zone;
+        t.joule[k] = joule;
+    }
+    t.n_segs = k;
+    return true;
+}
+
+static int lanes_index(int L) { return L == 1 ? 0 : L == 2 ? 1 : L == 4 ? 2 : L == 8 ? 3 : L == 16 ? 4 : -1; }
+
+// Lanes per environment when the caller does not choose: the smallest L that (a) fits the
+// chunk in LDS and (b) puts at least ~2 waves on every SIMD (1024 SIMDs), preferring more
+// lanes only while the per-lane wire work still outweighs the replicated scalar work.
+static int auto_lanes(const wedm_ctx* ctx);
 
 static thread_local std::string g_create_error;
 
@@ -283,7 +546,7 @@ int32_t wedm_create(const wedm_params* params, int32_t num_envs, int32_t n_seg_m
     std::memcpy(host + 4 * n * 8, params->crater_valid, n * 4);
     if ((e = hipMemcpy(ctx->tables_dev, host, bytes, hipMemcpyHostToDevice)) != hipSuccess) {
         g_create_error = std::string("hipMemcpy(tables): ") + hipGetErrorString(e);
-        hipFree(ctx->tables_dev);
+        (void)hipFree(ctx->tables_dev);
         delete ctx;
         return WEDM_ERR_HIP;
     }
@@ -293,13 +556,45 @@ int32_t wedm_create(const wedm_params* params, int32_t num_envs, int32_t n_seg_m
     ctx->tb.crater_std = d + 2 * n;
     ctx->tb.crater_depth = d + 3 * n;
     ctx->tb.crater_valid = (const int32_t*)(d + 4 * n);
+    if (!params->per_env_geometry) {
+        SegTable host_tabs[5];
+        const int Ls[5] = {1, 2, 4, 8, 16};
+        for (int i = 0; i < 5; ++i) {
+            ctx->segs_ok[i] = build_segments(*params, Ls[i], host_tabs[i]);
+            ctx->segs_C[i] = host_tabs[i].C;
+        }
+        if ((e = hipMalloc((void**)&ctx->segs_dev, sizeof(host_tabs))) != hipSuccess ||
+            (e = hipMemcpy(ctx->segs_dev, host_tabs, sizeof(host_tabs), hipMemcpyHostToDevice)) != hipSuccess) {
+            g_create_error = std::string("segment tables: ") + hipGetErrorString(e);
+            if (ctx->segs_dev) (void)hipFree(ctx->segs_dev);
+            (void)hipFree(ctx->tables_dev);
+            delete ctx;
+            return WEDM_ERR_HIP;
+        }
+    }
     *out = ctx;
     return WEDM_OK;
 }
 
+static int auto_lanes(const wedm_ctx* ctx) {
+    const int Ls[5] = {1, 2, 4, 8, 16};
+    int best = 0;
+    for (int i = 0; i < 5; ++i) {
+        if (!ctx->segs_ok[i]) continue;
+        const size_t lds = (size_t)ctx->segs_C[i] * 1024;
+        if (lds > (size_t)ctx->lds_limit) continue;
+        if (!best) best = Ls[i];
+        const long waves = (long)((ctx->num_envs + (256 / Ls[i]) - 1) / (256 / Ls[i])) * 4;
+        best = Ls[i];
+        if (waves >= 2048 || ctx->segs_C[i] <= 32) break;
+    }
+    return best;
+}
+
 int32_t wedm_destroy(wedm_ctx* ctx) {
     if (!ctx) return WEDM_ERR_BAD_ARG;
-    if (ctx->tables_dev) hipFree(ctx->tables_dev);
+    if (ctx->tables_dev) (void)hipFree(ctx->tables_dev);
+    if (ctx->segs_dev) (void)hipFree(ctx->segs_dev);
     delete ctx;
     return WEDM_OK;
 }
@@ -325,8 +620,16 @@ int32_t wedm_bind_geometry(wedm_ctx* ctx, const wedm_geom_ptrs* geom) {
 
 int32_t wedm_set_kernel(wedm_ctx* ctx, int32_t variant) {
     if (!ctx) return WEDM_ERR_BAD_ARG;
-    if (variant < 0 || variant > 2) return fail(ctx, WEDM_ERR_BAD_ARG, "wedm_set_kernel: variant must be 0, 1 or 2");
+    if (variant < 0 || variant > 3) return fail(ctx, WEDM_ERR_BAD_ARG, "wedm_set_kernel: variant must be 0..3");
     ctx->variant = variant;
+    return WEDM_OK;
+}
+
+int32_t wedm_set_lanes(wedm_ctx* ctx, int32_t lanes) {
+    if (!ctx) return WEDM_ERR_BAD_ARG;
+    if (lanes != 0 && lanes_index(lanes) < 0)
+        return fail(ctx, WEDM_ERR_BAD_ARG, "wedm_set_lanes: lanes must be 0 (auto), 1, 2, 4, 8 or 16");
+    ctx->lanes = lanes;
     return WEDM_OK;
 }
 
@@ -362,26 +665,54 @@ int32_t wedm_step(wedm_ctx* ctx, int32_t n_substeps, const wedm_action_ptrs* act
     k.num_envs = ctx->num_envs;
     k.n_substeps = n_substeps;
     k.n_seg_max = ctx->n_seg_max;
+    k.segs = nullptr;
 
     const size_t lds_bytes = (size_t)ctx->n_seg_max * 64 * sizeof(float);
+    int lanes = ctx->lanes ? ctx->lanes : auto_lanes(ctx);
+    const int li = lanes_index(lanes);
+    const bool fused_ok = !ctx->p.per_env_geometry && ctx->segs_dev && li >= 0 && ctx->segs_ok[li] &&
+                          (size_t)ctx->segs_C[li] * 1024 <= (size_t)ctx->lds_limit;
     int variant = ctx->variant;
-    if (variant == 0) variant = (n_substeps > 1 && lds_bytes <= (size_t)ctx->lds_limit) ? 2 : 1;
+    if (variant == 0) {
+        if (n_substeps > 1 && fused_ok) variant = 3;
+        else variant = (n_substeps > 1 && lds_bytes <= (size_t)ctx->lds_limit) ? 2 : 1;
+    }
+    if (variant == 3 && !fused_ok)
+        return fail(ctx, WEDM_ERR_UNSUPPORTED, "wedm_step: fused kernel needs uniform geometry and a chunk that fits in LDS");
     if (variant == 2 && lds_bytes > (size_t)ctx->lds_limit)
         return fail(ctx, WEDM_ERR_UNSUPPORTED, "wedm_step: n_seg_max * 256 B exceeds the LDS a workgroup can take");
 
-    char name[128];
+    char name[160];
     if (variant == 1) {
         const int block = 256;
         const int grid = (ctx->num_envs + block - 1) / block;
         hipLaunchKernelGGL(wedm_step_global, dim3(grid), dim3(block), 0, (hipStream_t)stream, k);
         std::snprintf(name, sizeof(name), "wedm_step_global<<<%d,%d>>> n_sub=%d", grid, block, n_substeps);
-    } else {
+    } else if (variant == 2) {
         const int grid = (ctx->num_envs + 63) / 64;
         hipError_t ea = hipFuncSetAttribute((const void*)wedm_step_lds, hipFuncAttributeMaxDynamicSharedMemorySize,
                                             (int)lds_bytes);
         if (ea != hipSuccess) return hip_fail(ctx, ea, "hipFuncSetAttribute(wedm_step_lds)");
         hipLaunchKernelGGL(wedm_step_lds, dim3(grid), dim3(64), lds_bytes, (hipStream_t)stream, k);
         std::snprintf(name, sizeof(name), "wedm_step_lds<<<%d,64,%zuB>>> n_sub=%d", grid, lds_bytes, n_substeps);
+    } else {
+        const int epb = 256 / lanes;
+        const int grid = (ctx->num_envs + epb - 1) / epb;
+        const size_t fl = (size_t)ctx->segs_C[li] * 1024;
+        k.segs = ctx->segs_dev + li;
+        const void* fn = lanes == 1 ? (const void*)wedm_step_fused<1> : lanes == 2 ? (const void*)wedm_step_fused<2>
+                       : lanes == 4 ? (const void*)wedm_step_fused<4> : lanes == 8 ? (const void*)wedm_step_fused<8>
+                                                                                   : (const void*)wedm_step_fused<16>;
+        hipError_t ea = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)fl);
+        if (ea != hipSuccess) return hip_fail(ctx, ea, "hipFuncSetAttribute(wedm_step_fused)");
+        switch (lanes) {
+            case 1: hipLaunchKernelGGL(wedm_step_fused<1>, dim3(grid), dim3(256), fl, (hipStream_t)stream, k); break;
+            case 2: hipLaunchKernelGGL(wedm_step_fused<2>, dim3(grid), dim3(256), fl, (hipStream_t)stream, k); break;
+            case 4: hipLaunchKernelGGL(wedm_step_fused<4>, dim3(grid), dim3(256), fl, (hipStream_t)stream, k); break;
+            case 8: hipLaunchKernelGGL(wedm_step_fused<8>, dim3(grid), dim3(256), fl, (hipStream_t)stream, k); break;
+            default: hipLaunchKernelGGL(wedm_step_fused<16>, dim3(grid), dim3(256), fl, (hipStream_t)stream, k); break;
+        }
+        std::snprintf(name, sizeof(name), "wedm_step_fused<%d><<<%d,256,%zuB>>> n_sub=%d", lanes, grid, fl, n_substeps);
     }
     ctx->last_kernel = name;
     hipError_t e = hipGetLastError();

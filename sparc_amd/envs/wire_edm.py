@@ -301,9 +301,12 @@ class WireEDMEnv:
             idx = int(torch.nonzero(self.state.error)[0].item())
             raise ValueError(f"environment {idx}: fresh spark with a current mode that has no crater data")
 
-    def set_kernel(self, variant: int) -> None:
-        """0 = auto, 1 = global-memory stencil, 2 = LDS-staged fused stencil."""
+    def set_kernel(self, variant: int, lanes: int = 0) -> None:
+        """0 = auto, 1 = global-memory stencil, 2 = LDS predicated, 3 = LDS fused with
+        ``lanes`` lanes per environment (0 = auto).  All variants are bit-identical."""
         self._backend.set_kernel(variant)
+        if hasattr(self._backend, "set_lanes"):
+            self._backend.set_lanes(lanes)
 
     def zone_mean_temperature(self) -> torch.Tensor:
         """Mean wire temperature over the workpiece zone (wire.py:390-398), per environment."""

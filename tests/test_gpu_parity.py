@@ -50,7 +50,7 @@ def test_native_library_is_the_one_running():
     env.step(env.make_action())
     assert "wedm_step_global" in env._backend.last_kernel()
     env.step_many(env.make_action(), 10)
-    assert "wedm_step_lds" in env._backend.last_kernel()
+    assert "wedm_step_fused" in env._backend.last_kernel()
 
 
 @pytest.mark.parametrize("kind", [0, 1, 2, 3, 4, 5, 6, 7])
@@ -98,8 +98,8 @@ def test_device_math_primitives_match_cpu_bit_for_bit(orc, kind):
     elif kind == 5:
         want = a / b
     elif kind == 6:
-        want = np.array([(lambda u: u[0] + 2.0 * u[1])(orc.uniform_pair(0x9abcdef012345678, int(y), 3, int(x), 1))
-                         for x, y in zip(a[:4096], b[:4096])])
+        want = np.array([(lambda u: u[0] + 2.0 * u[1] + 4.0 * u[2] + 8.0 * u[3])(
+            orc.step_uniforms(0x9abcdef012345678, int(y), 3, int(x))) for x, y in zip(a[:4096], b[:4096])])
         got = got[:4096]
     else:
         want = np.array([orc.std_normal(0x9abcdef012345678, int(y), 3, int(x))[0] for x, y in zip(a[:4096], b[:4096])])
@@ -108,13 +108,22 @@ def test_device_math_primitives_match_cpu_bit_for_bit(orc, kind):
         f"kind {kind}: {np.count_nonzero(got.view(np.uint64) != want.view(np.uint64))} of {len(want)} differ"
 
 
-@pytest.mark.parametrize("variant", [1, 2])
-def test_default_config_fused_matches_oracle(variant):
-    """BASELINE config 2 shape (S=400): 3 control intervals, both kernels."""
+KERNELS = [(1, 0), (2, 0), (3, 1), (3, 2), (3, 4), (3, 8), (3, 16)]
+
+
+@pytest.mark.parametrize("variant,lanes", KERNELS)
+def test_default_config_fused_matches_oracle(variant, lanes):
+    """BASELINE config 2 shape (S=400): 3 control intervals, every kernel variant."""
     n = 320
     gpu, cpu = make_pair(n)
-    gpu.set_kernel(variant)
+    gpu.set_kernel(variant, lanes)
     both((gpu, cpu), lambda e: (e.reset(seed=1234), close_gap(e)))
+    if variant == 3 and -(-gpu.n_segments // lanes) * 1024 > 160 * 1024:
+        from sparc_amd._lib import WedmError
+
+        with pytest.raises(WedmError, match="WEDM_ERR_UNSUPPORTED"):  # chunk does not fit in 160 KB of LDS
+            gpu.step_many(gpu.make_action(), 10)
+        return
     for env in (gpu, cpu):
         a = env.make_action(0.1, 80.0, 5, 3.0, 80.0)
         for _ in range(3):
@@ -144,11 +153,13 @@ def test_single_microsecond_steps_with_changing_actions():
     assert torch.equal(tg.cpu(), tc)
 
 
-def test_config3_grid_128_segments():
+@pytest.mark.parametrize("variant,lanes", KERNELS)
+def test_config3_grid_128_segments(variant, lanes):
     """BASELINE config 3: segment_len 0.625 -> 128 segments."""
     n = 1024
     kw = dict(wire_params=WireModuleParameters(segment_len=0.625))
     gpu, cpu = make_pair(n, **kw)
+    gpu.set_kernel(variant, lanes)
     assert gpu.n_segments == 128
     both((gpu, cpu), lambda e: (e.reset(seed=99), close_gap(e, 22.0, 10.0)))
     for env in (gpu, cpu):
@@ -156,6 +167,27 @@ def test_config3_grid_128_segments():
         env.step_many(a, 1)
         env.step_many(a, 2499)
     check(gpu, cpu, n)
+
+
+@pytest.mark.parametrize("lanes", [4, 8, 16])
+def test_fused_kernel_with_ragged_chunks_and_heavy_sparking(lanes):
+    """361 segments (not divisible by any lane count), thin wire + I17: Joule heating,
+    plasma cells at chunk edges, wire breaks and frozen environments inside live waves."""
+    n = 200
+    kw = dict(config=EnvironmentConfig(workpiece_height=12.3, wire_diameter=0.15, target_cutting_distance=5000.0))
+    gpu, cpu = make_pair(n, **kw)
+    assert gpu.n_segments == 361
+    gpu.set_kernel(3, lanes)
+    both((gpu, cpu), lambda e: (e.reset(seed=17), close_gap(e, 24.0, 10.0)))
+    for env in (gpu, cpu):
+        a = env.make_action(0.1, 80.0, 17, 3.0, 40.0)
+        env.step_many(a, 1)
+        env.step_many(a, 1799)
+        env.state.wire_unwinding_velocity[::7] = 0.0   # mixed advection inside a wave
+        env.step_many(a, 700)
+    check(gpu, cpu, n)
+    assert f"wedm_step_fused<{lanes}>" in gpu._backend.last_kernel()
+    assert bool(gpu.state.is_wire_broken.any()) and not bool(gpu.state.is_wire_broken.all())
 
 
 def test_per_environment_geometry_config5():
@@ -175,6 +207,7 @@ def test_per_environment_geometry_config5():
             a = env.make_action(0.1, 80.0, mode, 3.0, 40.0)
             env.step_many(a, 1100)
         check(gpu, cpu, n)
+    assert int(gpu.state.spark_count.sum()) > 100
 
 
 SCENARIOS = {
@@ -343,8 +376,10 @@ def test_full_size_fusion_and_sharding_invariance():
     act = a_env.make_action(0.1, 80.0, 5, 3.0, 80.0)
     a_env.step_many(act, 1000)
     a_env.step_many(act, 300)
+    assert "wedm_step_fused" in a_env._backend.last_kernel()
     for _ in range(1300):
         b_env.step(act)
+    assert "wedm_step_global" in b_env._backend.last_kernel()
     half.step_many(half.make_action(0.1, 80.0, 5, 3.0, 80.0), 1300)
     torch.cuda.synchronize()
     A, B, H = a_env.state.clone_blocks(), b_env.state.clone_blocks(), half.state.clone_blocks()

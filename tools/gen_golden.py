@@ -98,12 +98,12 @@ class PhiloxShim(RecordingRNG):
     def random(self):
         slot = self.n_random
         self.n_random += 1
-        u = orc.uniform_pair(self.seed, self.env_id, self.episode, self.t, 0 if slot < 2 else 1)
-        return self._log(u[slot & 1])
+        u = orc.step_uniforms(self.seed, self.env_id, self.episode, self.t)
+        return self._log(u[slot])
 
     def uniform(self, low, high):
-        u = orc.uniform_pair(self.seed, self.env_id, self.episode, self.t, 1)
-        return self._log(low + (high - low) * u[1])  # NumPy: low + (high-low)*next_double
+        u = orc.step_uniforms(self.seed, self.env_id, self.episode, self.t)
+        return self._log(low + (high - low) * u[3])  # NumPy: low + (high-low)*next_double
 
     def normal(self, loc, scale):
         z, _ = orc.std_normal(self.seed, self.env_id, self.episode, self.t)
