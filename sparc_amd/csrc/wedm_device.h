@@ -171,20 +171,42 @@ struct Env {
     int32_t is_short, broken, reached, done, ctrl, err;
 };
 
-struct Geom {
-    double h, kerf_base, cavity_coeff, s_area, joule_geom;
-    float k, tuf, A;
-    int32_t n_seg, zone_start, az_start, az_end, cb, ct;
+// What an ORDINARY microsecond reads.  Passed by value (kernarg -> SGPRs).  Everything
+// else stays in the device copy of wedm_params ("cold") and is fetched through an
+// opaque pointer inside the rare branch that needs it, so it never occupies SGPRs in
+// the substep loop (the full struct is ~1 KB: by value it spilled >150 SGPRs to VGPR
+// lanes and cost ~500 v_readlane per step).
+struct Hot {
+    double hard_short_gap, base_critical_density, gap_coefficient, max_critical_density, sigmoid_steepness;
+    double ignition_a, ignition_b, ignition_c, ln2;
+    double default_target_voltage, default_on_time, default_off_time, spark_voltage_factor;
+    double debris_removal_per_us;
+    double dt_s, damping_coeff, stiffness_coeff, omega_n, max_acceleration, max_jerk_dt, max_speed;
+    float spool, tref, alpha, tdiel, tcrit, tbreak;
+    int32_t servo_interval, dt_us, control_mode, disable_ignition, has_random_short, per_env_geometry;
+    uint32_t env_id_offset;
+    int32_t n_seg;  // uniform geometry only
 };
 
-// float32 coefficients the scalar prelude hands to the stencil pass
+// per-lane geometry the every-step path needs (uniform values or the env's rows)
+struct Geom {
+    double cavity_coeff;
+    float k, tuf;
+    int32_t n_seg, az_start, az_end, cb, ct;
+};
+
+// per-lane coefficients that survive across substeps (recomputed only when their
+// inputs change): wire.py:304-312 advection, wire.py:349-374 convection
+struct Persist {
+    float adv, conv_base, conv_zone;
+    int32_t adv_on;
+};
+
+// float32 per-step coefficients the scalar prelude hands to the stencil pass
 struct Coef {
-    float jf;        // joule_factor (wire.py:98), 0 when I^2 <= 1e-6
-    float q;         // plasma heat (wire.py:298)
-    float conv_base; // h_eff * A outside the zone (wire.py:109)
-    float conv_zone; // h_eff * A inside the zone
-    float adv;       // advection coefficient (wire.py:304-312)
-    int32_t joule_on, adv_on, pidx;
+    float jf;  // joule_factor (wire.py:98)
+    float q;   // plasma heat (wire.py:298)
+    int32_t joule_on, pidx;
 };
 
 struct Tables {  // device copies of wedm_params' per-mode tables
@@ -195,10 +217,32 @@ struct Tables {  // device copies of wedm_params' per-mode tables
     const int32_t* crater_valid;
 };
 
+struct Cold {  // everything reachable only through rare branches
+    const wedm_params* p;
+    wedm_geom_ptrs g;
+    wedm_action_ptrs a;
+    wedm_state_ptrs s;
+    Tables tb;
+};
+
+// Hide a pointer from loop-invariant code motion: loads through the result cannot be
+// hoisted out of the (rare) branch they sit in, so they cost SGPRs only there.
+template <class T>
+__device__ __forceinline__ const T* opaque(const T* p) {
+    asm volatile("" : "+s"(p));
+    return p;
+}
+
 #define WEDM_ROW(ptr, row) ((ptr) + (int64_t)(row) * stride + e)
 
-__device__ __forceinline__ double peak_current(const wedm_params& p, const Tables& tb, int32_t mode) {
-    return (mode >= 1 && mode <= WEDM_MAX_MODE) ? tb.mode_current[mode] : p.default_current;
+// cold geometry scalars: the env's row when geometry is per environment, else the uniform value
+#define WEDM_COLD_GEOM_F64(cold, hot, row, field) \
+    ((hot).per_env_geometry ? (cold).g.f64[(int64_t)(row) * (cold).s.stride + e] : opaque((cold).p)->field)
+#define WEDM_COLD_GEOM_I32(cold, hot, row, field) \
+    ((hot).per_env_geometry ? (cold).g.i32[(int64_t)(row) * (cold).s.stride + e] : opaque((cold).p)->field)
+
+__device__ __forceinline__ double peak_current(const Cold& cold, int32_t mode) {
+    return (mode >= 1 && mode <= WEDM_MAX_MODE) ? cold.tb.mode_current[mode] : opaque(cold.p)->default_current;
 }
 
 __device__ __forceinline__ void load_env(const wedm_state_ptrs& s, int64_t e, Env& v) {
@@ -228,6 +272,7 @@ __device__ __forceinline__ void load_env(const wedm_state_ptrs& s, int64_t e, En
     v.broken = *WEDM_ROW(s.i8, WEDM_B_WIRE_BROKEN); v.reached = *WEDM_ROW(s.i8, WEDM_B_TARGET_REACHED);
     v.done = *WEDM_ROW(s.i8, WEDM_B_DONE); v.ctrl = *WEDM_ROW(s.i8, WEDM_B_CTRL_STEP);
     v.err = *WEDM_ROW(s.i8, WEDM_B_ERROR);
+    v.ipk = 0.0;
 }
 
 __device__ __forceinline__ void store_env(const wedm_state_ptrs& s, int64_t e, const Env& v) {
@@ -256,141 +301,165 @@ __device__ __forceinline__ void store_env(const wedm_state_ptrs& s, int64_t e, c
     *WEDM_ROW(s.i8, WEDM_B_ERROR) = (int8_t)v.err;
 }
 
-__device__ __forceinline__ void load_geom(const wedm_params& p, const wedm_geom_ptrs& gp, int64_t stride,
-                                          int64_t e, Geom& g) {
-    if (p.per_env_geometry) {
-        g.h = *WEDM_ROW(gp.f64, WEDM_G_HEIGHT); g.kerf_base = *WEDM_ROW(gp.f64, WEDM_G_KERF_BASE);
+__device__ __forceinline__ void load_geom(const Hot& hot, const Cold& cold, int64_t e, Geom& g) {
+    const int64_t stride = cold.s.stride;
+    if (hot.per_env_geometry) {
+        const wedm_geom_ptrs& gp = cold.g;
         g.cavity_coeff = *WEDM_ROW(gp.f64, WEDM_G_CAVITY_COEFF);
         g.k = (float)*WEDM_ROW(gp.f64, WEDM_G_K_COND); g.tuf = (float)*WEDM_ROW(gp.f64, WEDM_G_TUF);
-        g.A = (float)*WEDM_ROW(gp.f64, WEDM_G_A_SURF); g.s_area = *WEDM_ROW(gp.f64, WEDM_G_S_AREA);
-        g.joule_geom = *WEDM_ROW(gp.f64, WEDM_G_JOULE_GEOM);
-        g.n_seg = *WEDM_ROW(gp.i32, WEDM_GI_N_SEG); g.zone_start = *WEDM_ROW(gp.i32, WEDM_GI_ZONE_START);
+        g.n_seg = *WEDM_ROW(gp.i32, WEDM_GI_N_SEG);
         g.az_start = *WEDM_ROW(gp.i32, WEDM_GI_AZ_START); g.az_end = *WEDM_ROW(gp.i32, WEDM_GI_AZ_END);
         g.cb = *WEDM_ROW(gp.i32, WEDM_GI_CONTACT_BOTTOM); g.ct = *WEDM_ROW(gp.i32, WEDM_GI_CONTACT_TOP);
     } else {
-        g.h = p.workpiece_height; g.kerf_base = p.kerf_base; g.cavity_coeff = p.cavity_coeff;
-        g.k = (float)p.k_cond; g.tuf = (float)p.tuf; g.A = (float)p.a_surf; g.s_area = p.s_area;
-        g.joule_geom = p.joule_geom;
-        g.n_seg = p.n_seg; g.zone_start = p.zone_start; g.az_start = p.az_start; g.az_end = p.az_end;
-        g.cb = p.contact_bottom; g.ct = p.contact_top;
+        const wedm_params* p = cold.p;
+        g.cavity_coeff = p->cavity_coeff;
+        g.k = (float)p->k_cond; g.tuf = (float)p->tuf;
+        g.n_seg = p->n_seg; g.az_start = p->az_start; g.az_end = p->az_end;
+        g.cb = p->contact_bottom; g.ct = p->contact_top;
     }
+}
+
+// wire.py:349-374: h_eff * A products the stencil uses (float32 x float32, wire.py:109)
+__device__ __forceinline__ void refresh_convection(const Hot& hot, const Cold& cold, int64_t e, const Env& s,
+                                                   Persist& ps) {
+    const float A = (float)WEDM_COLD_GEOM_F64(cold, hot, WEDM_G_A_SURF, a_surf);
+    ps.conv_base = s.h_base * A;
+    ps.conv_zone = s.h_zone * A;
+}
+
+// once per launch: coefficients whose inputs no module changes (wire.py:304-312)
+__device__ __forceinline__ void init_persist(const Hot& hot, const Cold& cold, int64_t e, const Env& s, Persist& ps) {
+    double adv = 0.0;
+    if (__builtin_fabs(s.unwind) > 1e-6) {
+        const double s_area = WEDM_COLD_GEOM_F64(cold, hot, WEDM_G_S_AREA, s_area);
+        adv = cold.p->rho_c * __builtin_fabs(s.unwind) * s_area;
+    }
+    ps.adv_on = __builtin_fabs(adv) > 1e-9;
+    ps.adv = (float)adv;
+    refresh_convection(hot, cold, e, s, ps);
 }
 
 // --------------------------------------------------- scalar prelude (modules 1-4a)
 // wire_edm.py:117-121 latch, ignition.py:175-319, material.py:79-174,
-// dielectric.py:82-163, wire.py:271-312.  Returns the stencil coefficients.
-__device__ __forceinline__ Coef scalar_prelude(const wedm_params& p, const Geom& g, const Tables& tb,
-                                               const wedm_action_ptrs& act, int64_t e, uint32_t gid, Env& s) {
+// dielectric.py:82-163, wire.py:271-312.  Returns the per-step stencil coefficients.
+__device__ __forceinline__ Coef scalar_prelude(const Hot& p, const Cold& cold, const Geom& g, int64_t e,
+                                               uint32_t gid, Env& s, Persist& ps) {
     // ---- control-step latch (wire_edm.py:117-121,162-170)
     s.ctrl = s.tss >= p.servo_interval;
     if (s.ctrl) {
+        const wedm_action_ptrs& act = cold.a;
         s.tdelta = act.servo[e];
         s.tvolt = act.target_voltage[e];
         s.mode = act.current_mode[e];
         s.on = act.on_time[e];
         s.off = act.off_time[e];
         s.tss = 0;
-        s.ipk = peak_current(p, tb, s.mode);
+        s.ipk = peak_current(cold, s.mode);
     }
     const uint32_t t = (uint32_t)s.time, ep = (uint32_t)s.episode;
 
     if (!p.disable_ignition) {
-    // ---- short-circuit detection (ignition.py:197-245)
-    // One Philox call serves the whole step, and only lanes that can use a variate pay
-    // for it: no short timer running and (a roll that can succeed, or an idle generator).
-    const bool timers = (s.rnd_rem > 0) || (s.deb_rem > 0);
-    double p_d = 0.0, p_r = 0.0;
-    if (!timers) {
-        double d = s.wp - s.x;
-        double gap = d > 0.0 ? d : 0.0;
-        if (gap < p.hard_short_gap) {  // ignition.py:115-146
-            p_d = 1.0;
-        } else {
-            double crit = p.base_critical_density + p.gap_coefficient * gap;
-            crit = crit < p.max_critical_density ? crit : p.max_critical_density;
-            double ex = -p.sigmoid_steepness * (s.rho - crit);
-            // every uniform is >= 2^-33, and 1/(1+e^ex) < 2^-33 for ex > 24: the roll cannot
-            // succeed, so the exponential need not be evaluated (same decision, exactly)
-            if (ex > 24.0) p_d = 0.0;
-            else if (ex < -500) p_d = 1.0;
-            else p_d = 1.0 / (1.0 + portable_exp(ex));
-        }
-        if (gap >= p.random_short_max_gap) p_r = 0.0;
-        else if (gap <= p.random_short_min_gap) p_r = p.random_short_max_probability;
-        else
-            p_r = (1.0 - (gap - p.random_short_min_gap) / (p.random_short_max_gap - p.random_short_min_gap)) *
-                  p.random_short_max_probability;
-    }
-    W4 w{0u, 0u, 0u, 0u};
-    if (!timers && (p_d > 0.0 || p_r > 0.0 || s.state == 0)) w = philox4(s.key0, s.key1, t, ep, gid, 0u);
-    if (s.rnd_rem > 0) {
-        s.rnd_rem -= 1;
-        s.is_short = 1;
-    } else if (s.deb_rem > 0) {
-        s.deb_rem -= 1;
-        s.is_short = 1;
-    } else if (u32_to_unit(w.x) < p_d) {
-        s.deb_rem = p.debris_short_duration;
-        s.is_short = 1;
-    } else if (u32_to_unit(w.y) < p_r) {
-        s.rnd_rem = p.random_short_duration;
-        s.is_short = 1;
-    } else {
-        s.is_short = 0;
-    }
-    if (s.is_short) s.V = 0.0;
-
-    // `x or default` getters (ignition.py:329-343)
-    const double Vt = s.tvolt != 0.0 ? s.tvolt : p.default_target_voltage;
-    const double on = s.on != 0.0 ? s.on : p.default_on_time;
-    const double off = s.off != 0.0 ? s.off : p.default_off_time;
-    const double Ipk = s.ipk;
-
-    // ---- spark state machine (ignition.py:186-195, 247-319)
-    if (s.state == 0) {
-        s.I = 0.0;
-        if (s.is_short) {
-            s.state = -1; s.y = __builtin_nan(""); s.dur = 0;
-            s.I = Ipk;
-        } else {
-            s.V = Vt;
-            double gap = s.wp - s.x;  // unclamped (ignition.py:353)
-            double lam = p.ln2 / (p.ignition_a * (gap * gap) + p.ignition_b * gap + p.ignition_c);
-            if (u32_to_unit(w.z) < lam) {
-                s.y = 0.0 + (g.h - 0.0) * u32_to_unit(w.w);  // Generator.uniform(0, h)
-                s.state = 1; s.dur = 0;
-                s.V = Vt * p.spark_voltage_factor;
-                s.I = Ipk;
+        // ---- short-circuit detection (ignition.py:197-245)
+        // One Philox call serves the whole step, and only lanes that can use a variate pay
+        // for it: no short timer running and (a roll that can succeed, or an idle generator).
+        const bool timers = (s.rnd_rem > 0) || (s.deb_rem > 0);
+        double p_d = 0.0, p_r = 0.0;
+        if (!timers) {
+            double d = s.wp - s.x;
+            double gap = d > 0.0 ? d : 0.0;
+            if (gap < p.hard_short_gap) {  // ignition.py:115-146
+                p_d = 1.0;
+            } else {
+                double crit = p.base_critical_density + p.gap_coefficient * gap;
+                crit = crit < p.max_critical_density ? crit : p.max_critical_density;
+                double ex = -p.sigmoid_steepness * (s.rho - crit);
+                // every uniform is >= 2^-33, and 1/(1+e^ex) < 2^-33 for ex > 24: the roll cannot
+                // succeed, so the exponential need not be evaluated (same decision, exactly)
+                if (ex > 24.0) p_d = 0.0;
+                else if (ex < -500) p_d = 1.0;
+                else p_d = 1.0 / (1.0 + portable_exp(ex));
+            }
+            if (p.has_random_short) {  // ignition.py:221-230; max_probability == 0 by default
+                const wedm_params* c = opaque(cold.p);
+                if (gap >= c->random_short_max_gap) p_r = 0.0;
+                else if (gap <= c->random_short_min_gap) p_r = c->random_short_max_probability;
+                else
+                    p_r = (1.0 - (gap - c->random_short_min_gap) / (c->random_short_max_gap - c->random_short_min_gap)) *
+                          c->random_short_max_probability;
             }
         }
-    } else if (s.state == 1) {
-        s.dur += 1;
-        if ((double)s.dur >= on) {
-            s.state = -2; s.I = 0.0;
-            if (!s.is_short) s.V = 0.0;
+        W4 w{0u, 0u, 0u, 0u};
+        if (!timers && (p_d > 0.0 || p_r > 0.0 || s.state == 0)) w = philox4(s.key0, s.key1, t, ep, gid, 0u);
+        if (s.rnd_rem > 0) {
+            s.rnd_rem -= 1;
+            s.is_short = 1;
+        } else if (s.deb_rem > 0) {
+            s.deb_rem -= 1;
+            s.is_short = 1;
+        } else if (u32_to_unit(w.x) < p_d) {
+            s.deb_rem = opaque(cold.p)->debris_short_duration;
+            s.is_short = 1;
+        } else if (u32_to_unit(w.y) < p_r) {
+            s.rnd_rem = opaque(cold.p)->random_short_duration;
+            s.is_short = 1;
         } else {
-            s.I = Ipk;
-            if (!s.is_short) s.V = Vt * p.spark_voltage_factor;
+            s.is_short = 0;
         }
-    } else if (s.state == -1) {
-        s.dur += 1;
-        if ((double)s.dur >= on) { s.state = -2; s.I = 0.0; }
-        else s.I = Ipk;
-    } else {  // -2 rest
-        s.dur += 1;
-        if ((double)s.dur >= on + off) {
-            s.state = 0; s.y = __builtin_nan(""); s.dur = 0; s.I = 0.0;
-            if (!s.is_short) s.V = Vt;
-        } else {
+        if (s.is_short) s.V = 0.0;
+
+        // `x or default` getters (ignition.py:329-343)
+        const double Vt = s.tvolt != 0.0 ? s.tvolt : p.default_target_voltage;
+        const double on = s.on != 0.0 ? s.on : p.default_on_time;
+        const double off = s.off != 0.0 ? s.off : p.default_off_time;
+        const double Ipk = s.ipk;
+
+        // ---- spark state machine (ignition.py:186-195, 247-319)
+        if (s.state == 0) {
             s.I = 0.0;
-            if (!s.is_short) s.V = 0.0;
+            if (s.is_short) {
+                s.state = -1; s.y = __builtin_nan(""); s.dur = 0;
+                s.I = Ipk;
+            } else {
+                s.V = Vt;
+                double gap = s.wp - s.x;  // unclamped (ignition.py:353)
+                double lam = p.ln2 / (p.ignition_a * (gap * gap) + p.ignition_b * gap + p.ignition_c);
+                if (u32_to_unit(w.z) < lam) {
+                    const double h = WEDM_COLD_GEOM_F64(cold, p, WEDM_G_HEIGHT, workpiece_height);
+                    s.y = 0.0 + (h - 0.0) * u32_to_unit(w.w);  // Generator.uniform(0, h)
+                    s.state = 1; s.dur = 0;
+                    s.V = Vt * p.spark_voltage_factor;
+                    s.I = Ipk;
+                }
+            }
+        } else if (s.state == 1) {
+            s.dur += 1;
+            if ((double)s.dur >= on) {
+                s.state = -2; s.I = 0.0;
+                if (!s.is_short) s.V = 0.0;
+            } else {
+                s.I = Ipk;
+                if (!s.is_short) s.V = Vt * p.spark_voltage_factor;
+            }
+        } else if (s.state == -1) {
+            s.dur += 1;
+            if ((double)s.dur >= on) { s.state = -2; s.I = 0.0; }
+            else s.I = Ipk;
+        } else {  // -2 rest
+            s.dur += 1;
+            if ((double)s.dur >= on + off) {
+                s.state = 0; s.y = __builtin_nan(""); s.dur = 0; s.I = 0.0;
+                if (!s.is_short) s.V = Vt;
+            } else {
+                s.I = 0.0;
+                if (!s.is_short) s.V = 0.0;
+            }
         }
-    }
     }  // !disable_ignition
     const bool fresh = (s.state == 1) && (s.dur == 0);  // material.py:83, dielectric.py:95
 
     // ---- material removal (material.py:79-174)
     if (fresh) {
+        const Tables& tb = cold.tb;
         int m = s.mode == 0 ? 1 : s.mode;  // None -> "I1" (material.py:104-105)
         if (m < 1 || m > WEDM_MAX_MODE || !tb.crater_valid[m]) { s.err = 1; m = 1; }
         double z = philox_std_normal(s.key0, s.key1, t, ep, gid);
@@ -400,9 +469,11 @@ __device__ __forceinline__ Coef scalar_prelude(const wedm_params& p, const Geom&
         double crater = vol / 1e9;
         s.last_crater = crater;
         if (crater > 0) {
-            double kerf = g.kerf_base + tb.crater_depth[m] / 1000.0;
+            const double kerf_base = WEDM_COLD_GEOM_F64(cold, p, WEDM_G_KERF_BASE, kerf_base);
+            const double h = WEDM_COLD_GEOM_F64(cold, p, WEDM_G_HEIGHT, workpiece_height);
+            double kerf = kerf_base + tb.crater_depth[m] / 1000.0;
             double dx = 0.0;
-            if (kerf > 0 && g.h > 0) dx = crater / (kerf * g.h) * 1000.0;
+            if (kerf > 0 && h > 0) dx = crater / (kerf * h) * 1000.0;
             s.wp += dx;
         }
     } else {
@@ -422,12 +493,13 @@ __device__ __forceinline__ Coef scalar_prelude(const wedm_params& p, const Geom&
             s.rho = 0.0;
         }
         if (__builtin_fabs(gap_um - s.last_gap) > 0.01 || __builtin_fabs(s.rho - s.last_rho) > 0.001) {
-            double cube = cube_cr(gap_um / p.reference_gap);
+            const wedm_params* c = opaque(cold.p);
+            double cube = cube_cr(gap_um / c->reference_gap);
             double gap_factor = cube < 1.0 ? cube : 1.0;
-            double kd = p.debris_obstruction_coeff * s.rho;
+            double kd = c->debris_obstruction_coeff * s.rho;
             double df;
             if (kd < 2.0) df = kd < 0.5 ? (1 - 0.5 * kd) / (1 + 0.5 * kd) : portable_exp(-kd);
-            else df = portable_exp(-p.debris_obstruction_coeff * s.rho);
+            else df = portable_exp(-c->debris_obstruction_coeff * s.rho);
             s.flow = gap_factor * df;
             s.last_gap = gap_um;
             s.last_rho = s.rho;
@@ -439,44 +511,48 @@ __device__ __forceinline__ Coef scalar_prelude(const wedm_params& p, const Geom&
     }
 
     // ---- wire prelude (wire.py:271-312, 349-374)
-    Coef c;
+    Coef cf;
     {
         const double I = s.I, I2 = I * I;
         if (__builtin_fabs(s.flow - s.wire_last_flow) > 0.01) {
-            double ve = p.convection_velocity_factor * s.unwind;
+            const wedm_params* c = opaque(cold.p);
+            double ve = c->convection_velocity_factor * s.unwind;
             ve = ve > -0.9 ? ve : -0.9;
-            double hb = p.base_convection * (1.0 + ve);
-            double fl = 0.1 * p.base_convection;
+            double hb = c->base_convection * (1.0 + ve);
+            double fl = 0.1 * c->base_convection;
             hb = fl > hb ? fl : hb;
-            double he = hb * (1.0 + p.convection_flow_enhancement * s.flow);
+            double he = hb * (1.0 + c->convection_flow_enhancement * s.flow);
             s.h_base = (float)hb;
             s.h_zone = (float)he;
             s.wire_last_flow = s.flow;
+            refresh_convection(p, cold, e, s, ps);
         }
-        c.pidx = -1;
-        c.q = 0.0f;
+        cf.pidx = -1;
+        cf.q = 0.0f;
         if (s.state == 1 && s.y == s.y) {
-            int idx = p.segment_len != 0 ? g.zone_start + (int)py_floordiv(s.y, p.segment_len) : g.zone_start;
+            const wedm_params* c = opaque(cold.p);
+            const int zone_start = WEDM_COLD_GEOM_I32(cold, p, WEDM_GI_ZONE_START, zone_start);
+            const double seg = c->segment_len;
+            int idx = seg != 0 ? zone_start + (int)py_floordiv(s.y, seg) : zone_start;
             if (idx >= 0 && idx < g.n_seg) {
-                c.pidx = idx;
-                c.q = (float)(p.plasma_efficiency * s.V * I);
+                cf.pidx = idx;
+                cf.q = (float)(c->plasma_efficiency * s.V * I);
             }
         }
-        double adv = 0.0;
-        if (__builtin_fabs(s.unwind) > 1e-6) adv = p.rho_c * __builtin_fabs(s.unwind) * g.s_area;
-        c.adv_on = __builtin_fabs(adv) > 1e-9;
-        c.adv = (float)adv;
-        c.joule_on = I2 > 1e-6;
-        c.jf = (float)(g.joule_geom * I2 * p.rho_elec);
-        c.conv_base = s.h_base * g.A;
-        c.conv_zone = s.h_zone * g.A;
+        cf.joule_on = I2 > 1e-6;
+        cf.jf = 0.0f;
+        if (cf.joule_on) {
+            const double joule_geom = WEDM_COLD_GEOM_F64(cold, p, WEDM_G_JOULE_GEOM, joule_geom);
+            cf.jf = (float)(joule_geom * I2 * opaque(cold.p)->rho_elec);
+        }
     }
-    return c;
+    return cf;
 }
 
 // one cell of wire.py:58-123, float32 op for op; tm1/tc/tp1 are OLD temperatures
 __device__ __forceinline__ float stencil_cell(int i, int n_seg, float tm1, float tc, float tp1, const Geom& g,
-                                              const Coef& c, float tref, float alpha, float tdiel) {
+                                              const Coef& c, const Persist& ps, float tref, float alpha,
+                                              float tdiel) {
     float d;
     if (i < n_seg - 1) {
         float t2 = 2.0f * tc;
@@ -491,19 +567,19 @@ __device__ __forceinline__ float stencil_cell(int i, int n_seg, float tm1, float
     }
     if (i == c.pidx) d = d + c.q;
     bool in_zone = (i >= g.az_start) && (i < g.az_end);
-    float conv = in_zone ? c.conv_zone : c.conv_base;
+    float conv = in_zone ? ps.conv_zone : ps.conv_base;
     d = d - conv * (tc - tdiel);
-    if (c.adv_on) d = d + c.adv * (tm1 - tc);
+    if (ps.adv_on) d = d + ps.adv * (tm1 - tc);
     return tc + d * g.tuf;
 }
 
 // ------------------------------------------- scalar epilogue (modules 4b, 5, env)
 // wire.py:376-388, wire_edm.py:129-146,172-179, mechanics.py:79-114
-__device__ __forceinline__ void scalar_epilogue(const wedm_params& p, Env& s, float tmax) {
+__device__ __forceinline__ void scalar_epilogue(const Hot& p, Env& s, float tmax) {
     s.tmax = tmax;
-    if (tmax > (float)p.critical_temperature) s.tcrit += 1;
+    if (tmax > p.tcrit) s.tcrit += 1;
     else s.tcrit = 0;
-    if (tmax > (float)p.breaking_temperature) s.broken = 1;
+    if (tmax > p.tbreak) s.broken = 1;
     if (s.broken) {  // early return before mechanics and clocks
         s.done = 1;
         return;
@@ -539,8 +615,9 @@ __device__ __forceinline__ void scalar_epilogue(const wedm_params& p, Env& s, fl
     else if (s.wp >= s.tpos) { s.reached = 1; s.done = 1; }
 }
 
-__device__ __forceinline__ void write_obs(const wedm_params& p, const wedm_state_ptrs& st, int64_t e, const Env& s) {
-    if (!st.obs || p.obs_dim < 8) return;
+__device__ __forceinline__ void write_obs(const Cold& cold, int64_t e, const Env& s) {
+    const wedm_state_ptrs& st = cold.s;
+    if (!st.obs || cold.p->obs_dim < 8) return;
     const int64_t stride = st.stride;
     float* o = st.obs + e;
     o[0 * stride] = (float)(s.wp - s.x);

@@ -52,11 +52,8 @@ struct SegTable {
 };
 
 struct KArgs {
-    wedm_params p;
-    wedm_state_ptrs s;
-    wedm_geom_ptrs g;
-    wedm_action_ptrs a;
-    Tables tb;
+    Hot hot;    // every-step parameters, by value
+    Cold cold;  // device pointers: full wedm_params copy, state/geometry/action blocks, tables
     int32_t num_envs;
     int32_t n_substeps;
     int32_t n_seg_max;
@@ -80,8 +77,8 @@ struct LdsT {
 // "next" temperatures are loaded before any of the tile's stores, so every cell sees
 // OLD neighbours (explicit Euler) with one load + one store per cell.
 template <class TA>
-__device__ __forceinline__ float stencil_pass(const TA& T, const Geom& g, const Coef& c, float spool, float tref,
-                                              float alpha, float tdiel) {
+__device__ __forceinline__ float stencil_pass(const TA& T, const Geom& g, const Coef& c, const Persist& ps,
+                                              float spool, float tref, float alpha, float tdiel) {
     const int n = g.n_seg;
     T.st(0, spool);  // boundary condition (wire.py:83,123)
     float tmax = spool;
@@ -99,7 +96,7 @@ __device__ __forceinline__ float stencil_pass(const TA& T, const Geom& g, const 
         for (int u = 0; u < 8; ++u) {
             int i = i0 + u;
             if (i < n) {
-                float tn = stencil_cell(i, n, tm1, tc, nx[u], g, c, tref, alpha, tdiel);
+                float tn = stencil_cell(i, n, tm1, tc, nx[u], g, c, ps, tref, alpha, tdiel);
                 T.st(i, tn);
                 tmax = tn > tmax ? tn : tmax;
                 tm1 = tc;
@@ -113,14 +110,14 @@ __device__ __forceinline__ float stencil_pass(const TA& T, const Geom& g, const 
 template <class TA>
 __device__ __forceinline__ void run_substeps(const KArgs& k, const Geom& g, int64_t e, uint32_t gid, Env& s,
                                              const TA& T) {
-    const float spool = (float)k.p.spool_T, tref = (float)k.p.temp_ref, alpha = (float)k.p.alpha_rho;
-    const float tdiel = (float)k.p.dielectric_temperature;
+    Persist ps;
+    init_persist(k.hot, k.cold, e, s, ps);
     for (int it = 0; it < k.n_substeps; ++it) {
         if (s.done) break;
-        Coef c = scalar_prelude(k.p, g, k.tb, k.a, e, gid, s);
-        float tmax = stencil_pass(T, g, c, spool, tref, alpha, tdiel);
-        scalar_epilogue(k.p, s, tmax);
-        if (s.ctrl) write_obs(k.p, k.s, e, s);
+        Coef c = scalar_prelude(k.hot, k.cold, g, e, gid, s, ps);
+        float tmax = stencil_pass(T, g, c, ps, k.hot.spool, k.hot.tref, k.hot.alpha, k.hot.tdiel);
+        scalar_epilogue(k.hot, s, tmax);
+        if (s.ctrl) write_obs(k.cold, e, s);
     }
 }
 
@@ -128,14 +125,14 @@ __global__ void __launch_bounds__(256) wedm_step_global(const KArgs k) {
     const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (e >= k.num_envs) return;
     Env s;
-    load_env(k.s, e, s);
+    load_env(k.cold.s, e, s);
     if (s.done) return;
-    s.ipk = peak_current(k.p, k.tb, s.mode);
+    s.ipk = peak_current(k.cold, s.mode);
     Geom g;
-    load_geom(k.p, k.g, k.s.stride, e, g);
-    GlobalT T{k.s.T + e, k.s.stride};
-    run_substeps(k, g, e, k.p.env_id_offset + (uint32_t)e, s, T);
-    store_env(k.s, e, s);
+    load_geom(k.hot, k.cold, e, g);
+    GlobalT T{k.cold.s.T + e, k.cold.s.stride};
+    run_substeps(k, g, e, k.hot.env_id_offset + (uint32_t)e, s, T);
+    store_env(k.cold.s, e, s);
 }
 
 __global__ void __launch_bounds__(64) wedm_step_lds(const KArgs k) {
@@ -144,24 +141,24 @@ __global__ void __launch_bounds__(64) wedm_step_lds(const KArgs k) {
     const int64_t e = (int64_t)blockIdx.x * 64 + lane;
     if (e >= k.num_envs) return;
     Env s;
-    load_env(k.s, e, s);
+    load_env(k.cold.s, e, s);
     if (s.done) return;
-    s.ipk = peak_current(k.p, k.tb, s.mode);
+    s.ipk = peak_current(k.cold, s.mode);
     Geom g;
-    load_geom(k.p, k.g, k.s.stride, e, g);
+    load_geom(k.hot, k.cold, e, g);
     LdsT T{lds + lane};
-    const float* src = k.s.T + e;
-    const int64_t stride = k.s.stride;
+    const float* src = k.cold.s.T + e;
+    const int64_t stride = k.cold.s.stride;
     for (int i = 0; i < g.n_seg; ++i) T.st(i, src[(int64_t)i * stride]);
-    run_substeps(k, g, e, k.p.env_id_offset + (uint32_t)e, s, T);
-    float* dst = k.s.T + e;
+    run_substeps(k, g, e, k.hot.env_id_offset + (uint32_t)e, s, T);
+    float* dst = k.cold.s.T + e;
     for (int i = 0; i < g.n_seg; ++i) dst[(int64_t)i * stride] = T.ld(i);
-    store_env(k.s, e, s);
+    store_env(k.cold.s, e, s);
 }
 
-
 // ===================================================== fused kernel, L lanes / env
-__device__ __forceinline__ float fmax_gt(float a, float b) { return b > a ? b : a; }
+// np.max over finite temperatures; maps to v_max_f32 / v_max3_f32
+__device__ __forceinline__ float fmax_gt(float a, float b) { return __builtin_fmaxf(a, b); }
 
 // Interior cells of one segment: identical formula in every lane, coefficients are
 // per-lane registers chosen once per segment.  JOULE / ADV are wave-uniform.
@@ -215,8 +212,8 @@ __global__ void __launch_bounds__(256) wedm_step_fused(const KArgs k) {
     const bool live = e < k.num_envs;
     const SegTable* __restrict__ sg = k.segs;
     const int C = sg->C;
-    const int n = k.p.n_seg;
-    const int64_t stride = k.s.stride;
+    const int n = k.hot.n_seg;
+    const int64_t stride = k.cold.s.stride;
 
     // ---- stage the block's EPB wire columns: coalesced rows of T[seg][env] -> LDS
     {
@@ -224,7 +221,7 @@ __global__ void __launch_bounds__(256) wedm_step_fused(const KArgs k) {
         int ci = 0, ji = r;                        // (chunk, cell) of row i = i0 + r
         while (ji >= C) { ji -= C; ++ci; }
         const bool ok = e0 + sel < k.num_envs;
-        const float* src = k.s.T + e0 + sel;
+        const float* src = k.cold.s.T + e0 + sel;
         for (int i0 = 0; i0 < n; i0 += L) {
             const int i = i0 + r;
             if (i < n && ok) lds[ji * 256 + sel * L + ci] = src[(int64_t)i * stride];
@@ -236,30 +233,32 @@ __global__ void __launch_bounds__(256) wedm_step_fused(const KArgs k) {
 
     Env s;
     Geom g;
-    load_geom(k.p, k.g, stride, live ? e : 0, g);
-    if (live) load_env(k.s, e, s);
-    else s.done = 1;
-    if (!s.done) s.ipk = peak_current(k.p, k.tb, s.mode);
-    const uint32_t gid = k.p.env_id_offset + (uint32_t)e;
+    Persist ps{0.0f, 0.0f, 0.0f, 0};
+    load_geom(k.hot, k.cold, live ? e : 0, g);
+    if (live) load_env(k.cold.s, e, s);
+    else { s.done = 1; s.unwind = 0.0; s.h_base = 0.0f; s.h_zone = 0.0f; }
+    if (!s.done) {
+        s.ipk = peak_current(k.cold, s.mode);
+        init_persist(k.hot, k.cold, e, s, ps);
+    }
+    const uint32_t gid = k.hot.env_id_offset + (uint32_t)e;
 
     float* col = lds + tid;
     const int cbase = c * C;
-    const float spool = (float)k.p.spool_T, tref = (float)k.p.temp_ref, alpha = (float)k.p.alpha_rho;
-    const float tdiel = (float)k.p.dielectric_temperature;
+    const float spool = k.hot.spool, tref = k.hot.tref, alpha = k.hot.alpha, tdiel = k.hot.tdiel;
     const int n_segs = sg->n_segs;
+    // advection is on or off for the whole launch (no module changes the unwinding speed)
+    const bool adv_all = __all(ps.adv_on || s.done), adv_none = !__any(ps.adv_on && !s.done);
 
     for (int it = 0; it < k.n_substeps; ++it) {
         if (__all(s.done)) break;
-        Coef cf;
-        if (!s.done) cf = scalar_prelude(k.p, g, k.tb, k.a, e, gid, s);
-        else { cf.jf = 0.f; cf.q = 0.f; cf.conv_base = 0.f; cf.conv_zone = 0.f; cf.adv = 0.f; cf.joule_on = 0; cf.adv_on = 0; cf.pidx = -1; }
+        Coef cf{0.0f, 0.0f, 0, -1};
+        if (!s.done) cf = scalar_prelude(k.hot, k.cold, g, e, gid, s, ps);
 
         // ---- halos: OLD neighbour values, read before any lane of this wave stores
         const float halo_l = (c > 0) ? col[(C - 1) * 256 - 1] : spool;
         const float halo_r = (c < L - 1) ? col[1] : 0.0f;
 
-        // wave-uniform mode switches
-        const bool adv_all = __all(cf.adv_on || s.done), adv_none = !__any(cf.adv_on && !s.done);
         // irregular waves (mixed advection, negative plasma heat, a frozen environment) take
         // the predicated path for every cell; results are identical, only slower
         const bool all_slow = !(adv_all || adv_none) || __any(cf.q < 0.0f) || __any(s.done);
@@ -274,7 +273,7 @@ __global__ void __launch_bounds__(256) wedm_step_fused(const KArgs k) {
                 if (cf.pidx == 1) tm = spool;  // T[0] is held at the spool temperature (wire.py:83)
                 const float tcc = col[jp * 256];
                 const float tp = jp < C - 1 ? col[(jp + 1) * 256] : halo_r;
-                tpl = stencil_cell(cf.pidx, n, tm, tcc, tp, g, cf, tref, alpha, tdiel);
+                tpl = stencil_cell(cf.pidx, n, tm, tcc, tp, g, cf, ps, tref, alpha, tdiel);
             }
         }
 
@@ -286,15 +285,15 @@ __global__ void __launch_bounds__(256) wedm_step_fused(const KArgs k) {
             const bool in_zone = (sg->zone[kseg] >> c) & 1;
             const bool in_joule = (sg->joule[kseg] >> c) & 1;
             if (sg->fast[kseg] && !all_slow) {
-                const float conv = in_zone ? cf.conv_zone : cf.conv_base;
+                const float conv = in_zone ? ps.conv_zone : ps.conv_base;
                 const float jfe = (in_joule && cf.joule_on && !s.done) ? cf.jf : 0.0f;
                 const bool joule_any = __any(jfe != 0.0f);
                 if (joule_any) {
-                    if (adv_all) fast_segment<true, true>(col, j0, j1, tm1, tc, tmax, g.k, g.tuf, conv, tdiel, cf.adv, jfe, alpha, tref);
-                    else fast_segment<true, false>(col, j0, j1, tm1, tc, tmax, g.k, g.tuf, conv, tdiel, cf.adv, jfe, alpha, tref);
+                    if (adv_all) fast_segment<true, true>(col, j0, j1, tm1, tc, tmax, g.k, g.tuf, conv, tdiel, ps.adv, jfe, alpha, tref);
+                    else fast_segment<true, false>(col, j0, j1, tm1, tc, tmax, g.k, g.tuf, conv, tdiel, ps.adv, jfe, alpha, tref);
                 } else {
-                    if (adv_all) fast_segment<false, true>(col, j0, j1, tm1, tc, tmax, g.k, g.tuf, conv, tdiel, cf.adv, jfe, alpha, tref);
-                    else fast_segment<false, false>(col, j0, j1, tm1, tc, tmax, g.k, g.tuf, conv, tdiel, cf.adv, jfe, alpha, tref);
+                    if (adv_all) fast_segment<false, true>(col, j0, j1, tm1, tc, tmax, g.k, g.tuf, conv, tdiel, ps.adv, jfe, alpha, tref);
+                    else fast_segment<false, false>(col, j0, j1, tm1, tc, tmax, g.k, g.tuf, conv, tdiel, ps.adv, jfe, alpha, tref);
                 }
             } else {
                 // boundary cells, chunk tails and irregular steps: fully predicated per lane
@@ -302,7 +301,7 @@ __global__ void __launch_bounds__(256) wedm_step_fused(const KArgs k) {
                     const int i = cbase + j;
                     const float tp1 = (j < C - 1) ? col[(j + 1) * 256] : halo_r;
                     float tn = spool;
-                    if (i >= 1 && i < n) tn = stencil_cell(i, n, tm1, tc, tp1, g, cf, tref, alpha, tdiel);
+                    if (i >= 1 && i < n) tn = stencil_cell(i, n, tm1, tc, tp1, g, cf, ps, tref, alpha, tdiel);
                     if (i < n && !s.done) {
                         col[j * 256] = tn;
                         tmax = fmax_gt(tmax, tn);
@@ -319,8 +318,8 @@ __global__ void __launch_bounds__(256) wedm_step_fused(const KArgs k) {
 #pragma unroll
         for (int m = 1; m < L; m <<= 1) tmax = fmax_gt(tmax, __shfl_xor(tmax, m));
         if (!s.done) {
-            scalar_epilogue(k.p, s, tmax);
-            if (s.ctrl && c == 0) write_obs(k.p, k.s, e, s);
+            scalar_epilogue(k.hot, s, tmax);
+            if (s.ctrl && c == 0) write_obs(k.cold, e, s);
         }
     }
 
@@ -330,7 +329,7 @@ __global__ void __launch_bounds__(256) wedm_step_fused(const KArgs k) {
         int ci = 0, ji = r;
         while (ji >= C) { ji -= C; ++ci; }
         const bool ok = e0 + sel < k.num_envs;
-        float* dst = k.s.T + e0 + sel;
+        float* dst = k.cold.s.T + e0 + sel;
         for (int i0 = 0; i0 < n; i0 += L) {
             const int i = i0 + r;
             if (i < n && ok) dst[(int64_t)i * stride] = lds[ji * 256 + sel * L + ci];
@@ -338,7 +337,7 @@ __global__ void __launch_bounds__(256) wedm_step_fused(const KArgs k) {
             while (ji >= C) { ji -= C; ++ci; }
         }
     }
-    if (live && c == 0) store_env(k.s, e, s);
+    if (live && c == 0) store_env(k.cold.s, e, s);
 }
 
 __global__ void __launch_bounds__(256)
@@ -408,6 +407,7 @@ struct wedm_ctx {
     wedm_state_ptrs s{};
     wedm_geom_ptrs g{};
     void* tables_dev = nullptr;
+    wedm_params* params_dev = nullptr;  // "cold" parameters, read through rare branches only
     Tables tb{};
     int32_t variant = 0;
     int32_t lanes = 0;                 // lanes per environment for the fused kernel (0 = auto)
@@ -556,6 +556,14 @@ int32_t wedm_create(const wedm_params* params, int32_t num_envs, int32_t n_seg_m
     ctx->tb.crater_std = d + 2 * n;
     ctx->tb.crater_depth = d + 3 * n;
     ctx->tb.crater_valid = (const int32_t*)(d + 4 * n);
+    if ((e = hipMalloc((void**)&ctx->params_dev, sizeof(wedm_params))) != hipSuccess ||
+        (e = hipMemcpy(ctx->params_dev, params, sizeof(wedm_params), hipMemcpyHostToDevice)) != hipSuccess) {
+        g_create_error = std::string("params copy: ") + hipGetErrorString(e);
+        if (ctx->params_dev) (void)hipFree(ctx->params_dev);
+        (void)hipFree(ctx->tables_dev);
+        delete ctx;
+        return WEDM_ERR_HIP;
+    }
     if (!params->per_env_geometry) {
         SegTable host_tabs[5];
         const int Ls[5] = {1, 2, 4, 8, 16};
@@ -567,6 +575,7 @@ int32_t wedm_create(const wedm_params* params, int32_t num_envs, int32_t n_seg_m
             (e = hipMemcpy(ctx->segs_dev, host_tabs, sizeof(host_tabs), hipMemcpyHostToDevice)) != hipSuccess) {
             g_create_error = std::string("segment tables: ") + hipGetErrorString(e);
             if (ctx->segs_dev) (void)hipFree(ctx->segs_dev);
+            (void)hipFree(ctx->params_dev);
             (void)hipFree(ctx->tables_dev);
             delete ctx;
             return WEDM_ERR_HIP;
@@ -595,6 +604,7 @@ int32_t wedm_destroy(wedm_ctx* ctx) {
     if (!ctx) return WEDM_ERR_BAD_ARG;
     if (ctx->tables_dev) (void)hipFree(ctx->tables_dev);
     if (ctx->segs_dev) (void)hipFree(ctx->segs_dev);
+    if (ctx->params_dev) (void)hipFree(ctx->params_dev);
     delete ctx;
     return WEDM_OK;
 }
@@ -656,12 +666,31 @@ int32_t wedm_step(wedm_ctx* ctx, int32_t n_substeps, const wedm_action_ptrs* act
         return fail(ctx, WEDM_ERR_NOT_BOUND, "wedm_step: per_env_geometry set but wedm_bind_geometry not called");
     if (n_substeps == 0) return WEDM_OK;
 
+    const wedm_params& P = ctx->p;
     KArgs k;
-    k.p = ctx->p;
-    k.s = ctx->s;
-    k.g = ctx->g;
-    k.a = *action;
-    k.tb = ctx->tb;
+    Hot& h = k.hot;
+    h.hard_short_gap = P.hard_short_gap; h.base_critical_density = P.base_critical_density;
+    h.gap_coefficient = P.gap_coefficient; h.max_critical_density = P.max_critical_density;
+    h.sigmoid_steepness = P.sigmoid_steepness;
+    h.ignition_a = P.ignition_a; h.ignition_b = P.ignition_b; h.ignition_c = P.ignition_c; h.ln2 = P.ln2;
+    h.default_target_voltage = P.default_target_voltage; h.default_on_time = P.default_on_time;
+    h.default_off_time = P.default_off_time; h.spark_voltage_factor = P.spark_voltage_factor;
+    h.debris_removal_per_us = P.debris_removal_per_us;
+    h.dt_s = P.dt_s; h.damping_coeff = P.damping_coeff; h.stiffness_coeff = P.stiffness_coeff;
+    h.omega_n = P.omega_n; h.max_acceleration = P.max_acceleration; h.max_jerk_dt = P.max_jerk_dt;
+    h.max_speed = P.max_speed;
+    h.spool = (float)P.spool_T; h.tref = (float)P.temp_ref; h.alpha = (float)P.alpha_rho;
+    h.tdiel = (float)P.dielectric_temperature;
+    h.tcrit = (float)P.critical_temperature; h.tbreak = (float)P.breaking_temperature;
+    h.servo_interval = P.servo_interval; h.dt_us = P.dt_us; h.control_mode = P.control_mode;
+    h.disable_ignition = P.disable_ignition;
+    h.has_random_short = P.random_short_max_probability != 0.0 ? 1 : 0;
+    h.per_env_geometry = P.per_env_geometry; h.env_id_offset = P.env_id_offset; h.n_seg = P.n_seg;
+    k.cold.p = ctx->params_dev;
+    k.cold.g = ctx->g;
+    k.cold.a = *action;
+    k.cold.s = ctx->s;
+    k.cold.tb = ctx->tb;
     k.num_envs = ctx->num_envs;
     k.n_substeps = n_substeps;
     k.n_seg_max = ctx->n_seg_max;
