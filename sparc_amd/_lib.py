@@ -10,7 +10,11 @@ from pathlib import Path
 
 from . import _abi
 
-LIB_PATH = Path(__file__).resolve().parent / "libwedm_hip.so"
+# WEDM_HIP_LIB lets the profiling scripts load an instrumented build of the SAME library;
+# it never selects a different implementation.
+import os
+
+LIB_PATH = Path(os.environ.get("WEDM_HIP_LIB") or (Path(__file__).resolve().parent / "libwedm_hip.so"))
 
 
 class WedmError(RuntimeError):

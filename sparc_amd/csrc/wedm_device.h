@@ -334,8 +334,8 @@ __device__ __forceinline__ void init_persist(const Hot& hot, const Cold& cold, i
         const double s_area = WEDM_COLD_GEOM_F64(cold, hot, WEDM_G_S_AREA, s_area);
         adv = cold.p->rho_c * __builtin_fabs(s.unwind) * s_area;
     }
-    ps.adv_on = __builtin_fabs(adv) > 1e-9;
-    ps.adv = (float)adv;
+    ps.adv_on = __builtin_fabs(adv) > 1e-9;  // wire.py:115
+    ps.adv = ps.adv_on ? (float)adv : 0.0f;
     refresh_convection(hot, cold, e, s, ps);
 }
 
@@ -358,102 +358,86 @@ __device__ __forceinline__ Coef scalar_prelude(const Hot& p, const Cold& cold, c
     }
     const uint32_t t = (uint32_t)s.time, ep = (uint32_t)s.episode;
 
+#ifdef WEDM_ABL_NO_IGN
+    if (false) {
+#else
     if (!p.disable_ignition) {
-        // ---- short-circuit detection (ignition.py:197-245)
-        // One Philox call serves the whole step, and only lanes that can use a variate pay
-        // for it: no short timer running and (a roll that can succeed, or an idle generator).
-        const bool timers = (s.rnd_rem > 0) || (s.deb_rem > 0);
-        double p_d = 0.0, p_r = 0.0;
-        if (!timers) {
-            double d = s.wp - s.x;
-            double gap = d > 0.0 ? d : 0.0;
-            if (gap < p.hard_short_gap) {  // ignition.py:115-146
-                p_d = 1.0;
-            } else {
-                double crit = p.base_critical_density + p.gap_coefficient * gap;
-                crit = crit < p.max_critical_density ? crit : p.max_critical_density;
-                double ex = -p.sigmoid_steepness * (s.rho - crit);
-                // every uniform is >= 2^-33, and 1/(1+e^ex) < 2^-33 for ex > 24: the roll cannot
-                // succeed, so the exponential need not be evaluated (same decision, exactly)
-                if (ex > 24.0) p_d = 0.0;
-                else if (ex < -500) p_d = 1.0;
-                else p_d = 1.0 / (1.0 + portable_exp(ex));
-            }
-            if (p.has_random_short) {  // ignition.py:221-230; max_probability == 0 by default
-                const wedm_params* c = opaque(cold.p);
-                if (gap >= c->random_short_max_gap) p_r = 0.0;
-                else if (gap <= c->random_short_min_gap) p_r = c->random_short_max_probability;
-                else
-                    p_r = (1.0 - (gap - c->random_short_min_gap) / (c->random_short_max_gap - c->random_short_min_gap)) *
-                          c->random_short_max_probability;
-            }
+#endif
+        // ---- short-circuit detection (ignition.py:197-245), written branch-free: in a
+        // wave the lanes are in different generator states, so every per-lane `if` would be
+        // executed by the whole wave anyway; selects avoid the exec-mask bookkeeping.  Real
+        // branches remain only around rare, heavy work (exp, Philox, cold parameters).
+        const bool timer_r = s.rnd_rem > 0;                 // random-short timer runs (checked first)
+        const bool timer_d = !timer_r && (s.deb_rem > 0);   // debris-short timer runs
+        const bool timers = timer_r || timer_d;
+        const double d0 = s.wp - s.x;                       // unclamped gap (ignition.py:353)
+        const double gap = d0 > 0.0 ? d0 : 0.0;
+        const bool hard = gap < p.hard_short_gap;           // ignition.py:127-128
+        double crit = p.base_critical_density + p.gap_coefficient * gap;
+        crit = crit < p.max_critical_density ? crit : p.max_critical_density;
+        const double ex = -p.sigmoid_steepness * (s.rho - crit);
+        // every uniform is >= 2^-33 and 1/(1+e^ex) < 2^-33 for ex > 24: the roll cannot succeed,
+        // so the exponential need not be evaluated there (same decision, exactly)
+        double p_d = (hard || ex < -500) ? 1.0 : 0.0;
+        if (!timers && !hard && ex <= 24.0 && ex >= -500) p_d = 1.0 / (1.0 + portable_exp(ex));
+        double p_r = 0.0;
+        if (p.has_random_short) {  // ignition.py:221-230; max_probability == 0 by default
+            const wedm_params* c = opaque(cold.p);
+            if (gap >= c->random_short_max_gap) p_r = 0.0;
+            else if (gap <= c->random_short_min_gap) p_r = c->random_short_max_probability;
+            else
+                p_r = (1.0 - (gap - c->random_short_min_gap) / (c->random_short_max_gap - c->random_short_min_gap)) *
+                      c->random_short_max_probability;
         }
+        const bool idle = s.state == 0;
         W4 w{0u, 0u, 0u, 0u};
-        if (!timers && (p_d > 0.0 || p_r > 0.0 || s.state == 0)) w = philox4(s.key0, s.key1, t, ep, gid, 0u);
-        if (s.rnd_rem > 0) {
-            s.rnd_rem -= 1;
-            s.is_short = 1;
-        } else if (s.deb_rem > 0) {
-            s.deb_rem -= 1;
-            s.is_short = 1;
-        } else if (u32_to_unit(w.x) < p_d) {
-            s.deb_rem = opaque(cold.p)->debris_short_duration;
-            s.is_short = 1;
-        } else if (u32_to_unit(w.y) < p_r) {
-            s.rnd_rem = opaque(cold.p)->random_short_duration;
-            s.is_short = 1;
-        } else {
-            s.is_short = 0;
+#ifndef WEDM_ABL_NO_PHILOX
+        if (!timers && (p_d > 0.0 || p_r > 0.0 || idle)) w = philox4(s.key0, s.key1, t, ep, gid, 0u);
+#else
+        w = W4{t * 2654435761u + gid, 1u, 0xffffffffu - (t ^ gid) * 40503u, 7u};
+#endif
+        const bool new_d = !timers && (u32_to_unit(w.x) < p_d);
+        const bool new_r = !timers && !new_d && (u32_to_unit(w.y) < p_r);
+        if (new_d || new_r) {  // rare: a short begins (durations are cold parameters)
+            const wedm_params* c = opaque(cold.p);
+            if (new_d) s.deb_rem = c->debris_short_duration;
+            else s.rnd_rem = c->random_short_duration;
         }
-        if (s.is_short) s.V = 0.0;
+        s.rnd_rem = timer_r ? s.rnd_rem - 1 : s.rnd_rem;
+        s.deb_rem = timer_d ? s.deb_rem - 1 : s.deb_rem;
+        const bool shrt = timers || new_d || new_r;
+        s.is_short = shrt ? 1 : 0;
 
         // `x or default` getters (ignition.py:329-343)
         const double Vt = s.tvolt != 0.0 ? s.tvolt : p.default_target_voltage;
         const double on = s.on != 0.0 ? s.on : p.default_on_time;
         const double off = s.off != 0.0 ? s.off : p.default_off_time;
+        const double Vs = Vt * p.spark_voltage_factor;
         const double Ipk = s.ipk;
 
-        // ---- spark state machine (ignition.py:186-195, 247-319)
-        if (s.state == 0) {
-            s.I = 0.0;
-            if (s.is_short) {
-                s.state = -1; s.y = __builtin_nan(""); s.dur = 0;
-                s.I = Ipk;
-            } else {
-                s.V = Vt;
-                double gap = s.wp - s.x;  // unclamped (ignition.py:353)
-                double lam = p.ln2 / (p.ignition_a * (gap * gap) + p.ignition_b * gap + p.ignition_c);
-                if (u32_to_unit(w.z) < lam) {
-                    const double h = WEDM_COLD_GEOM_F64(cold, p, WEDM_G_HEIGHT, workpiece_height);
-                    s.y = 0.0 + (h - 0.0) * u32_to_unit(w.w);  // Generator.uniform(0, h)
-                    s.state = 1; s.dur = 0;
-                    s.V = Vt * p.spark_voltage_factor;
-                    s.I = Ipk;
-                }
-            }
-        } else if (s.state == 1) {
-            s.dur += 1;
-            if ((double)s.dur >= on) {
-                s.state = -2; s.I = 0.0;
-                if (!s.is_short) s.V = 0.0;
-            } else {
-                s.I = Ipk;
-                if (!s.is_short) s.V = Vt * p.spark_voltage_factor;
-            }
-        } else if (s.state == -1) {
-            s.dur += 1;
-            if ((double)s.dur >= on) { s.state = -2; s.I = 0.0; }
-            else s.I = Ipk;
-        } else {  // -2 rest
-            s.dur += 1;
-            if ((double)s.dur >= on + off) {
-                s.state = 0; s.y = __builtin_nan(""); s.dur = 0; s.I = 0.0;
-                if (!s.is_short) s.V = Vt;
-            } else {
-                s.I = 0.0;
-                if (!s.is_short) s.V = 0.0;
-            }
+        // ---- spark state machine (ignition.py:186-195, 247-319) as selects
+        const bool spk = s.state == 1, pls = s.state == -1, rst = s.state == -2;
+        const double lam = p.ln2 / (p.ignition_a * (d0 * d0) + p.ignition_b * d0 + p.ignition_c);
+        const bool ign = idle && !shrt && (u32_to_unit(w.z) < lam);   // _should_ignite
+        const bool to_pulse = idle && shrt;                           // short during idle -> pulse
+        const int32_t dur1 = s.dur + 1;
+        const double ddur = (double)dur1;
+        const bool end_on = (spk || pls) && (ddur >= on);             // spark / pulse finished
+        const bool end_rest = rst && (ddur >= on + off);              // rest finished
+        const bool burning = (ign || to_pulse) || ((spk || pls) && !end_on);
+        double V = shrt ? 0.0 : s.V;                                  // ignition.py:182-183
+        V = (idle && !shrt) ? (ign ? Vs : Vt) : V;
+        V = (spk && !shrt) ? (end_on ? 0.0 : Vs) : V;
+        V = (rst && !shrt) ? (end_rest ? Vt : 0.0) : V;
+        s.V = V;
+        s.I = burning ? Ipk : 0.0;
+        if (ign) {  // rare: spark location, Generator.uniform(0, h)
+            const double h = WEDM_COLD_GEOM_F64(cold, p, WEDM_G_HEIGHT, workpiece_height);
+            s.y = 0.0 + (h - 0.0) * u32_to_unit(w.w);
         }
+        s.y = (to_pulse || end_rest) ? __builtin_nan("") : s.y;
+        s.dur = idle ? ((ign || to_pulse) ? 0 : s.dur) : (end_rest ? 0 : dur1);
+        s.state = ign ? 1 : to_pulse ? -1 : end_on ? -2 : end_rest ? 0 : s.state;
     }  // !disable_ignition
     const bool fresh = (s.state == 1) && (s.dur == 0);  // material.py:83, dielectric.py:95
 
@@ -481,6 +465,7 @@ __device__ __forceinline__ Coef scalar_prelude(const Hot& p, const Cold& cold, c
     }
 
     // ---- dielectric / debris (dielectric.py:82-163)
+#ifndef WEDM_ABL_NO_DIEL
     {
         double d = s.wp - s.x;
         double gap_um = d > 0.001 ? d : 0.001;
@@ -509,6 +494,7 @@ __device__ __forceinline__ Coef scalar_prelude(const Hot& p, const Cold& cold, c
             s.debris = nv > 0.0 ? nv : 0.0;
         }
     }
+#endif
 
     // ---- wire prelude (wire.py:271-312, 349-374)
     Coef cf;
@@ -584,6 +570,7 @@ __device__ __forceinline__ void scalar_epilogue(const Hot& p, Env& s, float tmax
         s.done = 1;
         return;
     }
+#ifndef WEDM_ABL_NO_MECH
     {
         double x = s.x, v = s.v, a_nom;
         if (p.control_mode == 0) {
@@ -606,6 +593,7 @@ __device__ __forceinline__ void scalar_epilogue(const Hot& p, Env& s, float tmax
         s.v = v;
         s.x = x;
     }
+#endif
     s.time += p.dt_us;
     s.tss += p.dt_us;
     s.tsov += p.dt_us;

@@ -32,24 +32,36 @@
 #include <cstdio>
 #include <cstring>
 #include <new>
-#include <set>
+#include <vector>
 #include <string>
 
 #include "wedm_device.h"
 
 using namespace wedm;
 
-// Wave-uniform description of one step's walk over a chunk of C cells (see
-// build_segments()).  Segment k covers chunk-local cells [j0[k], j0[k+1]).
-#define WEDM_MAX_SEGS 128
-struct SegTable {
-    int32_t n_segs;
-    int32_t C;                          // cells per chunk = ceil(n_seg / L)
-    int16_t j0[WEDM_MAX_SEGS + 1];
-    uint8_t fast[WEDM_MAX_SEGS];        // 1: every lane's cell is an interior cell (1 <= i <= n-2)
-    uint16_t zone[WEDM_MAX_SEGS];       // bit c: chunk c is inside the workpiece zone here
-    uint16_t joule[WEDM_MAX_SEGS];      // bit c: chunk c is between the contacts here
+// Wave-uniform description of one step's walk over a chunk of C cells (see build_walk()).
+// Cell j of chunk c is wire segment i = c*C + j.  The chunk is walked in ceil(C/8) tiles of 8
+// cells.  A NORMAL tile holds 8 interior cells (1 <= i <= n-2) with the same zone / contact
+// membership in every chunk; anything else (boundary cells, a breakpoint inside the tile, the
+// padded tail) is a SPECIAL tile that looks its flags up per cell.
+#define WEDM_MAX_C 160  // 160 KB LDS / (256 lanes * 4 B)
+#define WEDM_MAX_TILES (WEDM_MAX_C / 8 + 1)
+struct WalkTable {
+    int32_t C;                             // cells per chunk = ceil(n_seg / L)
+    int32_t n_tiles;                       // ceil(C / 8)
+    // dword entries so that the (wave-uniform) lookups compile to scalar loads:
+    uint32_t zj[WEDM_MAX_TILES * 8];  // bits 0-15: chunk c has cell j inside the workpiece zone;
+                                      // bits 16-31: chunk c has cell j between the contacts
+    uint32_t iv[WEDM_MAX_TILES * 8];  // bits 0-15: 1 <= c*C + j <= n-2 (interior, j < C);
+                                      // bits 16-31: c*C + j < n (valid, j < C)
+    uint32_t kind[WEDM_MAX_TILES];    // TILE_N / TILE_B / TILE_S
+    uint32_t split[WEDM_MAX_TILES];   // TILE_B: first cell offset that uses the tile's second flag set (8: none)
 };
+// TILE_N: 8 interior cells, one flag set.  TILE_B: every cell takes the interior formula with at
+// most one flag change inside the tile; boundary cells (wire cell 0, the last cell, cells past
+// the end of the wire) are kept out of the running max and patched afterwards.  TILE_S: per-cell
+// predicated fallback (more than one flag change in a tile).
+enum { TILE_N = 0, TILE_B = 1, TILE_S = 2 };
 
 struct KArgs {
     Hot hot;    // every-step parameters, by value
@@ -57,7 +69,7 @@ struct KArgs {
     int32_t num_envs;
     int32_t n_substeps;
     int32_t n_seg_max;
-    const SegTable* segs;  // device copy of the table for the L in use (fused kernel only)
+    const WalkTable* walk;  // device copy of the table for the L in use (fused kernel only)
 };
 
 // ------------------------------------------------------------ T accessors
@@ -160,45 +172,21 @@ __global__ void __launch_bounds__(64) wedm_step_lds(const KArgs k) {
 // np.max over finite temperatures; maps to v_max_f32 / v_max3_f32
 __device__ __forceinline__ float fmax_gt(float a, float b) { return __builtin_fmaxf(a, b); }
 
-// Interior cells of one segment: identical formula in every lane, coefficients are
-// per-lane registers chosen once per segment.  JOULE / ADV are wave-uniform.
-template <bool JOULE, bool ADV>
-__device__ __forceinline__ void fast_segment(float* col, int j0, int j1, float& tm1, float& tc, float& tmax,
-                                             float k, float tuf, float conv, float tdiel, float adv, float jfe,
-                                             float alpha, float tref) {
-    auto cell = [&](float tp1) -> float {
-        float a = tm1 - (tc + tc);  // 2*T[i] is exact
-        float d = k * (a + tp1);
-        if (JOULE) {
-            float rho_T = 1.0f + alpha * (tc - tref);
-            d = d + jfe * rho_T;  // jfe == 0 in lanes outside the contacts: d + 0 == d
-        }
-        d = d - conv * (tc - tdiel);
-        if (ADV) d = d + adv * (tm1 - tc);
-        return tc + d * tuf;
-    };
-    int j = j0;
-    for (; j + 8 <= j1; j += 8) {
-        float nx[8];
-#pragma unroll
-        for (int u = 0; u < 8; ++u) nx[u] = col[(j + 1 + u) * 256];
-#pragma unroll
-        for (int u = 0; u < 8; ++u) {
-            float tn = cell(nx[u]);
-            col[(j + u) * 256] = tn;
-            tmax = fmax_gt(tmax, tn);
-            tm1 = tc;
-            tc = nx[u];
-        }
+// One interior cell (1 <= i <= n-2), float32 op for op as wire.py:91-120 evaluates it.
+// The advection term is always applied: adv == 0 in lanes where the reference skips it
+// (d + 0*(..) == d), which keeps the loop free of a per-lane branch.
+template <bool JOULE>
+__device__ __forceinline__ float interior_cell(float tm1, float tc, float tp1, float k, float tuf, float conv,
+                                               float tdiel, float adv, float jfe, float alpha, float tref) {
+    float a = tm1 - (tc + tc);  // 2*T[i] is exact
+    float d = k * (a + tp1);
+    if (JOULE) {
+        float rho_T = 1.0f + alpha * (tc - tref);
+        d = d + jfe * rho_T;  // jfe == 0 in lanes outside the contacts: d + 0 == d
     }
-    for (; j < j1; ++j) {
-        float tp1 = col[(j + 1) * 256];
-        float tn = cell(tp1);
-        col[j * 256] = tn;
-        tmax = fmax_gt(tmax, tn);
-        tm1 = tc;
-        tc = tp1;
-    }
+    d = d - conv * (tc - tdiel);
+    d = d + adv * (tm1 - tc);
+    return tc + d * tuf;
 }
 
 template <int L>
@@ -210,8 +198,8 @@ __global__ void __launch_bounds__(256) wedm_step_fused(const KArgs k) {
     const int64_t e0 = (int64_t)blockIdx.x * EPB;
     const int64_t e = e0 + el;
     const bool live = e < k.num_envs;
-    const SegTable* __restrict__ sg = k.segs;
-    const int C = sg->C;
+    const WalkTable* __restrict__ wt = k.walk;
+    const int C = wt->C;
     const int n = k.hot.n_seg;
     const int64_t stride = k.cold.s.stride;
 
@@ -246,72 +234,181 @@ __global__ void __launch_bounds__(256) wedm_step_fused(const KArgs k) {
     float* col = lds + tid;
     const int cbase = c * C;
     const float spool = k.hot.spool, tref = k.hot.tref, alpha = k.hot.alpha, tdiel = k.hot.tdiel;
-    const int n_segs = sg->n_segs;
-    // advection is on or off for the whole launch (no module changes the unwinding speed)
-    const bool adv_all = __all(ps.adv_on || s.done), adv_none = !__any(ps.adv_on && !s.done);
+    const int n_tiles = wt->n_tiles;
+    // per-lane tile membership, gathered ONCE so that walking a tile reads nothing but LDS
+    // (scalar loads share lgkmcnt with LDS and would drain the prefetch every tile):
+    // bit t of zone_lo/joule_lo = flags of the tile's first cell, *_hi = flags of its last cell
+    uint32_t zone_lo = 0u, joule_lo = 0u, zone_hi = 0u, joule_hi = 0u, kind_n = 0u, kind_s = 0u;
+    uint32_t split_pack[3] = {0u, 0u, 0u};  // 4 bits per tile (WEDM_MAX_TILES <= 24)
+    for (int t = 0; t < n_tiles; ++t) {
+        const uint32_t lo = wt->zj[8 * t], hi = wt->zj[8 * t + 7], kd = wt->kind[t];
+        split_pack[t >> 3] |= (wt->split[t] & 15u) << ((t & 7) * 4);
+        zone_lo |= ((lo >> c) & 1u) << t;
+        joule_lo |= ((lo >> (16 + c)) & 1u) << t;
+        zone_hi |= ((hi >> c) & 1u) << t;
+        joule_hi |= ((hi >> (16 + c)) & 1u) << t;
+        kind_n |= (kd == TILE_N ? 1u : 0u) << t;
+        kind_s |= (kd == TILE_S ? 1u : 0u) << t;
+    }
+    kind_n = __builtin_amdgcn_readfirstlane(kind_n);
+    kind_s = __builtin_amdgcn_readfirstlane(kind_s);
+#pragma unroll
+    for (int q = 0; q < 3; ++q) split_pack[q] = __builtin_amdgcn_readfirstlane(split_pack[q]);
+    if (c == 0) col[0] = spool;  // wire cell 0 is held at the spool temperature (wire.py:83)
+    // the lane that owns the wire's last cell (Neumann boundary, wire.py:95)
+    const bool owns_last = (n >= 2) && (n - 1 >= cbase) && (n - 1 < cbase + C);
 
     for (int it = 0; it < k.n_substeps; ++it) {
         if (__all(s.done)) break;
         Coef cf{0.0f, 0.0f, 0, -1};
         if (!s.done) cf = scalar_prelude(k.hot, k.cold, g, e, gid, s, ps);
 
-        // ---- halos: OLD neighbour values, read before any lane of this wave stores
+        // ---- halos: OLD neighbour values, read before any lane of this wave stores.  The right
+        // halo goes into the chunk's extra LDS row C, so cell C-1 is walked like any other.
         const float halo_l = (c > 0) ? col[(C - 1) * 256 - 1] : spool;
         const float halo_r = (c < L - 1) ? col[1] : 0.0f;
+        col[C * 256] = halo_r;
 
-        // irregular waves (mixed advection, negative plasma heat, a frozen environment) take
-        // the predicated path for every cell; results are identical, only slower
-        const bool all_slow = !(adv_all || adv_none) || __any(cf.q < 0.0f) || __any(s.done);
+        // a wave with a frozen environment (or a negative plasma heat) walks every cell on the
+        // predicated path; results are identical, only slower
+        const bool all_slow = __any(cf.q < 0.0f) || __any(s.done);
+        const uint32_t slow_now = all_slow ? 0xffffffffu : kind_s;
 
-        // ---- plasma cell: computed from OLD values now, written after the walk
-        const bool owns = !s.done && cf.pidx >= 1 && cf.pidx >= cbase && cf.pidx < cbase + C;
-        float tpl = 0.0f;
-        if (__any(owns)) {
-            if (owns) {
+        // ---- patched cells: the plasma cell and the wire's last cell are computed with the
+        // full predicated formula from OLD values now and written after the walk
+        const bool owns_pl = !s.done && cf.pidx >= 1 && cf.pidx >= cbase && cf.pidx < cbase + C;
+        float tpl = 0.0f, tlast = 0.0f;
+        if (__any(owns_pl)) {
+            if (owns_pl) {
                 const int jp = cf.pidx - cbase;
                 float tm = jp > 0 ? col[(jp - 1) * 256] : halo_l;
-                if (cf.pidx == 1) tm = spool;  // T[0] is held at the spool temperature (wire.py:83)
+                if (cf.pidx == 1) tm = spool;
                 const float tcc = col[jp * 256];
                 const float tp = jp < C - 1 ? col[(jp + 1) * 256] : halo_r;
                 tpl = stencil_cell(cf.pidx, n, tm, tcc, tp, g, cf, ps, tref, alpha, tdiel);
             }
         }
+        if (owns_last && !s.done) {
+            const int jl = n - 1 - cbase;
+            float tm = jl > 0 ? col[(jl - 1) * 256] : halo_l;
+            if (n - 1 == 1) tm = spool;
+            tlast = stencil_cell(n - 1, n, tm, col[jl * 256], 0.0f, g, cf, ps, tref, alpha, tdiel);
+        }
 
         float tmax = spool;
         float tm1 = halo_l;
         float tc = col[0];
-        for (int kseg = 0; kseg < n_segs; ++kseg) {
-            const int j0 = sg->j0[kseg], j1 = sg->j0[kseg + 1];
-            const bool in_zone = (sg->zone[kseg] >> c) & 1;
-            const bool in_joule = (sg->joule[kseg] >> c) & 1;
-            if (sg->fast[kseg] && !all_slow) {
-                const float conv = in_zone ? ps.conv_zone : ps.conv_base;
-                const float jfe = (in_joule && cf.joule_on && !s.done) ? cf.jf : 0.0f;
-                const bool joule_any = __any(jfe != 0.0f);
-                if (joule_any) {
-                    if (adv_all) fast_segment<true, true>(col, j0, j1, tm1, tc, tmax, g.k, g.tuf, conv, tdiel, ps.adv, jfe, alpha, tref);
-                    else fast_segment<true, false>(col, j0, j1, tm1, tc, tmax, g.k, g.tuf, conv, tdiel, ps.adv, jfe, alpha, tref);
-                } else {
-                    if (adv_all) fast_segment<false, true>(col, j0, j1, tm1, tc, tmax, g.k, g.tuf, conv, tdiel, ps.adv, jfe, alpha, tref);
-                    else fast_segment<false, false>(col, j0, j1, tm1, tc, tmax, g.k, g.tuf, conv, tdiel, ps.adv, jfe, alpha, tref);
+#ifdef WEDM_ABL_NO_STENCIL
+        asm volatile("" ::"v"(cf.jf), "v"(cf.q), "v"(cf.pidx), "v"(ps.conv_base), "v"(ps.conv_zone), "v"(tpl), "v"(tlast));
+        if (false) {
+#else
+        {
+#endif
+            const float jf_lane = (cf.joule_on && !s.done) ? cf.jf : 0.0f;
+            const bool joule_wave = __any(jf_lane != 0.0f);
+
+            // tile t covers cells j = 8t..8t+7; cur[u] = OLD T[j+1+u]; `nxt` is loaded one tile ahead
+            auto load8 = [&](float (&dst)[8], int j) {
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    int row = j + 1 + u;
+                    row = row < C ? row : C;  // rows past the chunk are never used; row C is the halo
+                    dst[u] = col[row * 256];
                 }
-            } else {
-                // boundary cells, chunk tails and irregular steps: fully predicated per lane
-                for (int j = j0; j < j1; ++j) {
-                    const int i = cbase + j;
-                    const float tp1 = (j < C - 1) ? col[(j + 1) * 256] : halo_r;
-                    float tn = spool;
-                    if (i >= 1 && i < n) tn = stencil_cell(i, n, tm1, tc, tp1, g, cf, ps, tref, alpha, tdiel);
-                    if (i < n && !s.done) {
-                        col[j * 256] = tn;
-                        tmax = fmax_gt(tmax, tn);
+            };
+            auto tile = [&](int t, const float (&cur)[8], float (&nxt)[8]) {
+                const int j = 8 * t;
+                if (t + 1 < n_tiles) load8(nxt, j + 8);
+                const float conv_lo = ((zone_lo >> t) & 1u) ? ps.conv_zone : ps.conv_base;
+                const float jfe_lo = ((joule_lo >> t) & 1u) ? jf_lane : 0.0f;
+                if (((kind_n & ~slow_now) >> t) & 1u) {
+                    if (joule_wave && __any(jfe_lo != 0.0f)) {
+#pragma unroll
+                        for (int u = 0; u < 8; ++u) {
+                            float tn = interior_cell<true>(tm1, tc, cur[u], g.k, g.tuf, conv_lo, tdiel, ps.adv, jfe_lo, alpha, tref);
+                            col[(j + u) * 256] = tn;
+                            tmax = fmax_gt(tmax, tn);
+                            tm1 = tc;
+                            tc = cur[u];
+                        }
+                    } else {
+#pragma unroll
+                        for (int u = 0; u < 8; ++u) {
+                            float tn = interior_cell<false>(tm1, tc, cur[u], g.k, g.tuf, conv_lo, tdiel, ps.adv, jfe_lo, alpha, tref);
+                            col[(j + u) * 256] = tn;
+                            tmax = fmax_gt(tmax, tn);
+                            tm1 = tc;
+                            tc = cur[u];
+                        }
                     }
-                    tm1 = (i == 0) ? spool : tc;
-                    tc = tp1;
+                } else if (!((slow_now >> t) & 1u)) {
+                    // TILE_B: interior formula everywhere, one flag change at `split`, boundary and
+                    // out-of-wire cells excluded from the max (they are patched / never read)
+                    const int split = (int)((split_pack[t >> 3] >> ((t & 7) * 4)) & 15u);
+                    const int cnt = (C - j) < 8 ? (C - j) : 8;
+                    const float conv_hi = ((zone_hi >> t) & 1u) ? ps.conv_zone : ps.conv_base;
+                    const float jfe_hi = ((joule_hi >> t) & 1u) ? jf_lane : 0.0f;
+                    const uint32_t im1 = (uint32_t)(cbase + j - 1);  // (i - 1) of the tile's first cell
+                    const uint32_t span = (uint32_t)(n - 3);         // interior <=> (i - 1) <= n - 3 (unsigned)
+#pragma unroll
+                    for (int u = 0; u < 8; ++u) {
+                        if (u < cnt) {
+                            const float conv = u < split ? conv_lo : conv_hi;
+                            const float jfe = u < split ? jfe_lo : jfe_hi;
+                            float tn = interior_cell<true>(tm1, tc, cur[u], g.k, g.tuf, conv, tdiel, ps.adv, jfe, alpha, tref);
+                            col[(j + u) * 256] = tn;
+                            const bool inter = (n >= 3) && (im1 + (uint32_t)u <= span);
+                            tmax = inter ? fmax_gt(tmax, tn) : tmax;
+                            tm1 = tc;
+                            tc = cur[u];
+                        }
+                    }
+                } else {
+#pragma unroll 1
+                    for (int u = 0; u < 8; ++u) {
+                        const int jj = j + u;
+                        const uint32_t zj = wt->zj[jj], iv = wt->iv[jj];
+                        const bool zbit = (zj >> c) & 1u, jbit = (zj >> (16 + c)) & 1u;
+                        const bool inter = ((iv >> c) & 1u) && !all_slow;
+                        const bool valid = ((iv >> (16 + c)) & 1u) && !s.done;
+                        const float conv = zbit ? ps.conv_zone : ps.conv_base;
+                        const float jfe = jbit ? jf_lane : 0.0f;
+                        const float tp1 = cur[0];
+                        float tn = interior_cell<true>(tm1, tc, tp1, g.k, g.tuf, conv, tdiel, ps.adv, jfe, alpha, tref);
+                        if (!inter && valid) {  // boundary cells and irregular waves: predicated formula
+                            const int i = cbase + jj;
+                            tn = (i >= 1) ? stencil_cell(i, n, (i == 1) ? spool : tm1, tc, tp1, g, cf, ps, tref, alpha, tdiel)
+                                          : spool;
+                        }
+                        if (valid) {
+                            col[jj * 256] = tn;
+                            tmax = fmax_gt(tmax, tn);
+                        }
+                        tm1 = tc;
+                        tc = tp1;
+                        // rotate the prefetch window (this fallback is rare; keep its code small)
+                        float* w = const_cast<float*>(&cur[0]);
+                        float first = w[0];
+#pragma unroll
+                        for (int q = 0; q < 7; ++q) w[q] = w[q + 1];
+                        w[7] = first;
+                    }
                 }
+            };
+            float bufA[8], bufB[8];
+            load8(bufA, 0);
+            for (int t = 0; t < n_tiles; t += 2) {
+                tile(t, bufA, bufB);
+                if (t + 1 < n_tiles) tile(t + 1, bufB, bufA);
             }
         }
-        if (owns) {
+        // ---- patches (after every store of the walk): boundary condition, last cell, plasma cell
+        if (c == 0 && !s.done) col[0] = spool;
+        if (owns_last && !s.done) {
+            col[(n - 1 - cbase) * 256] = tlast;
+            tmax = fmax_gt(tmax, tlast);
+        }
+        if (owns_pl) {
             col[(cf.pidx - cbase) * 256] = tpl;
             tmax = fmax_gt(tmax, tpl);
         }
@@ -412,9 +509,9 @@ struct wedm_ctx {
     int32_t variant = 0;
     int32_t lanes = 0;                 // lanes per environment for the fused kernel (0 = auto)
     int lds_limit = 0;
-    SegTable* segs_dev = nullptr;      // [5] tables for L = 1, 2, 4, 8, 16
-    bool segs_ok[5] = {false, false, false, false, false};
-    int32_t segs_C[5] = {0, 0, 0, 0, 0};
+    WalkTable* walk_dev = nullptr;     // [5] tables for L = 1, 2, 4, 8, 16
+    bool walk_ok[5] = {false, false, false, false, false};
+    int32_t walk_C[5] = {0, 0, 0, 0, 0};
     std::string err;
     std::string last_kernel;
 };
@@ -428,45 +525,45 @@ static int32_t hip_fail(wedm_ctx* ctx, hipError_t e, const char* what) {
 }
 
 
-// Segment table for L lanes per environment (uniform geometry).  Breakpoints are the
-// indices where the per-cell formula changes (cell 0 boundary condition, first/last
-// contact cell, zone start/end, last cell, end of wire), mapped into every chunk's local
-// coordinates; between two consecutive breakpoints all L chunks see constant flags.
-static bool build_segments(const wedm_params& p, int L, SegTable& t) {
+// Walk table for L lanes per environment (uniform geometry): for every chunk-local cell j
+// which chunks have that cell inside the zone / between the contacts / interior / valid, and
+// per 8-cell tile whether it needs the per-cell (SPECIAL) path.
+static bool build_walk(const wedm_params& p, int L, WalkTable& t) {
     std::memset(&t, 0, sizeof(t));
     const int n = p.n_seg;
     const int C = (n + L - 1) / L;
+    if (C + 1 > WEDM_MAX_C) return false;  // +1: the halo row
     const int cb = p.contact_bottom, ct = p.contact_top, zs = p.az_start, ze = p.az_end;
-    std::set<int> bp = {0, C};
-    auto add = [&](int i_break) {
-        for (int c = 0; c < L; ++c) {
-            int j = i_break - c * C;
-            if (j > 0 && j < C) bp.insert(j);
-        }
-    };
-    add(1); add(n - 1); add(n); add(cb); add(ct + 1);
-    if (zs < ze) { add(zs); add(ze); }
-    if (C - 1 > 0) bp.insert(C - 1);
-    if ((int)bp.size() - 1 > WEDM_MAX_SEGS) return false;
     t.C = C;
-    int k = 0;
-    for (auto it = bp.begin(); std::next(it) != bp.end(); ++it, ++k) {
-        const int a = *it, b = *std::next(it);
-        t.j0[k] = (int16_t)a;
-        t.j0[k + 1] = (int16_t)b;
-        bool fast = b <= C - 1;  // the chunk's last cell takes its right neighbour from a halo register
-        uint16_t zone = 0, joule = 0;
-        for (int c = 0; c < L; ++c) {
-            const int i0 = c * C + a, i1 = c * C + b - 1;
-            if (i0 < 1 || i1 > n - 2) fast = false;
-            if (zs < ze && i0 >= zs && i1 < ze) zone |= (uint16_t)(1u << c);
-            if (i0 >= cb && i1 <= ct) joule |= (uint16_t)(1u << c);
+    t.n_tiles = (C + 7) / 8;
+    const uint16_t all = (uint16_t)((1u << L) - 1u);
+    for (int j = 0; j < t.n_tiles * 8; ++j) {
+        uint16_t zone = 0, joule = 0, inter = 0, valid = 0;
+        for (int c = 0; c < L && j < C; ++c) {
+            const int i = c * C + j;
+            if (zs < ze && i >= zs && i < ze) zone |= (uint16_t)(1u << c);
+            if (i >= cb && i <= ct) joule |= (uint16_t)(1u << c);
+            if (i >= 1 && i <= n - 2) inter |= (uint16_t)(1u << c);
+            if (i < n) valid |= (uint16_t)(1u << c);
         }
-        t.fast[k] = fast ? 1 : 0;
-        t.zone[k] = zone;
-        t.joule[k] = joule;
+        t.zj[j] = (uint32_t)zone | ((uint32_t)joule << 16);
+        t.iv[j] = (uint32_t)inter | ((uint32_t)valid << 16);
     }
-    t.n_segs = k;
+    for (int tile = 0; tile < t.n_tiles; ++tile) {
+        const int j0 = 8 * tile, j1 = std::min(j0 + 8, C);
+        bool all_interior = (j1 - j0 == 8);
+        int changes = 0, split = 8;
+        for (int j = j0; j < j1; ++j) {
+            if ((t.iv[j] & 0xffffu) != all) all_interior = false;
+            if (j > j0 && t.zj[j] != t.zj[j - 1]) { ++changes; split = j - j0; }
+        }
+        // cells past the chunk keep the last real cell's flags so that zj[8t+7] is the tile's "hi" set
+        for (int j = j1; j < j0 + 8; ++j) t.zj[j] = t.zj[j1 - 1];
+        t.split[tile] = (uint32_t)split;
+        if (changes > 1) t.kind[tile] = TILE_S;
+        else if (all_interior && changes == 0) t.kind[tile] = TILE_N;
+        else t.kind[tile] = TILE_B;
+    }
     return true;
 }
 
@@ -565,16 +662,16 @@ int32_t wedm_create(const wedm_params* params, int32_t num_envs, int32_t n_seg_m
         return WEDM_ERR_HIP;
     }
     if (!params->per_env_geometry) {
-        SegTable host_tabs[5];
+        WalkTable host_tabs[5];
         const int Ls[5] = {1, 2, 4, 8, 16};
         for (int i = 0; i < 5; ++i) {
-            ctx->segs_ok[i] = build_segments(*params, Ls[i], host_tabs[i]);
-            ctx->segs_C[i] = host_tabs[i].C;
+            ctx->walk_ok[i] = build_walk(*params, Ls[i], host_tabs[i]);
+            ctx->walk_C[i] = host_tabs[i].C;
         }
-        if ((e = hipMalloc((void**)&ctx->segs_dev, sizeof(host_tabs))) != hipSuccess ||
-            (e = hipMemcpy(ctx->segs_dev, host_tabs, sizeof(host_tabs), hipMemcpyHostToDevice)) != hipSuccess) {
-            g_create_error = std::string("segment tables: ") + hipGetErrorString(e);
-            if (ctx->segs_dev) (void)hipFree(ctx->segs_dev);
+        if ((e = hipMalloc((void**)&ctx->walk_dev, sizeof(host_tabs))) != hipSuccess ||
+            (e = hipMemcpy(ctx->walk_dev, host_tabs, sizeof(host_tabs), hipMemcpyHostToDevice)) != hipSuccess) {
+            g_create_error = std::string("walk tables: ") + hipGetErrorString(e);
+            if (ctx->walk_dev) (void)hipFree(ctx->walk_dev);
             (void)hipFree(ctx->params_dev);
             (void)hipFree(ctx->tables_dev);
             delete ctx;
@@ -589,13 +686,13 @@ static int auto_lanes(const wedm_ctx* ctx) {
     const int Ls[5] = {1, 2, 4, 8, 16};
     int best = 0;
     for (int i = 0; i < 5; ++i) {
-        if (!ctx->segs_ok[i]) continue;
-        const size_t lds = (size_t)ctx->segs_C[i] * 1024;
+        if (!ctx->walk_ok[i]) continue;
+        const size_t lds = ((size_t)ctx->walk_C[i] + 1) * 1024;
         if (lds > (size_t)ctx->lds_limit) continue;
         if (!best) best = Ls[i];
         const long waves = (long)((ctx->num_envs + (256 / Ls[i]) - 1) / (256 / Ls[i])) * 4;
         best = Ls[i];
-        if (waves >= 2048 || ctx->segs_C[i] <= 32) break;
+        if (waves >= 2048 || ctx->walk_C[i] <= 32) break;
     }
     return best;
 }
@@ -603,7 +700,7 @@ static int auto_lanes(const wedm_ctx* ctx) {
 int32_t wedm_destroy(wedm_ctx* ctx) {
     if (!ctx) return WEDM_ERR_BAD_ARG;
     if (ctx->tables_dev) (void)hipFree(ctx->tables_dev);
-    if (ctx->segs_dev) (void)hipFree(ctx->segs_dev);
+    if (ctx->walk_dev) (void)hipFree(ctx->walk_dev);
     if (ctx->params_dev) (void)hipFree(ctx->params_dev);
     delete ctx;
     return WEDM_OK;
@@ -694,13 +791,13 @@ int32_t wedm_step(wedm_ctx* ctx, int32_t n_substeps, const wedm_action_ptrs* act
     k.num_envs = ctx->num_envs;
     k.n_substeps = n_substeps;
     k.n_seg_max = ctx->n_seg_max;
-    k.segs = nullptr;
+    k.walk = nullptr;
 
     const size_t lds_bytes = (size_t)ctx->n_seg_max * 64 * sizeof(float);
     int lanes = ctx->lanes ? ctx->lanes : auto_lanes(ctx);
     const int li = lanes_index(lanes);
-    const bool fused_ok = !ctx->p.per_env_geometry && ctx->segs_dev && li >= 0 && ctx->segs_ok[li] &&
-                          (size_t)ctx->segs_C[li] * 1024 <= (size_t)ctx->lds_limit;
+    const bool fused_ok = !ctx->p.per_env_geometry && ctx->walk_dev && li >= 0 && ctx->walk_ok[li] &&
+                          ((size_t)ctx->walk_C[li] + 1) * 1024 <= (size_t)ctx->lds_limit;
     int variant = ctx->variant;
     if (variant == 0) {
         if (n_substeps > 1 && fused_ok) variant = 3;
@@ -727,8 +824,8 @@ int32_t wedm_step(wedm_ctx* ctx, int32_t n_substeps, const wedm_action_ptrs* act
     } else {
         const int epb = 256 / lanes;
         const int grid = (ctx->num_envs + epb - 1) / epb;
-        const size_t fl = (size_t)ctx->segs_C[li] * 1024;
-        k.segs = ctx->segs_dev + li;
+        const size_t fl = ((size_t)ctx->walk_C[li] + 1) * 1024;
+        k.walk = ctx->walk_dev + li;
         const void* fn = lanes == 1 ? (const void*)wedm_step_fused<1> : lanes == 2 ? (const void*)wedm_step_fused<2>
                        : lanes == 4 ? (const void*)wedm_step_fused<4> : lanes == 8 ? (const void*)wedm_step_fused<8>
                                                                                    : (const void*)wedm_step_fused<16>;

@@ -118,7 +118,7 @@ def test_default_config_fused_matches_oracle(variant, lanes):
     gpu, cpu = make_pair(n)
     gpu.set_kernel(variant, lanes)
     both((gpu, cpu), lambda e: (e.reset(seed=1234), close_gap(e)))
-    if variant == 3 and -(-gpu.n_segments // lanes) * 1024 > 160 * 1024:
+    if variant == 3 and (-(-gpu.n_segments // lanes) + 1) * 1024 > 160 * 1024:
         from sparc_amd._lib import WedmError
 
         with pytest.raises(WedmError, match="WEDM_ERR_UNSUPPORTED"):  # chunk does not fit in 160 KB of LDS
