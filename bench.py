@@ -44,7 +44,7 @@ def parse_args():
     ap.add_argument("--substeps", type=int, default=1000, help="physics microseconds per bench step")
     ap.add_argument("--workload", choices=["config3", "config2", "config4"], default="config3")
     ap.add_argument("--num-envs", type=int, default=0, help="override environments per GPU")
-    ap.add_argument("--kernel", type=int, default=0, help="0 auto, 1 global-memory, 2 LDS predicated, 3 LDS fused")
+    ap.add_argument("--kernel", type=int, default=0, help="0 auto, 1 global-memory, 2 LDS predicated, 3 LDS fused, 4 LDS fused + packed f32")
     ap.add_argument("--lanes", type=int, default=0, help="lanes per environment in kernel 3 (0 auto)")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="target wall time of the cpu_baseline leg")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -67,32 +67,47 @@ def workload(args):
     return n, wire, name
 
 
-def cpu_baseline(wire_params, n_sub, target_seconds):
-    """Time the CPU oracle on a bounded sample of the same workload (all host cores)."""
+def cpu_baseline(wire_params, n_envs, n_sub, target_seconds):
+    """Time the CPU oracle (oracle/, the checker) on a bounded sample of the same workload:
+    the same batch, as many control intervals as fit in ~target_seconds, all host cores."""
     from oracle import oracle as orc
     from sparc_amd import WireEDMEnv
     from tests._oracle_backend import OracleBackend
 
     threads = int(orc.lib().wedm_oracle_max_threads())
-
-    def run(n_envs, subs):
-        env = WireEDMEnv(num_envs=n_envs, device="cpu", backend=OracleBackend, wire_params=wire_params)
-        env.reset(seed=1234)
-        act = env.make_action(0.1, 80.0, 5, 3.0, 80.0)
-        t0 = time.perf_counter()
-        env.step_many(act, subs)
-        return time.perf_counter() - t0
-
-    probe_envs = 64 * threads
-    dt = run(probe_envs, 200)
-    rate = probe_envs * 200 / dt
-    n_envs = max(probe_envs, int(rate * target_seconds / n_sub) // (64 * threads) * (64 * threads))
     n_envs = min(n_envs, 65536)
-    dt = run(n_envs, n_sub)
+    env = WireEDMEnv(num_envs=n_envs, device="cpu", backend=OracleBackend, wire_params=wire_params)
+    env.reset(seed=1234)
+    act = env.make_action(0.1, 80.0, 5, 3.0, 80.0)
+    t0 = time.perf_counter()
+    env.step_many(act, n_sub)  # also the probe that sizes the sample
+    probe = time.perf_counter() - t0
+    intervals = max(1, min(200, int(target_seconds / max(probe, 1e-3)) - 1))
+    t0 = time.perf_counter()
+    for _ in range(intervals):
+        env.step_many(act, n_sub)
+    dt = time.perf_counter() - t0
     return {
-        "value": n_envs * n_sub / dt, "unit": "env-steps/s", "cores": threads, "kind": "port",
-        "sample": f"{n_envs} envs x {n_sub} us of the same workload, OpenMP static over envs, {dt:.1f} s",
+        "value": n_envs * n_sub * intervals / dt, "unit": "env-steps/s", "cores": threads, "kind": "port",
+        "sample": f"{n_envs} envs x {intervals} control intervals x {n_sub} us of the same workload "
+                  f"(after one warm-up interval), OpenMP static over envs, {dt:.1f} s",
     }
+
+
+def measured_traffic(kernel_name):
+    """HBM bytes per launch from the separate rocprofv3 --pmc passes recorded under profiles/
+    (FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for gfx950, + WRITE_SIZE); null when
+    no recorded pass matches the kernel that ran."""
+    path = ROOT / "profiles" / "traffic.json"
+    if not path.exists():
+        return None
+    try:
+        for row in json.loads(path.read_text()):
+            if kernel_name.startswith(row["kernel_prefix"]):
+                return row["hbm_bytes_per_launch"]
+    except Exception:
+        return None
+    return None
 
 
 def main():
@@ -174,7 +189,8 @@ def main():
             },
             "roofline": {
                 "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": achieved / HBM_PEAK_GBS, "traffic": args.traffic,
+                "frac": achieved / HBM_PEAK_GBS,
+                "traffic": args.traffic if args.traffic is not None else measured_traffic(env._backend.last_kernel()),
                 "kernel_ms": kernel_ms, "algorithmic_bytes_per_launch": bytes_per_launch,
                 "note": "algorithmic bytes B(S)=8S+208 per env-step x envs x substeps per launch; the fused "
                         "kernel keeps T in LDS, so physical HBM traffic is ~1/substeps of this",
@@ -182,7 +198,7 @@ def main():
             "check": {"envs_done": done, "sparks": sparks},
         }
         if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(wire, n_sub, args.cpu_seconds)
+            out["cpu_baseline"] = cpu_baseline(wire, n_local, n_sub, args.cpu_seconds)
             out["cpu_baseline"]["reference_python"] = (
                 "1 209 env-steps/s, 1 core: the Python reference itself (Numba stubbed), measured in the build "
                 "container (BASELINE.md); it cannot travel to the GPU box")

@@ -249,11 +249,12 @@ int32_t wedm_step(wedm_ctx* ctx, int32_t n_substeps, const wedm_action_ptrs* act
 
 /* selects the kernel used by wedm_step: 0 = auto, 1 = global-memory stencil (one pass
  * over T in HBM per substep), 2 = LDS-staged predicated stencil (any geometry),
- * 3 = LDS-staged fused stencil with a wave-uniform segment table (uniform geometry).
+ * 3 = LDS-staged fused stencil walking a wave-uniform tile table (uniform geometry),
+ * 4 = the same with two chunks per lane advanced by packed float32 math.
  * All variants produce bit-identical results.                                        */
 int32_t wedm_set_kernel(wedm_ctx* ctx, int32_t variant);
 
-/* lanes that share one environment in kernel 3: 0 = auto, or 1, 2, 4, 8, 16 */
+/* lanes that share one environment in kernels 3 and 4: 0 = auto, or 1, 2, 4, 8 (16: kernel 3 only) */
 int32_t wedm_set_lanes(wedm_ctx* ctx, int32_t lanes);
 
 /* name / launch geometry of the kernel the last wedm_step used (for profiles) */

@@ -70,6 +70,7 @@ struct KArgs {
     int32_t n_substeps;
     int32_t n_seg_max;
     const WalkTable* walk;  // device copy of the table for the L in use (fused kernel only)
+    unsigned long long* dbg; // diagnostic builds only (WEDM_STAMPS): per-wave phase cycle sums
 };
 
 // ------------------------------------------------------------ T accessors
@@ -168,6 +169,32 @@ __global__ void __launch_bounds__(64) wedm_step_lds(const KArgs k) {
     store_env(k.cold.s, e, s);
 }
 
+// In-kernel phase stamps (diagnostic build -DWEDM_STAMPS only; never in the shipped library).
+#ifdef WEDM_STAMPS
+#define WEDM_STAMP(var)                                                      \
+    do {                                                                     \
+        __builtin_amdgcn_sched_barrier(0);                                   \
+        asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(var)::"memory"); \
+        __builtin_amdgcn_sched_barrier(0);                                   \
+    } while (0)
+#define WEDM_STAMP_DECL unsigned long long st0 = 0, st1 = 0, st2 = 0, st3 = 0, st4 = 0, acc0 = 0, acc1 = 0, acc2 = 0, acc3 = 0, tk0 = 0, tk1 = 0, accN = 0, accB = 0, accS = 0, cntN = 0, cntB = 0, cntS = 0
+#define WEDM_STAMP_ACC() do { acc0 += st1 - st0; acc1 += st2 - st1; acc2 += st3 - st2; acc3 += st4 - st3; } while (0)
+#define WEDM_STAMP_OUT()                                                                         \
+    do {                                                                                         \
+        if (k.dbg && (threadIdx.x & 63) == 0) {                                                  \
+            unsigned long long* o = k.dbg + ((size_t)blockIdx.x * 4 + (threadIdx.x >> 6)) * 4;   \
+            o[0] = acc0; o[1] = acc1; o[2] = acc2; o[3] = acc3;                                  \
+            unsigned long long* o2 = k.dbg + (size_t)gridDim.x * 16 + ((size_t)blockIdx.x * 4 + (threadIdx.x >> 6)) * 6; \
+            o2[0] = accN; o2[1] = accB; o2[2] = accS; o2[3] = cntN; o2[4] = cntB; o2[5] = cntS;  \
+        }                                                                                        \
+    } while (0)
+#else
+#define WEDM_STAMP(var) do { } while (0)
+#define WEDM_STAMP_DECL do { } while (0)
+#define WEDM_STAMP_ACC() do { } while (0)
+#define WEDM_STAMP_OUT() do { } while (0)
+#endif
+
 // ===================================================== fused kernel, L lanes / env
 // np.max over finite temperatures; maps to v_max_f32 / v_max3_f32
 __device__ __forceinline__ float fmax_gt(float a, float b) { return __builtin_fmaxf(a, b); }
@@ -190,7 +217,7 @@ __device__ __forceinline__ float interior_cell(float tm1, float tc, float tp1, f
 }
 
 template <int L>
-__global__ void __launch_bounds__(256) wedm_step_fused(const KArgs k) {
+__global__ void __launch_bounds__(256, 2) wedm_step_fused(const KArgs k) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     constexpr int EPB = 256 / L;  // environments per block
     const int tid = threadIdx.x;
@@ -258,10 +285,13 @@ __global__ void __launch_bounds__(256) wedm_step_fused(const KArgs k) {
     // the lane that owns the wire's last cell (Neumann boundary, wire.py:95)
     const bool owns_last = (n >= 2) && (n - 1 >= cbase) && (n - 1 < cbase + C);
 
+    WEDM_STAMP_DECL;
     for (int it = 0; it < k.n_substeps; ++it) {
         if (__all(s.done)) break;
+        WEDM_STAMP(st0);
         Coef cf{0.0f, 0.0f, 0, -1};
         if (!s.done) cf = scalar_prelude(k.hot, k.cold, g, e, gid, s, ps);
+        WEDM_STAMP(st1);
 
         // ---- halos: OLD neighbour values, read before any lane of this wave stores.  The right
         // halo goes into the chunk's extra LDS row C, so cell C-1 is walked like any other.
@@ -321,6 +351,10 @@ __global__ void __launch_bounds__(256) wedm_step_fused(const KArgs k) {
                 if (t + 1 < n_tiles) load8(nxt, j + 8);
                 const float conv_lo = ((zone_lo >> t) & 1u) ? ps.conv_zone : ps.conv_base;
                 const float jfe_lo = ((joule_lo >> t) & 1u) ? jf_lane : 0.0f;
+#ifdef WEDM_STAMPS_TILES
+                WEDM_STAMP(tk0);
+                const int tkind = (((kind_n & ~slow_now) >> t) & 1u) ? 0 : (!((slow_now >> t) & 1u) ? 1 : 2);
+#endif
                 if (((kind_n & ~slow_now) >> t) & 1u) {
                     if (joule_wave && __any(jfe_lo != 0.0f)) {
 #pragma unroll
@@ -394,6 +428,10 @@ __global__ void __launch_bounds__(256) wedm_step_fused(const KArgs k) {
                         w[7] = first;
                     }
                 }
+#ifdef WEDM_STAMPS_TILES
+                WEDM_STAMP(tk1);
+                if (tkind == 0) { accN += tk1 - tk0; ++cntN; } else if (tkind == 1) { accB += tk1 - tk0; ++cntB; } else { accS += tk1 - tk0; ++cntS; }
+#endif
             };
             float bufA[8], bufB[8];
             load8(bufA, 0);
@@ -402,6 +440,7 @@ __global__ void __launch_bounds__(256) wedm_step_fused(const KArgs k) {
                 if (t + 1 < n_tiles) tile(t + 1, bufB, bufA);
             }
         }
+        WEDM_STAMP(st2);
         // ---- patches (after every store of the walk): boundary condition, last cell, plasma cell
         if (c == 0 && !s.done) col[0] = spool;
         if (owns_last && !s.done) {
@@ -414,11 +453,15 @@ __global__ void __launch_bounds__(256) wedm_step_fused(const KArgs k) {
         }
 #pragma unroll
         for (int m = 1; m < L; m <<= 1) tmax = fmax_gt(tmax, __shfl_xor(tmax, m));
+        WEDM_STAMP(st3);
         if (!s.done) {
             scalar_epilogue(k.hot, s, tmax);
             if (s.ctrl && c == 0) write_obs(k.cold, e, s);
         }
+        WEDM_STAMP(st4);
+        WEDM_STAMP_ACC();
     }
+    WEDM_STAMP_OUT();
 
     __syncthreads();
     {
@@ -432,6 +475,299 @@ __global__ void __launch_bounds__(256) wedm_step_fused(const KArgs k) {
             if (i < n && ok) dst[(int64_t)i * stride] = lds[ji * 256 + sel * L + ci];
             ji += L;
             while (ji >= C) { ji -= C; ++ci; }
+        }
+    }
+    if (live && c == 0) store_env(k.cold.s, e, s);
+}
+
+
+// ============================================ packed fused kernel, L lanes / env, 2 cells / op
+// Same walk as wedm_step_fused, but every lane owns TWO virtual chunks A and B of Cv cells and
+// advances them together in one float2 register pair, so each v_pk_add_f32 / v_pk_mul_f32 does
+// two cells.  With only 1-2 waves per SIMD (the batch fixes the wave count) a wave is limited by
+// its own in-order issue, one VALU per 4 cycles, while the SIMD pipe idles half the time: packing
+// halves the instructions the wave has to issue.  Rows of A and B are interleaved in the lane's
+// LDS column (row 2r = A[r], row 2r+1 = B[r]; rows 2Cv, 2Cv+1 hold the right halos), so a pair
+// is one ds_read2st64_b32 / ds_write2st64_b32.  The walk table is the one built for 2L chunks.
+typedef float f2 __attribute__((ext_vector_type(2)));
+
+template <bool JOULE>
+__device__ __forceinline__ f2 interior2(f2 tm1, f2 tc, f2 tp1, float k, float tuf, f2 conv, float tdiel, float adv,
+                                        f2 jfe, float alpha, float tref) {
+    f2 a = tm1 - (tc + tc);
+    f2 d = k * (a + tp1);
+    if (JOULE) {
+        f2 rho_T = 1.0f + alpha * (tc - tref);
+        d = d + jfe * rho_T;
+    }
+    d = d - conv * (tc - tdiel);
+    d = d + adv * (tm1 - tc);
+    return tc + d * tuf;
+}
+
+template <int L>
+__global__ void __launch_bounds__(256, 2) wedm_step_packed(const KArgs k) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    constexpr int EPB = 256 / L;
+    const int tid = threadIdx.x;
+    const int el = tid / L, c = tid % L;
+    const int64_t e0 = (int64_t)blockIdx.x * EPB;
+    const int64_t e = e0 + el;
+    const bool live = e < k.num_envs;
+    const WalkTable* __restrict__ wt = k.walk;  // built for 2L virtual chunks
+    const int Cv = wt->C;
+    const int R = 2 * Cv;  // data rows per lane; rows R and R+1 are the halo pair
+    const int n = k.hot.n_seg;
+    const int64_t stride = k.cold.s.stride;
+
+    // ---- stage: wire cell i -> virtual chunk vc = i / Cv, cell r = i % Cv -> lane vc/2, row 2r + vc%2
+    {
+        const int rr = tid / EPB, sel = tid % EPB;
+        int vc = 0, r = rr;
+        while (r >= Cv) { r -= Cv; ++vc; }
+        const bool ok = e0 + sel < k.num_envs;
+        const float* src = k.cold.s.T + e0 + sel;
+        for (int i0 = 0; i0 < n; i0 += L) {
+            const int i = i0 + rr;
+            if (i < n && ok) lds[(2 * r + (vc & 1)) * 256 + sel * L + (vc >> 1)] = src[(int64_t)i * stride];
+            r += L;
+            while (r >= Cv) { r -= Cv; ++vc; }
+        }
+    }
+    __syncthreads();
+
+    Env s;
+    Geom g;
+    Persist ps{0.0f, 0.0f, 0.0f, 0};
+    load_geom(k.hot, k.cold, live ? e : 0, g);
+    if (live) load_env(k.cold.s, e, s);
+    else { s.done = 1; s.unwind = 0.0; s.h_base = 0.0f; s.h_zone = 0.0f; }
+    if (!s.done) {
+        s.ipk = peak_current(k.cold, s.mode);
+        init_persist(k.hot, k.cold, e, s, ps);
+    }
+    const uint32_t gid = k.hot.env_id_offset + (uint32_t)e;
+
+    float* col = lds + tid;
+    const int baseA = 2 * c * Cv, baseB = baseA + Cv;  // first wire cell of each virtual chunk
+    const float spool = k.hot.spool, tref = k.hot.tref, alpha = k.hot.alpha, tdiel = k.hot.tdiel;
+    const int n_tiles = wt->n_tiles;
+    // per-lane tile flags for both virtual chunks, gathered once (see wedm_step_fused)
+    uint32_t zlA = 0u, zlB = 0u, jlA = 0u, jlB = 0u, zhA = 0u, zhB = 0u, jhA = 0u, jhB = 0u, kind_n = 0u, kind_s = 0u;
+    uint32_t split_pack[3] = {0u, 0u, 0u};
+    for (int t = 0; t < n_tiles; ++t) {
+        const uint32_t lo = wt->zj[8 * t], hi = wt->zj[8 * t + 7], kd = wt->kind[t];
+        split_pack[t >> 3] |= (wt->split[t] & 15u) << ((t & 7) * 4);
+        zlA |= ((lo >> (2 * c)) & 1u) << t;      zlB |= ((lo >> (2 * c + 1)) & 1u) << t;
+        jlA |= ((lo >> (16 + 2 * c)) & 1u) << t; jlB |= ((lo >> (17 + 2 * c)) & 1u) << t;
+        zhA |= ((hi >> (2 * c)) & 1u) << t;      zhB |= ((hi >> (2 * c + 1)) & 1u) << t;
+        jhA |= ((hi >> (16 + 2 * c)) & 1u) << t; jhB |= ((hi >> (17 + 2 * c)) & 1u) << t;
+        kind_n |= (kd == TILE_N ? 1u : 0u) << t;
+        kind_s |= (kd == TILE_S ? 1u : 0u) << t;
+    }
+    kind_n = __builtin_amdgcn_readfirstlane(kind_n);
+    kind_s = __builtin_amdgcn_readfirstlane(kind_s);
+#pragma unroll
+    for (int q = 0; q < 3; ++q) split_pack[q] = __builtin_amdgcn_readfirstlane(split_pack[q]);
+    if (c == 0) col[0] = spool;  // wire cell 0 (row 0 of lane 0's chunk A) is held at the spool temperature
+
+    // which of this lane's virtual chunks holds wire cell i (0: none, 1: A, 2: B)
+    auto owner = [&](int i) -> int {
+        if (i >= baseA && i < baseA + Cv) return 1;
+        if (i >= baseB && i < baseB + Cv) return 2;
+        return 0;
+    };
+    const int own_last = (n >= 2) ? owner(n - 1) : 0;
+
+    WEDM_STAMP_DECL;
+    for (int it = 0; it < k.n_substeps; ++it) {
+        if (__all(s.done)) break;
+        WEDM_STAMP(st0);
+        Coef cf{0.0f, 0.0f, 0, -1};
+        if (!s.done) cf = scalar_prelude(k.hot, k.cold, g, e, gid, s, ps);
+        WEDM_STAMP(st1);
+
+        // ---- halos (OLD values, read before any store of this step)
+        const float halo_l = (c > 0) ? col[(R - 1) * 256 - 1] : spool;  // left neighbour lane's B[Cv-1]
+        const float halo_r = (c < L - 1) ? col[1] : 0.0f;               // right neighbour lane's A[0]
+        const float a_last = col[(R - 2) * 256];                        // own A[Cv-1]: left halo of B
+        const float b_first = col[256];                                 // own B[0]: right halo of A
+        col[R * 256] = b_first;
+        col[(R + 1) * 256] = halo_r;
+
+        const bool all_slow = __any(cf.q < 0.0f) || __any(s.done);
+        const uint32_t slow_now = all_slow ? 0xffffffffu : kind_s;
+
+        // full predicated formula for one owned cell, from OLD values (patched cells)
+        auto patch_value = [&](int i, int own) -> float {
+            const int v = own - 1, r = i - (v ? baseB : baseA), row = 2 * r + v;
+            float tm = r > 0 ? col[(row - 2) * 256] : (v ? a_last : halo_l);
+            if (i == 1) tm = spool;
+            const float tp = r < Cv - 1 ? col[(row + 2) * 256] : (v ? halo_r : b_first);
+            return stencil_cell(i, n, tm, col[row * 256], tp, g, cf, ps, tref, alpha, tdiel);
+        };
+        const int own_pl = (!s.done && cf.pidx >= 1) ? owner(cf.pidx) : 0;
+        float tpl = 0.0f, tlast = 0.0f;
+        if (__any(own_pl != 0)) {
+            if (own_pl) tpl = patch_value(cf.pidx, own_pl);
+        }
+        if (own_last && !s.done) tlast = patch_value(n - 1, own_last);
+
+        float tmax = spool;
+        f2 tm1 = {halo_l, a_last};
+        f2 tc = {col[0], col[256]};
+#ifdef WEDM_ABL_NO_STENCIL
+        asm volatile("" ::"v"(cf.jf), "v"(cf.q), "v"(cf.pidx), "v"(ps.conv_base), "v"(ps.conv_zone), "v"(tpl), "v"(tlast));
+        if (false) {
+#else
+        {
+#endif
+            const float jf_lane = (cf.joule_on && !s.done) ? cf.jf : 0.0f;
+            const bool joule_wave = __any(jf_lane != 0.0f);
+            const float cz = ps.conv_zone, cb = ps.conv_base;
+
+            auto load8 = [&](f2 (&dst)[8], int r0) {  // dst[u] = OLD (A[r0+1+u], B[r0+1+u])
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    int p = r0 + 1 + u;
+                    p = p < Cv ? p : Cv;  // pair Cv is the halo pair; later pairs are never used
+                    dst[u].x = col[(2 * p) * 256];
+                    dst[u].y = col[(2 * p + 1) * 256];
+                }
+            };
+            auto store2 = [&](int r, f2 v) {
+                col[(2 * r) * 256] = v.x;
+                col[(2 * r + 1) * 256] = v.y;
+            };
+            auto tile = [&](int t, f2 (&cur)[8], f2 (&nxt)[8]) {
+                const int r0 = 8 * t;
+                if (t + 1 < n_tiles) load8(nxt, r0 + 8);
+                const f2 conv_lo = {((zlA >> t) & 1u) ? cz : cb, ((zlB >> t) & 1u) ? cz : cb};
+                const f2 jfe_lo = {((jlA >> t) & 1u) ? jf_lane : 0.0f, ((jlB >> t) & 1u) ? jf_lane : 0.0f};
+                if (((kind_n & ~slow_now) >> t) & 1u) {
+                    if (joule_wave && __any(jfe_lo.x != 0.0f || jfe_lo.y != 0.0f)) {
+#pragma unroll
+                        for (int u = 0; u < 8; ++u) {
+                            f2 tn = interior2<true>(tm1, tc, cur[u], g.k, g.tuf, conv_lo, tdiel, ps.adv, jfe_lo, alpha, tref);
+                            store2(r0 + u, tn);
+                            tmax = fmax_gt(tmax, fmax_gt(tn.x, tn.y));
+                            tm1 = tc;
+                            tc = cur[u];
+                        }
+                    } else {
+#pragma unroll
+                        for (int u = 0; u < 8; ++u) {
+                            f2 tn = interior2<false>(tm1, tc, cur[u], g.k, g.tuf, conv_lo, tdiel, ps.adv, jfe_lo, alpha, tref);
+                            store2(r0 + u, tn);
+                            tmax = fmax_gt(tmax, fmax_gt(tn.x, tn.y));
+                            tm1 = tc;
+                            tc = cur[u];
+                        }
+                    }
+                } else if (!((slow_now >> t) & 1u)) {
+                    // TILE_B: interior formula everywhere, one flag change at `split`; boundary and
+                    // out-of-wire cells stay out of the max (patched afterwards / never read)
+                    const int split = (int)((split_pack[t >> 3] >> ((t & 7) * 4)) & 15u);
+                    const int cnt = (Cv - r0) < 8 ? (Cv - r0) : 8;
+                    const f2 conv_hi = {((zhA >> t) & 1u) ? cz : cb, ((zhB >> t) & 1u) ? cz : cb};
+                    const f2 jfe_hi = {((jhA >> t) & 1u) ? jf_lane : 0.0f, ((jhB >> t) & 1u) ? jf_lane : 0.0f};
+                    const uint32_t imA = (uint32_t)(baseA + r0 - 1), imB = (uint32_t)(baseB + r0 - 1);
+                    const uint32_t span = (uint32_t)(n - 3);
+#pragma unroll
+                    for (int u = 0; u < 8; ++u) {
+                        if (u < cnt) {
+                            const f2 conv = u < split ? conv_lo : conv_hi;
+                            const f2 jfe = u < split ? jfe_lo : jfe_hi;
+                            f2 tn = interior2<true>(tm1, tc, cur[u], g.k, g.tuf, conv, tdiel, ps.adv, jfe, alpha, tref);
+                            store2(r0 + u, tn);
+                            const bool inA = (n >= 3) && (imA + (uint32_t)u <= span);
+                            const bool inB = (n >= 3) && (imB + (uint32_t)u <= span);
+                            tmax = inA ? fmax_gt(tmax, tn.x) : tmax;
+                            tmax = inB ? fmax_gt(tmax, tn.y) : tmax;
+                            tm1 = tc;
+                            tc = cur[u];
+                        }
+                    }
+                } else {
+                    // TILE_S: per-cell predicated fallback for both components (rare)
+#pragma unroll 1
+                    for (int u = 0; u < 8; ++u) {
+                        const int r = r0 + u;
+                        const uint32_t zj = wt->zj[r], iv = wt->iv[r];
+                        const f2 tp1 = cur[0];
+                        f2 tn;
+#pragma unroll
+                        for (int v = 0; v < 2; ++v) {
+                            const int vcid = 2 * c + v;
+                            const bool zbit = (zj >> vcid) & 1u, jbit = (zj >> (16 + vcid)) & 1u;
+                            const bool inter = ((iv >> vcid) & 1u) && !all_slow;
+                            const bool valid = ((iv >> (16 + vcid)) & 1u) && !s.done;
+                            const float conv = zbit ? cz : cb, jfe = jbit ? jf_lane : 0.0f;
+                            const float m = v ? tm1.y : tm1.x, cc = v ? tc.y : tc.x, pp = v ? tp1.y : tp1.x;
+                            float x = interior_cell<true>(m, cc, pp, g.k, g.tuf, conv, tdiel, ps.adv, jfe, alpha, tref);
+                            if (!inter && valid) {
+                                const int i = (v ? baseB : baseA) + r;
+                                x = (i >= 1) ? stencil_cell(i, n, (i == 1) ? spool : m, cc, pp, g, cf, ps, tref, alpha, tdiel) : spool;
+                            }
+                            if (valid) {
+                                col[(2 * r + v) * 256] = x;
+                                tmax = fmax_gt(tmax, x);
+                            }
+                            if (v) tn.y = x; else tn.x = x;
+                        }
+                        tm1 = tc;
+                        tc = tp1;
+                        f2 first = cur[0];
+#pragma unroll
+                        for (int q = 0; q < 7; ++q) cur[q] = cur[q + 1];
+                        cur[7] = first;
+                    }
+                }
+            };
+            f2 bufA[8], bufB[8];
+            load8(bufA, 0);
+            for (int t = 0; t < n_tiles; t += 2) {
+                tile(t, bufA, bufB);
+                if (t + 1 < n_tiles) tile(t + 1, bufB, bufA);
+            }
+        }
+        WEDM_STAMP(st2);
+        // ---- patches (after every store of the walk): boundary condition, last cell, plasma cell
+        if (c == 0 && !s.done) col[0] = spool;
+        if (own_last && !s.done) {
+            const int v = own_last - 1;
+            col[(2 * (n - 1 - (v ? baseB : baseA)) + v) * 256] = tlast;
+            tmax = fmax_gt(tmax, tlast);
+        }
+        if (own_pl) {
+            const int v = own_pl - 1;
+            col[(2 * (cf.pidx - (v ? baseB : baseA)) + v) * 256] = tpl;
+            tmax = fmax_gt(tmax, tpl);
+        }
+#pragma unroll
+        for (int m = 1; m < L; m <<= 1) tmax = fmax_gt(tmax, __shfl_xor(tmax, m));
+        WEDM_STAMP(st3);
+        if (!s.done) {
+            scalar_epilogue(k.hot, s, tmax);
+            if (s.ctrl && c == 0) write_obs(k.cold, e, s);
+        }
+        WEDM_STAMP(st4);
+        WEDM_STAMP_ACC();
+    }
+    WEDM_STAMP_OUT();
+
+    __syncthreads();
+    {
+        const int rr = tid / EPB, sel = tid % EPB;
+        int vc = 0, r = rr;
+        while (r >= Cv) { r -= Cv; ++vc; }
+        const bool ok = e0 + sel < k.num_envs;
+        float* dst = k.cold.s.T + e0 + sel;
+        for (int i0 = 0; i0 < n; i0 += L) {
+            const int i = i0 + rr;
+            if (i < n && ok) dst[(int64_t)i * stride] = lds[(2 * r + (vc & 1)) * 256 + sel * L + (vc >> 1)];
+            r += L;
+            while (r >= Cv) { r -= Cv; ++vc; }
         }
     }
     if (live && c == 0) store_env(k.cold.s, e, s);
@@ -508,6 +844,7 @@ struct wedm_ctx {
     Tables tb{};
     int32_t variant = 0;
     int32_t lanes = 0;                 // lanes per environment for the fused kernel (0 = auto)
+    unsigned long long* dbg = nullptr; // diagnostic builds: phase stamp buffer
     int lds_limit = 0;
     WalkTable* walk_dev = nullptr;     // [5] tables for L = 1, 2, 4, 8, 16
     bool walk_ok[5] = {false, false, false, false, false};
@@ -573,6 +910,7 @@ static int lanes_index(int L) { return L == 1 ? 0 : L == 2 ? 1 : L == 4 ? 2 : L 
 // chunk in LDS and (b) puts at least ~2 waves on every SIMD (1024 SIMDs), preferring more
 // lanes only while the per-lane wire work still outweighs the replicated scalar work.
 static int auto_lanes(const wedm_ctx* ctx);
+static int auto_lanes_packed(const wedm_ctx* ctx);
 
 static thread_local std::string g_create_error;
 
@@ -697,6 +1035,22 @@ static int auto_lanes(const wedm_ctx* ctx) {
     return best;
 }
 
+// packed kernel: the smallest L in {1,2,4,8} whose two chunks fit in LDS, raised until the
+// launch has ~2 waves per SIMD or the chunks get shorter than two tiles
+static int auto_lanes_packed(const wedm_ctx* ctx) {
+    const int Ls[4] = {1, 2, 4, 8};
+    int best = 0;
+    for (int i = 0; i < 4; ++i) {
+        const int ti = lanes_index(2 * Ls[i]);
+        if (!ctx->walk_ok[ti]) continue;
+        if ((2 * (size_t)ctx->walk_C[ti] + 2) * 1024 > (size_t)ctx->lds_limit) continue;
+        best = Ls[i];
+        const long waves = (long)((ctx->num_envs + (256 / Ls[i]) - 1) / (256 / Ls[i])) * 4;
+        if (waves >= 2048 || ctx->walk_C[ti] <= 16) break;
+    }
+    return best;
+}
+
 int32_t wedm_destroy(wedm_ctx* ctx) {
     if (!ctx) return WEDM_ERR_BAD_ARG;
     if (ctx->tables_dev) (void)hipFree(ctx->tables_dev);
@@ -727,8 +1081,16 @@ int32_t wedm_bind_geometry(wedm_ctx* ctx, const wedm_geom_ptrs* geom) {
 
 int32_t wedm_set_kernel(wedm_ctx* ctx, int32_t variant) {
     if (!ctx) return WEDM_ERR_BAD_ARG;
-    if (variant < 0 || variant > 3) return fail(ctx, WEDM_ERR_BAD_ARG, "wedm_set_kernel: variant must be 0..3");
+    if (variant < 0 || variant > 4) return fail(ctx, WEDM_ERR_BAD_ARG, "wedm_set_kernel: variant must be 0..4");
     ctx->variant = variant;
+    return WEDM_OK;
+}
+
+// diagnostic builds (-DWEDM_STAMPS): device buffer of 4 uint64 per wave receiving the cycles
+// spent in {prelude, walk, patches+reduce, epilogue}; ignored by the shipped library
+int32_t wedm_debug_set_stamp_buffer(wedm_ctx* ctx, void* buf) {
+    if (!ctx) return WEDM_ERR_BAD_ARG;
+    ctx->dbg = (unsigned long long*)buf;
     return WEDM_OK;
 }
 
@@ -792,19 +1154,29 @@ int32_t wedm_step(wedm_ctx* ctx, int32_t n_substeps, const wedm_action_ptrs* act
     k.n_substeps = n_substeps;
     k.n_seg_max = ctx->n_seg_max;
     k.walk = nullptr;
+    k.dbg = ctx->dbg;
 
     const size_t lds_bytes = (size_t)ctx->n_seg_max * 64 * sizeof(float);
+    // kernel 3 (one chunk per lane) and kernel 4 (two packed chunks per lane, table of 2L chunks)
     int lanes = ctx->lanes ? ctx->lanes : auto_lanes(ctx);
     const int li = lanes_index(lanes);
-    const bool fused_ok = !ctx->p.per_env_geometry && ctx->walk_dev && li >= 0 && ctx->walk_ok[li] &&
+    const bool uniform = !ctx->p.per_env_geometry && ctx->walk_dev;
+    const bool fused_ok = uniform && li >= 0 && ctx->walk_ok[li] &&
                           ((size_t)ctx->walk_C[li] + 1) * 1024 <= (size_t)ctx->lds_limit;
+    int planes = ctx->lanes ? ctx->lanes : auto_lanes_packed(ctx);
+    const int pli = (planes >= 1 && planes <= 8) ? lanes_index(2 * planes) : -1;
+    const bool packed_ok = uniform && pli >= 0 && ctx->walk_ok[pli] &&
+                           (2 * (size_t)ctx->walk_C[pli] + 2) * 1024 <= (size_t)ctx->lds_limit;
     int variant = ctx->variant;
     if (variant == 0) {
-        if (n_substeps > 1 && fused_ok) variant = 3;
+        if (n_substeps > 1 && packed_ok) variant = 4;
+        else if (n_substeps > 1 && fused_ok) variant = 3;
         else variant = (n_substeps > 1 && lds_bytes <= (size_t)ctx->lds_limit) ? 2 : 1;
     }
     if (variant == 3 && !fused_ok)
         return fail(ctx, WEDM_ERR_UNSUPPORTED, "wedm_step: fused kernel needs uniform geometry and a chunk that fits in LDS");
+    if (variant == 4 && !packed_ok)
+        return fail(ctx, WEDM_ERR_UNSUPPORTED, "wedm_step: packed kernel needs uniform geometry, lanes in {1,2,4,8} and two chunks that fit in LDS");
     if (variant == 2 && lds_bytes > (size_t)ctx->lds_limit)
         return fail(ctx, WEDM_ERR_UNSUPPORTED, "wedm_step: n_seg_max * 256 B exceeds the LDS a workgroup can take");
 
@@ -821,6 +1193,22 @@ int32_t wedm_step(wedm_ctx* ctx, int32_t n_substeps, const wedm_action_ptrs* act
         if (ea != hipSuccess) return hip_fail(ctx, ea, "hipFuncSetAttribute(wedm_step_lds)");
         hipLaunchKernelGGL(wedm_step_lds, dim3(grid), dim3(64), lds_bytes, (hipStream_t)stream, k);
         std::snprintf(name, sizeof(name), "wedm_step_lds<<<%d,64,%zuB>>> n_sub=%d", grid, lds_bytes, n_substeps);
+    } else if (variant == 4) {
+        const int epb = 256 / planes;
+        const int grid = (ctx->num_envs + epb - 1) / epb;
+        const size_t fl = (2 * (size_t)ctx->walk_C[pli] + 2) * 1024;
+        k.walk = ctx->walk_dev + pli;
+        const void* fn = planes == 1 ? (const void*)wedm_step_packed<1> : planes == 2 ? (const void*)wedm_step_packed<2>
+                       : planes == 4 ? (const void*)wedm_step_packed<4> : (const void*)wedm_step_packed<8>;
+        hipError_t ea = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)fl);
+        if (ea != hipSuccess) return hip_fail(ctx, ea, "hipFuncSetAttribute(wedm_step_packed)");
+        switch (planes) {
+            case 1: hipLaunchKernelGGL(wedm_step_packed<1>, dim3(grid), dim3(256), fl, (hipStream_t)stream, k); break;
+            case 2: hipLaunchKernelGGL(wedm_step_packed<2>, dim3(grid), dim3(256), fl, (hipStream_t)stream, k); break;
+            case 4: hipLaunchKernelGGL(wedm_step_packed<4>, dim3(grid), dim3(256), fl, (hipStream_t)stream, k); break;
+            default: hipLaunchKernelGGL(wedm_step_packed<8>, dim3(grid), dim3(256), fl, (hipStream_t)stream, k); break;
+        }
+        std::snprintf(name, sizeof(name), "wedm_step_packed<%d><<<%d,256,%zuB>>> n_sub=%d", planes, grid, fl, n_substeps);
     } else {
         const int epb = 256 / lanes;
         const int grid = (ctx->num_envs + epb - 1) / epb;

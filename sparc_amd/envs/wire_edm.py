@@ -302,8 +302,9 @@ class WireEDMEnv:
             raise ValueError(f"environment {idx}: fresh spark with a current mode that has no crater data")
 
     def set_kernel(self, variant: int, lanes: int = 0) -> None:
-        """0 = auto, 1 = global-memory stencil, 2 = LDS predicated, 3 = LDS fused with
-        ``lanes`` lanes per environment (0 = auto).  All variants are bit-identical."""
+        """0 = auto, 1 = global-memory stencil, 2 = LDS predicated, 3 = LDS fused, 4 = LDS
+        fused with packed float32 math; ``lanes`` lanes per environment for 3/4 (0 = auto).
+        All variants are bit-identical."""
         self._backend.set_kernel(variant)
         if hasattr(self._backend, "set_lanes"):
             self._backend.set_lanes(lanes)

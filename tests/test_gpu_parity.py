@@ -50,7 +50,7 @@ def test_native_library_is_the_one_running():
     env.step(env.make_action())
     assert "wedm_step_global" in env._backend.last_kernel()
     env.step_many(env.make_action(), 10)
-    assert "wedm_step_fused" in env._backend.last_kernel()
+    assert "wedm_step_packed" in env._backend.last_kernel() or "wedm_step_fused" in env._backend.last_kernel()
 
 
 @pytest.mark.parametrize("kind", [0, 1, 2, 3, 4, 5, 6, 7])
@@ -108,7 +108,7 @@ def test_device_math_primitives_match_cpu_bit_for_bit(orc, kind):
         f"kind {kind}: {np.count_nonzero(got.view(np.uint64) != want.view(np.uint64))} of {len(want)} differ"
 
 
-KERNELS = [(1, 0), (2, 0), (3, 1), (3, 2), (3, 4), (3, 8), (3, 16)]
+KERNELS = [(1, 0), (2, 0), (3, 1), (3, 2), (3, 4), (3, 8), (3, 16), (4, 1), (4, 2), (4, 4), (4, 8)]
 
 
 @pytest.mark.parametrize("variant,lanes", KERNELS)
@@ -118,7 +118,9 @@ def test_default_config_fused_matches_oracle(variant, lanes):
     gpu, cpu = make_pair(n)
     gpu.set_kernel(variant, lanes)
     both((gpu, cpu), lambda e: (e.reset(seed=1234), close_gap(e)))
-    if variant == 3 and (-(-gpu.n_segments // lanes) + 1) * 1024 > 160 * 1024:
+    too_big = (variant == 3 and (-(-gpu.n_segments // lanes) + 1) > 160) or \
+              (variant == 4 and (2 * -(-gpu.n_segments // (2 * lanes)) + 2) > 160)
+    if too_big:
         from sparc_amd._lib import WedmError
 
         with pytest.raises(WedmError, match="WEDM_ERR_UNSUPPORTED"):  # chunk does not fit in 160 KB of LDS
@@ -169,15 +171,15 @@ def test_config3_grid_128_segments(variant, lanes):
     check(gpu, cpu, n)
 
 
-@pytest.mark.parametrize("lanes", [4, 8, 16])
-def test_fused_kernel_with_ragged_chunks_and_heavy_sparking(lanes):
+@pytest.mark.parametrize("variant,lanes", [(3, 4), (3, 8), (3, 16), (4, 4), (4, 8)])
+def test_fused_kernel_with_ragged_chunks_and_heavy_sparking(variant, lanes):
     """361 segments (not divisible by any lane count), thin wire + I17: Joule heating,
     plasma cells at chunk edges, wire breaks and frozen environments inside live waves."""
     n = 200
     kw = dict(config=EnvironmentConfig(workpiece_height=12.3, wire_diameter=0.15, target_cutting_distance=5000.0))
     gpu, cpu = make_pair(n, **kw)
     assert gpu.n_segments == 361
-    gpu.set_kernel(3, lanes)
+    gpu.set_kernel(variant, lanes)
     both((gpu, cpu), lambda e: (e.reset(seed=17), close_gap(e, 24.0, 10.0)))
     for env in (gpu, cpu):
         a = env.make_action(0.1, 80.0, 17, 3.0, 40.0)
@@ -186,7 +188,7 @@ def test_fused_kernel_with_ragged_chunks_and_heavy_sparking(lanes):
         env.state.wire_unwinding_velocity[::7] = 0.0   # mixed advection inside a wave
         env.step_many(a, 700)
     check(gpu, cpu, n)
-    assert f"wedm_step_fused<{lanes}>" in gpu._backend.last_kernel()
+    assert f"{'wedm_step_fused' if variant == 3 else 'wedm_step_packed'}<{lanes}>" in gpu._backend.last_kernel()
     assert bool(gpu.state.is_wire_broken.any()) and not bool(gpu.state.is_wire_broken.all())
 
 
@@ -376,7 +378,7 @@ def test_full_size_fusion_and_sharding_invariance():
     act = a_env.make_action(0.1, 80.0, 5, 3.0, 80.0)
     a_env.step_many(act, 1000)
     a_env.step_many(act, 300)
-    assert "wedm_step_fused" in a_env._backend.last_kernel()
+    assert "wedm_step_packed" in a_env._backend.last_kernel()
     for _ in range(1300):
         b_env.step(act)
     assert "wedm_step_global" in b_env._backend.last_kernel()
