@@ -135,7 +135,8 @@ def main():
     act = env.make_action(0.1, 80.0, 5, 3.0, 80.0)
     S = env.n_segments
     obs_local = env.state.obs[:, :n_local]
-    gathered = torch.empty((world,) + tuple(obs_local.shape), dtype=obs_local.dtype, device=device) if world > 1 else None
+    gathered = (torch.empty((world * obs_local.shape[0], obs_local.shape[1]), dtype=obs_local.dtype, device=device)
+                if world > 1 else None)
 
     def one_step():
         env.step_many(act, n_sub)

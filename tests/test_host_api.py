@@ -1,0 +1,225 @@
+"""CPU-side tests of the host layer: the reference's own smoke tests (tests/test_state.py,
+tests/test_env_integration.py of the reference) restated for the batched environment,
+plus configuration, derivation and action plumbing.  The physics backend here is the
+oracle test seam (tests/_oracle_backend.py); the product itself has no CPU path."""
+from __future__ import annotations
+
+import json
+
+import numpy as np
+import pytest
+import torch
+
+from sparc_amd import (DielectricModuleParameters, EnvironmentConfig, IgnitionModuleParameters, MaterialDatabase,
+                       MaterialModuleParameters, MechanicsModuleParameters, WireEDMEnv, WireModuleParameters,
+                       get_material_db)
+from sparc_amd.core import derive
+from tests._oracle_backend import OracleBackend
+
+
+def make(n=4, **kw):
+    return WireEDMEnv(num_envs=n, device="cpu", backend=OracleBackend, **kw)
+
+
+# ---- reference tests/test_env_integration.py, batched --------------------------------------
+def test_env_creation():
+    env = make()
+    assert env is not None and env.config is not None
+
+
+def test_env_reset():
+    env = make()
+    obs, info = env.reset()
+    assert obs is not None and isinstance(info, dict)
+    assert (env.state.time == 0).all()
+    assert (env.state.workpiece_position == env.config.initial_gap).all()
+    assert (env.state.target_position == env.config.target_cutting_distance).all()
+
+
+def test_env_step_with_sampled_action():
+    env = make()
+    env.reset(seed=0)
+    action = env.action_space.sample(env.np_random)
+    action["generator_control"]["current_mode"] = np.array([5], dtype=np.int32)  # a mode with crater data
+    obs, reward, terminated, truncated, info = env.step(action)
+    assert (env.state.time > 0).all()
+    assert reward.shape == (4,) and terminated.dtype == torch.bool and truncated.dtype == torch.bool
+    assert set(info) == {"wire_broken", "target_reached", "spark_state", "time", "control_step"}
+
+
+def test_custom_config():
+    cfg = EnvironmentConfig(workpiece_height=20.0, wire_diameter=0.3, target_cutting_distance=1000.0)
+    env = make(config=cfg)
+    assert env.config.wire_diameter == 0.3 and env.config.target_cutting_distance == 1000.0
+    assert env.workpiece_height == 20.0 and env.wire_diameter == 0.3
+
+
+def test_control_modes():
+    assert make(mechanics_control_mode="position").mechanics_control_mode == "position"
+    assert make(mechanics_control_mode="velocity").mechanics.control_mode == "velocity"
+    with pytest.raises(ValueError):
+        make(mechanics_control_mode="invalid")
+
+
+# ---- reference tests/test_state.py, batched ------------------------------------------------
+def test_state_defaults_and_assignment():
+    env = make()
+    env.reset(seed=1)
+    s = env.state
+    assert (s.wire_position == 0.0).all() and (s.time == 0).all()
+    s.wire_position = 10.0
+    s.workpiece_position = torch.tensor([15.0, 16.0, 17.0, 18.0])
+    s.target_position = 100.0
+    assert (s.wire_position == 10.0).all()
+    assert s.workpiece_position.tolist() == [15.0, 16.0, 17.0, 18.0]
+    assert (s.target_position == 100.0).all()
+    assert s.wire_temperature.shape == (4, env.n_segments)
+    st, y, dur = s.spark_status
+    assert (st == 0).all() and y.isnan().all() and (dur == 0).all()
+
+
+# ---- configuration -------------------------------------------------------------------------
+@pytest.mark.parametrize("field,value", [("workpiece_height", 0.0), ("wire_diameter", -1.0), ("initial_gap", 0.0),
+                                         ("target_cutting_distance", 0.0), ("dt", 0), ("servo_interval", 0),
+                                         ("max_wire_temperature", 293.15)])
+def test_config_validate_raises_like_the_reference(field, value):
+    cfg = EnvironmentConfig(**{field: value})
+    with pytest.raises(ValueError):
+        cfg.validate()
+    with pytest.raises(ValueError):
+        make(config=cfg)
+
+
+def test_config_dict_json_roundtrip(tmp_path):
+    cfg = EnvironmentConfig(workpiece_height=12.5, wire_diameter=0.25, servo_interval=500)
+    d = cfg.to_dict()
+    assert EnvironmentConfig.from_dict({**d, "unknown_key": 1}) == cfg
+    cfg.to_json(tmp_path / "c.json")
+    assert EnvironmentConfig.from_json(tmp_path / "c.json") == cfg
+    assert json.loads((tmp_path / "c.json").read_text())["servo_interval"] == 500
+
+
+def test_material_database():
+    db = get_material_db()
+    brass = db.get_wire_material("brass")
+    assert (brass.density, brass.specific_heat, brass.melting_point, brass.breaking_temperature) == (8400, 377, 1173, 1500)
+    with pytest.raises(ValueError):
+        db.get_wire_material("unobtainium")
+    with pytest.raises(ValueError):
+        make(config=EnvironmentConfig(wire_material="unobtainium"))
+
+
+def test_material_database_save_and_reload(tmp_path):
+    db = MaterialDatabase(tmp_path)
+    db.save_materials()
+    assert MaterialDatabase(tmp_path).get_wire_material("brass").thermal_conductivity == 120
+
+
+def test_parameter_dataclass_defaults_match_the_reference():
+    i, w = IgnitionModuleParameters(), WireModuleParameters()
+    assert (i.sigmoid_steepness, i.debris_short_duration, i.random_short_max_probability) == (500.0, 50, 0.0)
+    assert (i.ignition_a_coeff, i.ignition_b_coeff, i.ignition_c_coeff, i.default_current_mode) == (0.48, -3.69, 14.05, "I5")
+    assert (w.segment_len, w.spool_T, w.base_convection_coefficient, w.plasma_efficiency) == (0.2, 293.15, 14000, 0.1)
+    assert MaterialModuleParameters().base_overcut == 0.12
+    d, m = DielectricModuleParameters(), MechanicsModuleParameters()
+    assert (d.base_flow_rate, d.debris_removal_efficiency, d.reference_gap) == (100.0, 0.01, 25.0)
+    assert (m.omega_n, m.zeta, m.max_acceleration, m.max_jerk, m.max_speed) == (235.0, 0.38, 3.0e5, 1.0e8, 3.0e4)
+
+
+# ---- host-side derivation vs the reference's constructors (fixture F4) ----------------------
+def test_derive_geometry_matches_reference_table(golden_dir):
+    z = np.load(golden_dir / "f4_geometry_table.npz")
+    cols = json.loads(str(z["columns"]))
+    brass = get_material_db().get_wire_material("brass")
+    for row in z["table"]:
+        r = dict(zip(cols, row))
+        wire = WireModuleParameters(segment_len=r["seg"], buffer_len_bottom=r["buf_bottom"], buffer_len_top=r["buf_top"],
+                                    contact_offset_bottom=r["off_bottom"], contact_offset_top=r["off_top"])
+        g = derive.derive_geometry(r["h"], r["d"], wire, brass, MaterialModuleParameters())
+        for k in ("n_seg", "zone_start", "zone_end", "az_start", "az_end", "contact_bottom", "contact_top"):
+            assert getattr(g, k) == int(r[k]), (k, r)
+        for k in ("k_cond", "tuf", "a_surf", "s_area", "joule_geom", "cavity_coeff"):
+            assert getattr(g, k) == r[k], (k, r)
+        p = derive.build_params(EnvironmentConfig(workpiece_height=r["h"], wire_diameter=r["d"]), "position",
+                                IgnitionModuleParameters(), wire, MaterialModuleParameters(),
+                                DielectricModuleParameters(), MechanicsModuleParameters(), brass, geometry=g)
+        for k in ("critical_temperature", "breaking_temperature", "debris_removal_per_us", "damping_coeff",
+                  "stiffness_coeff", "max_jerk_dt", "dt_s"):
+            assert getattr(p, k) == r[k], (k, r)
+
+
+def test_survey_geometry_known_answers():
+    """(h, seg, d) -> (n_seg, zone, contacts)."""
+    brass = get_material_db().get_wire_material("brass")
+    cases = {(20, .2, .2): (400, 149, 248, 100, 300), (20, .625, .2): (128, 48, 80, 32, 96),
+             (10, .2, .2): (350, 149, 198, 100, 250), (15, .2, .25): (375, 149, 223, 100, 275),
+             (30, .2, .3): (450, 149, 298, 100, 350)}
+    for (h, seg, d), want in cases.items():
+        g = derive.derive_geometry(h, d, WireModuleParameters(segment_len=seg), brass, MaterialModuleParameters())
+        assert (g.n_seg, g.zone_start, g.zone_end, g.contact_bottom, g.contact_top) == want
+
+
+# ---- action plumbing -----------------------------------------------------------------------
+def test_action_leaf_shapes_and_broadcast():
+    env = make(n=6)
+    env.reset(seed=3)
+    a = env.make_action(servo=np.linspace(-1, 1, 6), target_voltage=torch.full((6, 1), 90.0), current_mode=[1, 3, 5, 7, 9, 11],
+                        ON_time=2.0, OFF_time=np.array([30.0]))
+    assert a.servo.dtype == torch.float64 and a.current_mode.dtype == torch.int32
+    assert a.target_voltage.shape == (6,) and a.on_time.tolist() == [2.0] * 6
+    with pytest.raises(ValueError):
+        env.make_action(servo=np.zeros(5))
+
+
+def test_invalid_mode_raises_like_material_module():
+    env = make()
+    env.reset(seed=0)
+    for bad in (2, 4, 18, 19):
+        with pytest.raises(ValueError, match="not available in crater data"):
+            env.step(env.make_action(current_mode=bad))
+
+
+def test_action_is_latched_only_on_control_steps():
+    env = make(n=2)
+    env.reset(seed=5)
+    env.step_many(env.make_action(servo=0.7, target_voltage=123.0), 1000)
+    assert (env.state.target_delta == 0.0).all() and (env.state.target_voltage == 0.0).all()  # None until call 1001
+    _, _, _, _, info = env.step(env.make_action(servo=0.7, target_voltage=123.0))
+    assert info["control_step"].all()
+    assert (env.state.target_delta == 0.7).all() and (env.state.target_voltage == 123.0).all()
+    assert (env.state.time_since_servo == 1).all()
+
+
+def test_partial_reset_mask_and_seeding():
+    env = make(n=8)
+    env.reset(seed=11)
+    env.step_many(env.make_action(), 50)
+    mask = np.array([1, 0, 0, 1, 0, 0, 0, 1], dtype=bool)
+    env.reset(options={"mask": mask})
+    assert env.state.time.tolist() == [0, 50, 50, 0, 50, 50, 50, 0]
+    assert env.state.episode.tolist() == [1, 0, 0, 1, 0, 0, 0, 1]
+    a, b = make(n=8), make(n=8)
+    for e in (a, b):
+        e.reset(seed=99)
+        e.state.workpiece_position = 25.0
+        e.state.wire_position = 10.0
+        e.step_many(e.make_action(), 1500)
+    assert bool(((a.state.f64 == b.state.f64) | (a.state.f64.isnan() & b.state.f64.isnan())).all())
+    assert torch.equal(a.state.T, b.state.T)
+    assert int(a.state.spark_count.sum()) > 0
+
+
+def test_per_environment_geometry_rows():
+    h = np.array([10.0, 20.0, 30.0, 12.3])
+    d = np.array([0.10, 0.20, 0.30, 0.15])
+    env = make(n=4, workpiece_height=h, wire_diameter=d)
+    assert env.params.per_env_geometry == 1 and env.n_segments == 450
+    assert env._geom_i32[0, :4].tolist() == [350, 400, 450, 361]
+    with pytest.raises(ValueError):
+        make(n=4, workpiece_height=np.array([10.0, -1.0, 30.0, 12.3]))
+
+
+def test_product_refuses_to_run_without_the_gpu():
+    """No CPU fallback: the default backend is the HIP library and needs a CUDA/HIP device."""
+    with pytest.raises(RuntimeError, match="no CPU path"):
+        WireEDMEnv(num_envs=2, device="cpu")
