@@ -42,7 +42,7 @@ def parse_args():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--substeps", type=int, default=1000, help="physics microseconds per bench step")
-    ap.add_argument("--workload", choices=["config3", "config2", "config4"], default="config3")
+    ap.add_argument("--workload", choices=["config3", "config2", "config4", "config5"], default="config3")
     ap.add_argument("--num-envs", type=int, default=0, help="override environments per GPU")
     ap.add_argument("--kernel", type=int, default=0, help="0 auto, 1 global-memory, 2 LDS predicated, 3 LDS fused, 4 LDS fused + packed f32")
     ap.add_argument("--lanes", type=int, default=0, help="lanes per environment in kernel 3 (0 auto)")
@@ -60,11 +60,25 @@ def workload(args):
         n, wire, name = 65536, WireModuleParameters(segment_len=0.625), "BASELINE configs[2]"
     elif args.workload == "config2":
         n, wire, name = 4096, WireModuleParameters(), "BASELINE configs[1]"
-    else:
+    elif args.workload == "config4":
         n, wire, name = 32768, WireModuleParameters(), "BASELINE configs[3] (per-GPU shard)"
+    else:
+        n, wire, name = 16384, WireModuleParameters(), "BASELINE configs[4] (per-GPU shard, per-env geometry)"
     if args.num_envs:
         n = args.num_envs
     return n, wire, name
+
+
+def config5_draws(n_global, lo, hi):
+    """per-env workpiece_height ~ U[10,30] mm, wire_diameter and
+    current_mode from fixed sets, drawn host-side from numpy.default_rng(2024)."""
+    import numpy as np
+
+    rng = np.random.default_rng(2024)
+    h = rng.uniform(10.0, 30.0, n_global)
+    d = rng.choice([0.10, 0.15, 0.20, 0.25, 0.30], n_global)
+    mode = rng.choice([1, 3, 5, 7, 9, 11, 13, 15, 17], n_global).astype(np.int32)
+    return h[lo:hi], d[lo:hi], mode[lo:hi]
 
 
 def cpu_baseline(wire_params, n_envs, n_sub, target_seconds):
@@ -129,10 +143,19 @@ def main():
 
     n_local, wire, wl_name = workload(args)
     n_sub = args.substeps
-    env = WireEDMEnv(num_envs=n_local, device=device, wire_params=wire, env_id_offset=rank * n_local)
+    if args.workload == "config5":
+        from sparc_amd import EnvironmentConfig
+
+        h, d, mode = config5_draws(world * n_local, rank * n_local, (rank + 1) * n_local)
+        env = WireEDMEnv(num_envs=n_local, device=device, wire_params=wire, env_id_offset=rank * n_local,
+                         workpiece_height=h, wire_diameter=d,
+                         config=EnvironmentConfig(target_cutting_distance=5000.0))
+    else:
+        mode = 5
+        env = WireEDMEnv(num_envs=n_local, device=device, wire_params=wire, env_id_offset=rank * n_local)
     env.set_kernel(args.kernel, args.lanes)
     env.reset(seed=1234)
-    act = env.make_action(0.1, 80.0, 5, 3.0, 80.0)
+    act = env.make_action(0.1, 80.0, mode, 3.0, 80.0)
     S = env.n_segments
     obs_local = env.state.obs[:, :n_local]
     gathered = (torch.empty((world * obs_local.shape[0], obs_local.shape[1]), dtype=obs_local.dtype, device=device)

@@ -5,11 +5,9 @@
 //                      global memory (layout T[seg][env] -> every row access is a
 //                      256-B coalesced wave transaction).  One HBM/L2 pass per
 //                      microsecond; used for n_substeps == 1 (the reference's step()).
-//   wedm_step_lds    : same lanes, but the wave first stages its 64 wire columns into
-//                      LDS ([seg][lane], conflict-free: lane l always hits bank l%32 in
-//                      its half), runs n_substeps microseconds out of LDS + registers,
-//                      and writes everything back once.  No barriers: a lane only ever
-//                      touches its own LDS column.
+//   wedm_step_lanes<L>: any geometry (one (h, d) pair per environment: BASELINE config 5).
+//                      L lanes per environment, wire chunks in LDS, every cell on the
+//                      predicated formula with the lane's own indices.
 //   wedm_step_fused<L>: the throughput kernel for uniform geometry.  L lanes share one
 //                      environment: the wire is cut into L chunks, chunk c of environment
 //                      el lives in LDS column (el*L + c) as [cell j][256 lanes] (lane-linear
@@ -80,11 +78,6 @@ struct GlobalT {
     __device__ __forceinline__ float ld(int i) const { return base[(int64_t)i * stride]; }
     __device__ __forceinline__ void st(int i, float v) const { base[(int64_t)i * stride] = v; }
 };
-struct LdsT {
-    float* base;  // &lds[wave region][0][lane]
-    __device__ __forceinline__ float ld(int i) const { return base[i * 64]; }
-    __device__ __forceinline__ void st(int i, float v) const { base[i * 64] = v; }
-};
 
 // One in-place pass of wire.py:58-123 over the lane's wire.  Tiles of 8 cells: the 8
 // "next" temperatures are loaded before any of the tile's stores, so every cell sees
@@ -148,25 +141,110 @@ __global__ void __launch_bounds__(256) wedm_step_global(const KArgs k) {
     store_env(k.cold.s, e, s);
 }
 
-__global__ void __launch_bounds__(64) wedm_step_lds(const KArgs k) {
+// np.max over finite temperatures; maps to v_max_f32 / v_max3_f32
+__device__ __forceinline__ float fmax_gt(float a, float b) { return __builtin_fmaxf(a, b); }
+
+// Any geometry (uniform or one row per environment), L lanes per environment, every cell on the
+// predicated formula with the lane's own n_seg / zone / contact indices.  LDS layout and halo
+// exchange as in the fused kernels; the chunk length is uniform, C = ceil(n_seg_max / L), so an
+// environment with a shorter wire simply leaves the tail of its last chunks unused.
+template <int L>
+__global__ void __launch_bounds__(256, 2) wedm_step_lanes(const KArgs k) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
-    const int lane = threadIdx.x;
-    const int64_t e = (int64_t)blockIdx.x * 64 + lane;
-    if (e >= k.num_envs) return;
-    Env s;
-    load_env(k.cold.s, e, s);
-    if (s.done) return;
-    s.ipk = peak_current(k.cold, s.mode);
-    Geom g;
-    load_geom(k.hot, k.cold, e, g);
-    LdsT T{lds + lane};
-    const float* src = k.cold.s.T + e;
+    constexpr int EPB = 256 / L;
+    const int tid = threadIdx.x;
+    const int el = tid / L, c = tid % L;
+    const int64_t e0 = (int64_t)blockIdx.x * EPB;
+    const int64_t e = e0 + el;
+    const bool live = e < k.num_envs;
+    const int nmax = k.n_seg_max;
+    const int C = (nmax + L - 1) / L;
     const int64_t stride = k.cold.s.stride;
-    for (int i = 0; i < g.n_seg; ++i) T.st(i, src[(int64_t)i * stride]);
-    run_substeps(k, g, e, k.hot.env_id_offset + (uint32_t)e, s, T);
-    float* dst = k.cold.s.T + e;
-    for (int i = 0; i < g.n_seg; ++i) dst[(int64_t)i * stride] = T.ld(i);
-    store_env(k.cold.s, e, s);
+    {
+        const int r = tid / EPB, sel = tid % EPB;
+        int ci = 0, ji = r;
+        while (ji >= C) { ji -= C; ++ci; }
+        const bool ok = e0 + sel < k.num_envs;
+        const float* src = k.cold.s.T + e0 + sel;
+        for (int i0 = 0; i0 < nmax; i0 += L) {
+            const int i = i0 + r;
+            if (i < nmax && ok) lds[ji * 256 + sel * L + ci] = src[(int64_t)i * stride];
+            ji += L;
+            while (ji >= C) { ji -= C; ++ci; }
+        }
+    }
+    __syncthreads();
+
+    Env s;
+    Geom g;
+    Persist ps{0.0f, 0.0f, 0.0f, 0};
+    load_geom(k.hot, k.cold, live ? e : 0, g);
+    if (live) load_env(k.cold.s, e, s);
+    else { s.done = 1; s.unwind = 0.0; s.h_base = 0.0f; s.h_zone = 0.0f; }
+    if (!s.done) {
+        s.ipk = peak_current(k.cold, s.mode);
+        init_persist(k.hot, k.cold, e, s, ps);
+    }
+    const uint32_t gid = k.hot.env_id_offset + (uint32_t)e;
+    float* col = lds + tid;
+    const int cbase = c * C;
+    const int n = g.n_seg;  // this lane's environment
+    const float spool = k.hot.spool, tref = k.hot.tref, alpha = k.hot.alpha, tdiel = k.hot.tdiel;
+    if (c == 0) col[0] = spool;
+
+    for (int it = 0; it < k.n_substeps; ++it) {
+        if (__all(s.done)) break;
+        Coef cf{0.0f, 0.0f, 0, -1};
+        if (!s.done) cf = scalar_prelude(k.hot, k.cold, g, e, gid, s, ps);
+        const float halo_l = (c > 0) ? col[(C - 1) * 256 - 1] : spool;
+        const float halo_r = (c < L - 1) ? col[1] : 0.0f;
+        float tmax = spool, tm1 = halo_l, tc = col[0];
+        for (int j0 = 0; j0 < C; j0 += 8) {
+            float nx[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int row = j0 + 1 + u;
+                nx[u] = row < C ? col[row * 256] : halo_r;
+            }
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int j = j0 + u;
+                if (j < C) {
+                    const int i = cbase + j;
+                    if (i < n && !s.done) {
+                        const float tn = (i >= 1) ? stencil_cell(i, n, (i == 1) ? spool : tm1, tc, nx[u], g, cf, ps, tref, alpha, tdiel)
+                                                  : spool;
+                        col[j * 256] = tn;
+                        tmax = fmax_gt(tmax, tn);
+                    }
+                    tm1 = tc;
+                    tc = nx[u];
+                }
+            }
+        }
+#pragma unroll
+        for (int m = 1; m < L; m <<= 1) tmax = fmax_gt(tmax, __shfl_xor(tmax, m));
+        if (!s.done) {
+            scalar_epilogue(k.hot, s, tmax);
+            if (s.ctrl && c == 0) write_obs(k.cold, e, s);
+        }
+    }
+
+    __syncthreads();
+    {
+        const int r = tid / EPB, sel = tid % EPB;
+        int ci = 0, ji = r;
+        while (ji >= C) { ji -= C; ++ci; }
+        const bool ok = e0 + sel < k.num_envs;
+        float* dst = k.cold.s.T + e0 + sel;
+        for (int i0 = 0; i0 < nmax; i0 += L) {
+            const int i = i0 + r;
+            if (i < nmax && ok) dst[(int64_t)i * stride] = lds[ji * 256 + sel * L + ci];
+            ji += L;
+            while (ji >= C) { ji -= C; ++ci; }
+        }
+    }
+    if (live && c == 0) store_env(k.cold.s, e, s);
 }
 
 // In-kernel phase stamps (diagnostic build -DWEDM_STAMPS only; never in the shipped library).
@@ -196,8 +274,6 @@ __global__ void __launch_bounds__(64) wedm_step_lds(const KArgs k) {
 #endif
 
 // ===================================================== fused kernel, L lanes / env
-// np.max over finite temperatures; maps to v_max_f32 / v_max3_f32
-__device__ __forceinline__ float fmax_gt(float a, float b) { return __builtin_fmaxf(a, b); }
 
 // One interior cell (1 <= i <= n-2), float32 op for op as wire.py:91-120 evaluates it.
 // The advection term is always applied: adv == 0 in lanes where the reference skips it
@@ -773,6 +849,7 @@ __global__ void __launch_bounds__(256, 2) wedm_step_packed(const KArgs k) {
     if (live && c == 0) store_env(k.cold.s, e, s);
 }
 
+
 __global__ void __launch_bounds__(256)
 wedm_reset_kernel(const wedm_params p, const wedm_state_ptrs s, int32_t num_envs, int32_t n_seg_max,
                   const uint8_t* mask, uint32_t key_lo, uint32_t key_hi, int32_t reseed) {
@@ -1156,7 +1233,6 @@ int32_t wedm_step(wedm_ctx* ctx, int32_t n_substeps, const wedm_action_ptrs* act
     k.walk = nullptr;
     k.dbg = ctx->dbg;
 
-    const size_t lds_bytes = (size_t)ctx->n_seg_max * 64 * sizeof(float);
     // kernel 3 (one chunk per lane) and kernel 4 (two packed chunks per lane, table of 2L chunks)
     int lanes = ctx->lanes ? ctx->lanes : auto_lanes(ctx);
     const int li = lanes_index(lanes);
@@ -1167,18 +1243,33 @@ int32_t wedm_step(wedm_ctx* ctx, int32_t n_substeps, const wedm_action_ptrs* act
     const int pli = (planes >= 1 && planes <= 8) ? lanes_index(2 * planes) : -1;
     const bool packed_ok = uniform && pli >= 0 && ctx->walk_ok[pli] &&
                            (2 * (size_t)ctx->walk_C[pli] + 2) * 1024 <= (size_t)ctx->lds_limit;
+    // kernel 2 (any geometry): lanes per environment = the caller's choice, else the smallest L whose
+    // chunk fits in LDS, raised until the launch has ~2 waves per SIMD
+    int glanes = 0;
+    {
+        const int Ls[5] = {1, 2, 4, 8, 16};
+        for (int i = 0; i < 5; ++i) {
+            const size_t b = (size_t)((ctx->n_seg_max + Ls[i] - 1) / Ls[i]) * 1024;
+            if (b > (size_t)ctx->lds_limit) continue;
+            if (ctx->lanes) { if (Ls[i] == ctx->lanes) glanes = Ls[i]; continue; }
+            glanes = Ls[i];
+            const long waves = (long)((ctx->num_envs + (256 / Ls[i]) - 1) / (256 / Ls[i])) * 4;
+            if (waves >= 2048) break;
+        }
+    }
+    const bool lanes_ok = glanes > 0;
     int variant = ctx->variant;
     if (variant == 0) {
         if (n_substeps > 1 && packed_ok) variant = 4;
         else if (n_substeps > 1 && fused_ok) variant = 3;
-        else variant = (n_substeps > 1 && lds_bytes <= (size_t)ctx->lds_limit) ? 2 : 1;
+        else variant = (n_substeps > 1 && lanes_ok) ? 2 : 1;
     }
     if (variant == 3 && !fused_ok)
         return fail(ctx, WEDM_ERR_UNSUPPORTED, "wedm_step: fused kernel needs uniform geometry and a chunk that fits in LDS");
     if (variant == 4 && !packed_ok)
         return fail(ctx, WEDM_ERR_UNSUPPORTED, "wedm_step: packed kernel needs uniform geometry, lanes in {1,2,4,8} and two chunks that fit in LDS");
-    if (variant == 2 && lds_bytes > (size_t)ctx->lds_limit)
-        return fail(ctx, WEDM_ERR_UNSUPPORTED, "wedm_step: n_seg_max * 256 B exceeds the LDS a workgroup can take");
+    if (variant == 2 && !lanes_ok)
+        return fail(ctx, WEDM_ERR_UNSUPPORTED, "wedm_step: no lane count puts a chunk of the wire in LDS");
 
     char name[160];
     if (variant == 1) {
@@ -1187,12 +1278,23 @@ int32_t wedm_step(wedm_ctx* ctx, int32_t n_substeps, const wedm_action_ptrs* act
         hipLaunchKernelGGL(wedm_step_global, dim3(grid), dim3(block), 0, (hipStream_t)stream, k);
         std::snprintf(name, sizeof(name), "wedm_step_global<<<%d,%d>>> n_sub=%d", grid, block, n_substeps);
     } else if (variant == 2) {
-        const int grid = (ctx->num_envs + 63) / 64;
-        hipError_t ea = hipFuncSetAttribute((const void*)wedm_step_lds, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                            (int)lds_bytes);
-        if (ea != hipSuccess) return hip_fail(ctx, ea, "hipFuncSetAttribute(wedm_step_lds)");
-        hipLaunchKernelGGL(wedm_step_lds, dim3(grid), dim3(64), lds_bytes, (hipStream_t)stream, k);
-        std::snprintf(name, sizeof(name), "wedm_step_lds<<<%d,64,%zuB>>> n_sub=%d", grid, lds_bytes, n_substeps);
+        const int gl = glanes;
+        const int epb = 256 / gl;
+        const int grid = (ctx->num_envs + epb - 1) / epb;
+        const size_t fl = (size_t)((ctx->n_seg_max + gl - 1) / gl) * 1024;
+        const void* fn = gl == 1 ? (const void*)wedm_step_lanes<1> : gl == 2 ? (const void*)wedm_step_lanes<2>
+                       : gl == 4 ? (const void*)wedm_step_lanes<4> : gl == 8 ? (const void*)wedm_step_lanes<8>
+                                                                             : (const void*)wedm_step_lanes<16>;
+        hipError_t ea = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)fl);
+        if (ea != hipSuccess) return hip_fail(ctx, ea, "hipFuncSetAttribute(wedm_step_lanes)");
+        switch (gl) {
+            case 1: hipLaunchKernelGGL(wedm_step_lanes<1>, dim3(grid), dim3(256), fl, (hipStream_t)stream, k); break;
+            case 2: hipLaunchKernelGGL(wedm_step_lanes<2>, dim3(grid), dim3(256), fl, (hipStream_t)stream, k); break;
+            case 4: hipLaunchKernelGGL(wedm_step_lanes<4>, dim3(grid), dim3(256), fl, (hipStream_t)stream, k); break;
+            case 8: hipLaunchKernelGGL(wedm_step_lanes<8>, dim3(grid), dim3(256), fl, (hipStream_t)stream, k); break;
+            default: hipLaunchKernelGGL(wedm_step_lanes<16>, dim3(grid), dim3(256), fl, (hipStream_t)stream, k); break;
+        }
+        std::snprintf(name, sizeof(name), "wedm_step_lanes<%d><<<%d,256,%zuB>>> n_sub=%d", gl, grid, fl, n_substeps);
     } else if (variant == 4) {
         const int epb = 256 / planes;
         const int grid = (ctx->num_envs + epb - 1) / epb;

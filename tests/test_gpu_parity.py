@@ -51,6 +51,9 @@ def test_native_library_is_the_one_running():
     assert "wedm_step_global" in env._backend.last_kernel()
     env.step_many(env.make_action(), 10)
     assert "wedm_step_packed" in env._backend.last_kernel() or "wedm_step_fused" in env._backend.last_kernel()
+    env.set_kernel(2)
+    env.step_many(env.make_action(), 10)
+    assert "wedm_step_lanes" in env._backend.last_kernel()
 
 
 @pytest.mark.parametrize("kind", [0, 1, 2, 3, 4, 5, 6, 7])
@@ -188,7 +191,8 @@ def test_fused_kernel_with_ragged_chunks_and_heavy_sparking(variant, lanes):
         env.state.wire_unwinding_velocity[::7] = 0.0   # mixed advection inside a wave
         env.step_many(a, 700)
     check(gpu, cpu, n)
-    assert f"{'wedm_step_fused' if variant == 3 else 'wedm_step_packed'}<{lanes}>" in gpu._backend.last_kernel()
+    want = {3: f"wedm_step_fused<{lanes}>", 4: f"wedm_step_packed<{lanes}>"}[variant]
+    assert want in gpu._backend.last_kernel()
     assert bool(gpu.state.is_wire_broken.any()) and not bool(gpu.state.is_wire_broken.all())
 
 
@@ -203,12 +207,14 @@ def test_per_environment_geometry_config5():
     gpu, cpu = make_pair(n, **kw)
     assert gpu.n_segments == cpu.n_segments and 350 <= gpu.n_segments <= 450
     both((gpu, cpu), lambda e: (e.reset(seed=2024), close_gap(e, 24.0, 10.0)))
-    for variant in (1, 2):
-        gpu.set_kernel(variant)
+    for variant, lanes in ((1, 0), (2, 4), (2, 8), (2, 16), (2, 0)):
+        gpu.set_kernel(variant, lanes)
         for env in (gpu, cpu):
             a = env.make_action(0.1, 80.0, mode, 3.0, 40.0)
-            env.step_many(a, 1100)
+            env.step_many(a, 700)
         check(gpu, cpu, n)
+        if variant == 2:
+            assert "wedm_step_lanes" in gpu._backend.last_kernel()
     assert int(gpu.state.spark_count.sum()) > 100
 
 
