@@ -581,61 +581,194 @@ __device__ __forceinline__ f2 interior2(f2 tm1, f2 tc, f2 tp1, float k, float tu
     return tc + d * tuf;
 }
 
-// Eight packed cells (16 wire cells) evaluated STAGE-MAJOR: every stage applies one operation
-// of interior2() to all eight pairs, and a scheduling barrier separates the stages, so dependent
-// packed ops are always >= 8 instructions apart.  Left to itself the scheduler emits the eight
-// chains one after the other (each op waiting on the previous, s_nop in between).  Operation
-// order and rounding are exactly those of interior2().  old[u], old[u+1], old[u+2] are the OLD
-// (tm1, tc, tp1) of pair u.  conv/jfe: one coefficient pair per cell (PERCELL) or per tile.
-#define WEDM_STAGE_FENCE() __builtin_amdgcn_sched_barrier(0)
-template <bool JOULE, bool PERCELL>
-__device__ __forceinline__ void tile8_staged(const f2 (&old)[10], f2 (&tn)[8], float k, float tuf, const f2 (&conv)[8],
-                                             float tdiel, float adv, const f2 (&jfe)[8], float alpha, float tref) {
-    f2 a[8], e[8], f[8], r[8];
+
+typedef __attribute__((address_space(3))) float lds_f32;
+struct PackedWalkArgs {
+    lds_f32* col;
+    const WalkTable* wt;
+    Geom g;
+    Coef cf;
+    Persist ps;
+    float spool, tref, alpha, tdiel;
+    int32_t Cv, n, c, baseA, baseB, n_tiles, own_last, done;
+    uint32_t zlA, zlB, jlA, jlB, zhA, zhB, jhA, jhB, kind_n, kind_s, sp0, sp1, sp2;
+};
+
+// One microsecond of the packed walk as a real function: inside it only walk values are live,
+// so the scheduler can interleave the eight independent cell chains of a tile instead of
+// serialising them under the caller's register pressure (the Env state stays in the caller's
+// callee-saved registers).  LDS pointers are passed in address space 3 to keep ds_* accesses.
+template <int L>
+__attribute__((noinline)) __device__ float packed_walk(const PackedWalkArgs w) {
+    lds_f32* col = w.col;
+    const WalkTable* __restrict__ wt = w.wt;
+    const Geom g = w.g;
+    const Coef cf = w.cf;
+    const Persist ps = w.ps;
+    const float spool = w.spool, tref = w.tref, alpha = w.alpha, tdiel = w.tdiel;
+    const int Cv = w.Cv, n = w.n, c = w.c, baseA = w.baseA, baseB = w.baseB, n_tiles = w.n_tiles;
+    const int R = 2 * Cv;
+    const int own_last = w.own_last;
+    const uint32_t zlA = w.zlA, zlB = w.zlB, jlA = w.jlA, jlB = w.jlB, zhA = w.zhA, zhB = w.zhB, jhA = w.jhA, jhB = w.jhB;
+    const uint32_t kind_n = w.kind_n, kind_s = w.kind_s;
+    const uint32_t split_pack[3] = {w.sp0, w.sp1, w.sp2};
+    auto owner = [&](int i) -> int {
+        if (i >= baseA && i < baseA + Cv) return 1;
+        if (i >= baseB && i < baseB + Cv) return 2;
+        return 0;
+    };
+        // ---- halos (OLD values, read before any store of this step)
+        const float halo_l = (c > 0) ? col[(R - 1) * 256 - 1] : spool;  // left neighbour lane's B[Cv-1]
+        const float halo_r = (c < L - 1) ? col[1] : 0.0f;               // right neighbour lane's A[0]
+        const float a_last = col[(R - 2) * 256];                        // own A[Cv-1]: left halo of B
+        const float b_first = col[256];                                 // own B[0]: right halo of A
+        col[R * 256] = b_first;
+        col[(R + 1) * 256] = halo_r;
+
+        const bool all_slow = __any(cf.q < 0.0f) || __any(w.done);
+        const uint32_t slow_now = all_slow ? 0xffffffffu : kind_s;
+
+        // full predicated formula for one owned cell, from OLD values (patched cells)
+        auto patch_value = [&](int i, int own) -> float {
+            const int v = own - 1, r = i - (v ? baseB : baseA), row = 2 * r + v;
+            float tm = r > 0 ? col[(row - 2) * 256] : (v ? a_last : halo_l);
+            if (i == 1) tm = spool;
+            const float tp = r < Cv - 1 ? col[(row + 2) * 256] : (v ? halo_r : b_first);
+            return stencil_cell(i, n, tm, col[row * 256], tp, g, cf, ps, tref, alpha, tdiel);
+        };
+        const int own_pl = (!w.done && cf.pidx >= 1) ? owner(cf.pidx) : 0;
+        float tpl = 0.0f, tlast = 0.0f;
+        if (__any(own_pl != 0)) {
+            if (own_pl) tpl = patch_value(cf.pidx, own_pl);
+        }
+        if (own_last && !w.done) tlast = patch_value(n - 1, own_last);
+
+        float tmax = spool;
+        f2 tm1 = {halo_l, a_last};
+        f2 tc = {col[0], col[256]};
+        {
+            const float jf_lane = (cf.joule_on && !w.done) ? cf.jf : 0.0f;
+            const bool joule_wave = __any(jf_lane != 0.0f);
+            const float cz = ps.conv_zone, cb = ps.conv_base;
+
+            auto load8 = [&](f2 (&dst)[8], int r0) {  // dst[u] = OLD (A[r0+1+u], B[r0+1+u])
 #pragma unroll
-    for (int u = 0; u < 8; ++u) {
-        a[u] = old[u + 1] + old[u + 1];  // 2*T[i]
-        e[u] = old[u + 1] - tdiel;       // T[i] - T_dielectric
-        f[u] = old[u] - old[u + 1];      // T[i-1] - T[i]
-        if (JOULE) r[u] = old[u + 1] - tref;
-    }
-    WEDM_STAGE_FENCE();
+                for (int u = 0; u < 8; ++u) {
+                    int p = r0 + 1 + u;
+                    p = p < Cv ? p : Cv;  // pair Cv is the halo pair; later pairs are never used
+                    dst[u].x = col[(2 * p) * 256];
+                    dst[u].y = col[(2 * p + 1) * 256];
+                }
+            };
+            auto store2 = [&](int r, f2 v) {
+                col[(2 * r) * 256] = v.x;
+                col[(2 * r + 1) * 256] = v.y;
+            };
+            auto tile = [&](int t, f2 (&cur)[8], f2 (&nxt)[8]) {
+                const int r0 = 8 * t;
+                if (t + 1 < n_tiles) load8(nxt, r0 + 8);
+                const f2 conv_lo = {((zlA >> t) & 1u) ? cz : cb, ((zlB >> t) & 1u) ? cz : cb};
+                const f2 jfe_lo = {((jlA >> t) & 1u) ? jf_lane : 0.0f, ((jlB >> t) & 1u) ? jf_lane : 0.0f};
+                if (((kind_n & ~slow_now) >> t) & 1u) {
+                    if (joule_wave && __any(jfe_lo.x != 0.0f || jfe_lo.y != 0.0f)) {
 #pragma unroll
-    for (int u = 0; u < 8; ++u) {
-        a[u] = old[u] - a[u];
-        e[u] = (PERCELL ? conv[u] : conv[0]) * e[u];
-        f[u] = adv * f[u];
-        if (JOULE) r[u] = alpha * r[u];
-    }
-    WEDM_STAGE_FENCE();
+                        for (int u = 0; u < 8; ++u) {
+                            f2 tn = interior2<true>(tm1, tc, cur[u], g.k, g.tuf, conv_lo, tdiel, ps.adv, jfe_lo, alpha, tref);
+                            store2(r0 + u, tn);
+                            tmax = fmax_gt(tmax, fmax_gt(tn.x, tn.y));
+                            tm1 = tc;
+                            tc = cur[u];
+                        }
+                    } else {
 #pragma unroll
-    for (int u = 0; u < 8; ++u) {
-        a[u] = a[u] + old[u + 2];
-        if (JOULE) r[u] = 1.0f + r[u];
-    }
-    WEDM_STAGE_FENCE();
+                        for (int u = 0; u < 8; ++u) {
+                            f2 tn = interior2<false>(tm1, tc, cur[u], g.k, g.tuf, conv_lo, tdiel, ps.adv, jfe_lo, alpha, tref);
+                            store2(r0 + u, tn);
+                            tmax = fmax_gt(tmax, fmax_gt(tn.x, tn.y));
+                            tm1 = tc;
+                            tc = cur[u];
+                        }
+                    }
+                } else if (!((slow_now >> t) & 1u)) {
+                    // TILE_B: interior formula everywhere, one flag change at `split`; boundary and
+                    // out-of-wire cells stay out of the max (patched afterwards / never read)
+                    const int split = (int)((split_pack[t >> 3] >> ((t & 7) * 4)) & 15u);
+                    const int cnt = (Cv - r0) < 8 ? (Cv - r0) : 8;
+                    const f2 conv_hi = {((zhA >> t) & 1u) ? cz : cb, ((zhB >> t) & 1u) ? cz : cb};
+                    const f2 jfe_hi = {((jhA >> t) & 1u) ? jf_lane : 0.0f, ((jhB >> t) & 1u) ? jf_lane : 0.0f};
+                    const uint32_t imA = (uint32_t)(baseA + r0 - 1), imB = (uint32_t)(baseB + r0 - 1);
+                    const uint32_t span = (uint32_t)(n - 3);
 #pragma unroll
-    for (int u = 0; u < 8; ++u) {
-        a[u] = k * a[u];
-        if (JOULE) r[u] = (PERCELL ? jfe[u] : jfe[0]) * r[u];
-    }
-    WEDM_STAGE_FENCE();
-    if (JOULE) {
+                    for (int u = 0; u < 8; ++u) {
+                        if (u < cnt) {
+                            const f2 conv = u < split ? conv_lo : conv_hi;
+                            const f2 jfe = u < split ? jfe_lo : jfe_hi;
+                            f2 tn = interior2<true>(tm1, tc, cur[u], g.k, g.tuf, conv, tdiel, ps.adv, jfe, alpha, tref);
+                            store2(r0 + u, tn);
+                            const bool inA = (n >= 3) && (imA + (uint32_t)u <= span);
+                            const bool inB = (n >= 3) && (imB + (uint32_t)u <= span);
+                            tmax = inA ? fmax_gt(tmax, tn.x) : tmax;
+                            tmax = inB ? fmax_gt(tmax, tn.y) : tmax;
+                            tm1 = tc;
+                            tc = cur[u];
+                        }
+                    }
+                } else {
+                    // TILE_S: per-cell predicated fallback for both components (rare)
+#pragma unroll 1
+                    for (int u = 0; u < 8; ++u) {
+                        const int r = r0 + u;
+                        const uint32_t zj = wt->zj[r], iv = wt->iv[r];
+                        const f2 tp1 = cur[0];
+                        f2 tn;
 #pragma unroll
-        for (int u = 0; u < 8; ++u) a[u] = a[u] + r[u];
-        WEDM_STAGE_FENCE();
-    }
+                        for (int v = 0; v < 2; ++v) {
+                            const int vcid = 2 * c + v;
+                            const bool zbit = (zj >> vcid) & 1u, jbit = (zj >> (16 + vcid)) & 1u;
+                            const bool inter = ((iv >> vcid) & 1u) && !all_slow;
+                            const bool valid = ((iv >> (16 + vcid)) & 1u) && !w.done;
+                            const float conv = zbit ? cz : cb, jfe = jbit ? jf_lane : 0.0f;
+                            const float m = v ? tm1.y : tm1.x, cc = v ? tc.y : tc.x, pp = v ? tp1.y : tp1.x;
+                            float x = interior_cell<true>(m, cc, pp, g.k, g.tuf, conv, tdiel, ps.adv, jfe, alpha, tref);
+                            if (!inter && valid) {
+                                const int i = (v ? baseB : baseA) + r;
+                                x = (i >= 1) ? stencil_cell(i, n, (i == 1) ? spool : m, cc, pp, g, cf, ps, tref, alpha, tdiel) : spool;
+                            }
+                            if (valid) {
+                                col[(2 * r + v) * 256] = x;
+                                tmax = fmax_gt(tmax, x);
+                            }
+                            if (v) tn.y = x; else tn.x = x;
+                        }
+                        tm1 = tc;
+                        tc = tp1;
+                        f2 first = cur[0];
 #pragma unroll
-    for (int u = 0; u < 8; ++u) a[u] = a[u] - e[u];
-    WEDM_STAGE_FENCE();
-#pragma unroll
-    for (int u = 0; u < 8; ++u) a[u] = a[u] + f[u];
-    WEDM_STAGE_FENCE();
-#pragma unroll
-    for (int u = 0; u < 8; ++u) a[u] = a[u] * tuf;
-    WEDM_STAGE_FENCE();
-#pragma unroll
-    for (int u = 0; u < 8; ++u) tn[u] = old[u + 1] + a[u];
+                        for (int q = 0; q < 7; ++q) cur[q] = cur[q + 1];
+                        cur[7] = first;
+                    }
+                }
+            };
+            f2 bufA[8], bufB[8];
+            load8(bufA, 0);
+            for (int t = 0; t < n_tiles; t += 2) {
+                tile(t, bufA, bufB);
+                if (t + 1 < n_tiles) tile(t + 1, bufB, bufA);
+            }
+        }
+        // ---- patches (after every store of the walk): boundary condition, last cell, plasma cell
+        if (c == 0 && !w.done) col[0] = spool;
+        if (own_last && !w.done) {
+            const int v = own_last - 1;
+            col[(2 * (n - 1 - (v ? baseB : baseA)) + v) * 256] = tlast;
+            tmax = fmax_gt(tmax, tlast);
+        }
+        if (own_pl) {
+            const int v = own_pl - 1;
+            col[(2 * (cf.pidx - (v ? baseB : baseA)) + v) * 256] = tpl;
+            tmax = fmax_gt(tmax, tpl);
+        }
+        return tmax;
 }
 
 template <int L>
@@ -720,173 +853,15 @@ __global__ void __launch_bounds__(256, 2) wedm_step_packed(const KArgs k) {
         if (!s.done) cf = scalar_prelude(k.hot, k.cold, g, e, gid, s, ps);
         WEDM_STAMP(st1);
 
-        // ---- halos (OLD values, read before any store of this step)
-        const float halo_l = (c > 0) ? col[(R - 1) * 256 - 1] : spool;  // left neighbour lane's B[Cv-1]
-        const float halo_r = (c < L - 1) ? col[1] : 0.0f;               // right neighbour lane's A[0]
-        const float a_last = col[(R - 2) * 256];                        // own A[Cv-1]: left halo of B
-        const float b_first = col[256];                                 // own B[0]: right halo of A
-        col[R * 256] = b_first;
-        col[(R + 1) * 256] = halo_r;
-
-        const bool all_slow = __any(cf.q < 0.0f) || __any(s.done);
-        const uint32_t slow_now = all_slow ? 0xffffffffu : kind_s;
-
-        // full predicated formula for one owned cell, from OLD values (patched cells)
-        auto patch_value = [&](int i, int own) -> float {
-            const int v = own - 1, r = i - (v ? baseB : baseA), row = 2 * r + v;
-            float tm = r > 0 ? col[(row - 2) * 256] : (v ? a_last : halo_l);
-            if (i == 1) tm = spool;
-            const float tp = r < Cv - 1 ? col[(row + 2) * 256] : (v ? halo_r : b_first);
-            return stencil_cell(i, n, tm, col[row * 256], tp, g, cf, ps, tref, alpha, tdiel);
-        };
-        const int own_pl = (!s.done && cf.pidx >= 1) ? owner(cf.pidx) : 0;
-        float tpl = 0.0f, tlast = 0.0f;
-        if (__any(own_pl != 0)) {
-            if (own_pl) tpl = patch_value(cf.pidx, own_pl);
-        }
-        if (own_last && !s.done) tlast = patch_value(n - 1, own_last);
-
-        float tmax = spool;
-        f2 tm1 = {halo_l, a_last};
-        f2 tc = {col[0], col[256]};
-#ifdef WEDM_ABL_NO_STENCIL
-        asm volatile("" ::"v"(cf.jf), "v"(cf.q), "v"(cf.pidx), "v"(ps.conv_base), "v"(ps.conv_zone), "v"(tpl), "v"(tlast));
-        if (false) {
-#else
-        {
-#endif
-            const float jf_lane = (cf.joule_on && !s.done) ? cf.jf : 0.0f;
-            const bool joule_wave = __any(jf_lane != 0.0f);
-            const float cz = ps.conv_zone, cb = ps.conv_base;
-
-            auto load8 = [&](f2 (&dst)[8], int r0) {  // dst[u] = OLD (A[r0+1+u], B[r0+1+u])
-#pragma unroll
-                for (int u = 0; u < 8; ++u) {
-                    int p = r0 + 1 + u;
-                    p = p < Cv ? p : Cv;  // pair Cv is the halo pair; later pairs are never used
-                    dst[u].x = col[(2 * p) * 256];
-                    dst[u].y = col[(2 * p + 1) * 256];
-                }
-            };
-            auto store2 = [&](int r, f2 v) {
-                col[(2 * r) * 256] = v.x;
-                col[(2 * r + 1) * 256] = v.y;
-            };
-            auto tile = [&](int t, f2 (&cur)[8], f2 (&nxt)[8]) {
-                const int r0 = 8 * t;
-                if (t + 1 < n_tiles) load8(nxt, r0 + 8);
-                const f2 conv_lo = {((zlA >> t) & 1u) ? cz : cb, ((zlB >> t) & 1u) ? cz : cb};
-                const f2 jfe_lo = {((jlA >> t) & 1u) ? jf_lane : 0.0f, ((jlB >> t) & 1u) ? jf_lane : 0.0f};
-                if (((kind_n & ~slow_now) >> t) & 1u) {
-                    f2 old[10], tn[8], cv[8], jv[8];
-                    old[0] = tm1; old[1] = tc;
-#pragma unroll
-                    for (int u = 0; u < 8; ++u) old[u + 2] = cur[u];
-                    cv[0] = conv_lo; jv[0] = jfe_lo;
-                    if (joule_wave && __any(jfe_lo.x != 0.0f || jfe_lo.y != 0.0f))
-                        tile8_staged<true, false>(old, tn, g.k, g.tuf, cv, tdiel, ps.adv, jv, alpha, tref);
-                    else
-                        tile8_staged<false, false>(old, tn, g.k, g.tuf, cv, tdiel, ps.adv, jv, alpha, tref);
-                    float m0 = fmax_gt(tn[0].x, tn[0].y), m1 = fmax_gt(tn[1].x, tn[1].y);
-#pragma unroll
-                    for (int u = 0; u < 8; ++u) store2(r0 + u, tn[u]);
-#pragma unroll
-                    for (int u = 2; u < 8; u += 2) {
-                        m0 = fmax_gt(m0, fmax_gt(tn[u].x, tn[u].y));
-                        m1 = fmax_gt(m1, fmax_gt(tn[u + 1].x, tn[u + 1].y));
-                    }
-                    tmax = fmax_gt(tmax, fmax_gt(m0, m1));
-                    tm1 = cur[6];
-                    tc = cur[7];
-                } else if (!((slow_now >> t) & 1u)) {
-                    // TILE_B: interior formula everywhere, one flag change at `split`; boundary and
-                    // out-of-wire cells stay out of the max (patched afterwards / never read)
-                    const int split = (int)((split_pack[t >> 3] >> ((t & 7) * 4)) & 15u);
-                    const int cnt = (Cv - r0) < 8 ? (Cv - r0) : 8;
-                    const f2 conv_hi = {((zhA >> t) & 1u) ? cz : cb, ((zhB >> t) & 1u) ? cz : cb};
-                    const f2 jfe_hi = {((jhA >> t) & 1u) ? jf_lane : 0.0f, ((jhB >> t) & 1u) ? jf_lane : 0.0f};
-                    const uint32_t imA = (uint32_t)(baseA + r0 - 1), imB = (uint32_t)(baseB + r0 - 1);
-                    const uint32_t span = (uint32_t)(n - 3);
-                    f2 old[10], tn[8], cv[8], jv[8];
-                    old[0] = tm1; old[1] = tc;
-#pragma unroll
-                    for (int u = 0; u < 8; ++u) {
-                        old[u + 2] = cur[u];
-                        cv[u] = u < split ? conv_lo : conv_hi;
-                        jv[u] = u < split ? jfe_lo : jfe_hi;
-                    }
-                    if (joule_wave) tile8_staged<true, true>(old, tn, g.k, g.tuf, cv, tdiel, ps.adv, jv, alpha, tref);
-                    else tile8_staged<false, true>(old, tn, g.k, g.tuf, cv, tdiel, ps.adv, jv, alpha, tref);
-#pragma unroll
-                    for (int u = 0; u < 8; ++u) {
-                        if (u < cnt) {
-                            store2(r0 + u, tn[u]);
-                            const bool inA = (n >= 3) && (imA + (uint32_t)u <= span);
-                            const bool inB = (n >= 3) && (imB + (uint32_t)u <= span);
-                            tmax = inA ? fmax_gt(tmax, tn[u].x) : tmax;
-                            tmax = inB ? fmax_gt(tmax, tn[u].y) : tmax;
-                        }
-                    }
-                    // window after the tile: the last REAL pair of the chunk is what the next tile
-                    // (if any) needs; a short tile is always the last one, so only full tiles matter
-                    tm1 = cur[6];
-                    tc = cur[7];
-                } else {
-                    // TILE_S: per-cell predicated fallback for both components (rare)
-#pragma unroll 1
-                    for (int u = 0; u < 8; ++u) {
-                        const int r = r0 + u;
-                        const uint32_t zj = wt->zj[r], iv = wt->iv[r];
-                        const f2 tp1 = cur[0];
-                        f2 tn;
-#pragma unroll
-                        for (int v = 0; v < 2; ++v) {
-                            const int vcid = 2 * c + v;
-                            const bool zbit = (zj >> vcid) & 1u, jbit = (zj >> (16 + vcid)) & 1u;
-                            const bool inter = ((iv >> vcid) & 1u) && !all_slow;
-                            const bool valid = ((iv >> (16 + vcid)) & 1u) && !s.done;
-                            const float conv = zbit ? cz : cb, jfe = jbit ? jf_lane : 0.0f;
-                            const float m = v ? tm1.y : tm1.x, cc = v ? tc.y : tc.x, pp = v ? tp1.y : tp1.x;
-                            float x = interior_cell<true>(m, cc, pp, g.k, g.tuf, conv, tdiel, ps.adv, jfe, alpha, tref);
-                            if (!inter && valid) {
-                                const int i = (v ? baseB : baseA) + r;
-                                x = (i >= 1) ? stencil_cell(i, n, (i == 1) ? spool : m, cc, pp, g, cf, ps, tref, alpha, tdiel) : spool;
-                            }
-                            if (valid) {
-                                col[(2 * r + v) * 256] = x;
-                                tmax = fmax_gt(tmax, x);
-                            }
-                            if (v) tn.y = x; else tn.x = x;
-                        }
-                        tm1 = tc;
-                        tc = tp1;
-                        f2 first = cur[0];
-#pragma unroll
-                        for (int q = 0; q < 7; ++q) cur[q] = cur[q + 1];
-                        cur[7] = first;
-                    }
-                }
-            };
-            f2 bufA[8], bufB[8];
-            load8(bufA, 0);
-            for (int t = 0; t < n_tiles; t += 2) {
-                tile(t, bufA, bufB);
-                if (t + 1 < n_tiles) tile(t + 1, bufB, bufA);
-            }
-        }
+        PackedWalkArgs wa;
+        wa.col = (lds_f32*)col; wa.wt = wt; wa.g = g; wa.cf = cf; wa.ps = ps;
+        wa.spool = spool; wa.tref = tref; wa.alpha = alpha; wa.tdiel = tdiel;
+        wa.Cv = Cv; wa.n = n; wa.c = c; wa.baseA = baseA; wa.baseB = baseB; wa.n_tiles = n_tiles;
+        wa.own_last = own_last; wa.done = s.done;
+        wa.zlA = zlA; wa.zlB = zlB; wa.jlA = jlA; wa.jlB = jlB; wa.zhA = zhA; wa.zhB = zhB; wa.jhA = jhA; wa.jhB = jhB;
+        wa.kind_n = kind_n; wa.kind_s = kind_s; wa.sp0 = split_pack[0]; wa.sp1 = split_pack[1]; wa.sp2 = split_pack[2];
+        float tmax = packed_walk<L>(wa);
         WEDM_STAMP(st2);
-        // ---- patches (after every store of the walk): boundary condition, last cell, plasma cell
-        if (c == 0 && !s.done) col[0] = spool;
-        if (own_last && !s.done) {
-            const int v = own_last - 1;
-            col[(2 * (n - 1 - (v ? baseB : baseA)) + v) * 256] = tlast;
-            tmax = fmax_gt(tmax, tlast);
-        }
-        if (own_pl) {
-            const int v = own_pl - 1;
-            col[(2 * (cf.pidx - (v ? baseB : baseA)) + v) * 256] = tpl;
-            tmax = fmax_gt(tmax, tpl);
-        }
 #pragma unroll
         for (int m = 1; m < L; m <<= 1) tmax = fmax_gt(tmax, __shfl_xor(tmax, m));
         WEDM_STAMP(st3);
