@@ -138,7 +138,9 @@ def main():
         raise SystemExit("--gpus N > 1 must be launched with torch.distributed.run (one rank per GPU)")
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
-    if world > 1:
+    # WEDM_BENCH_FORCE_DIST=1 exercises the RCCL code path even with one rank (rehearsal on a 1-GPU box)
+    use_dist = world > 1 or os.environ.get("WEDM_BENCH_FORCE_DIST") == "1"
+    if use_dist:
         dist.init_process_group("nccl", device_id=device)
 
     n_local, wire, wl_name = workload(args)
@@ -159,11 +161,11 @@ def main():
     S = env.n_segments
     obs_local = env.state.obs[:, :n_local]
     gathered = (torch.empty((world * obs_local.shape[0], obs_local.shape[1]), dtype=obs_local.dtype, device=device)
-                if world > 1 else None)
+                if use_dist else None)
 
     def one_step():
         env.step_many(act, n_sub)
-        if world > 1:  # observations of every shard, once per control step, over xGMI
+        if use_dist:  # observations of every shard, once per control step, over xGMI
             dist.all_gather_into_tensor(gathered, obs_local.contiguous())
 
     for _ in range(args.warmup):
@@ -172,7 +174,7 @@ def main():
     # ---- timed region: exactly K steps between barrier + synchronize
     starts = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps)]
     ends = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps)]
-    if world > 1:
+    if use_dist:
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
@@ -180,13 +182,13 @@ def main():
         starts[i].record()          # torch's current stream == the stream wedm_step launches on
         env.step_many(act, n_sub)
         ends[i].record()
-        if world > 1:
+        if use_dist:
             dist.all_gather_into_tensor(gathered, obs_local.contiguous())
     torch.cuda.synchronize()
-    if world > 1:
+    if use_dist:
         dist.barrier()
     elapsed = time.perf_counter() - t0
-    if world > 1:
+    if use_dist:
         tmax = torch.tensor([elapsed], dtype=torch.float64, device=device)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         elapsed = float(tmax.item())
@@ -227,7 +229,9 @@ def main():
                 "1 209 env-steps/s, 1 core: the Python reference itself (Numba stubbed), measured in the build "
                 "container (BASELINE.md); it cannot travel to the GPU box")
         print(json.dumps(out))
-    if world > 1:
+    if use_dist:
+        if rank == 0 and gathered is not None:  # the gathered block really is the local observations
+            assert torch.equal(gathered[: obs_local.shape[0]], obs_local), "all-gather returned wrong data"
         dist.destroy_process_group()
 
 

@@ -23,13 +23,18 @@ from .modules.parameters import (
     WireModuleParameters,
 )
 
+from .controllers import GapController, run_controlled
+from .utils.logger import LoggerConfig, SimulationLogger
+from .vector import WireEDMVectorEnv
+
 EDMState = BatchedEDMState  # the reference's name for the state object
 
 __version__ = "0.1.0"
 
 __all__ = [
     "EDMState", "BatchedEDMState", "EnvironmentConfig", "MaterialDatabase", "WireMaterial", "get_material_db",
-    "WireEDMEnv", "DeviceAction",
+    "WireEDMEnv", "DeviceAction", "WireEDMVectorEnv", "GapController", "run_controlled",
+    "SimulationLogger", "LoggerConfig",
     "IgnitionModuleParameters", "WireModuleParameters", "MaterialModuleParameters",
     "DielectricModuleParameters", "MechanicsModuleParameters",
 ]

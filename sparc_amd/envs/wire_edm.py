@@ -320,6 +320,24 @@ class WireEDMEnv:
             return T[lo:hi].mean(dim=0)
         return T[: g.n_seg].mean(dim=0)
 
+    # ---- statistics the reference's modules expose -------------------------
+    def get_short_circuit_status(self) -> Dict[str, torch.Tensor]:
+        """`IgnitionModule.get_short_circuit_status` (ignition.py:386-399), per environment."""
+        r, d = self.state.random_short_remaining, self.state.debris_short_remaining
+        return {"has_random_short": r > 0, "random_short_remaining_us": r, "has_debris_short": d > 0,
+                "debris_short_remaining_us": d, "total_short_remaining_us": torch.maximum(r, d)}
+
+    def get_debris_statistics(self) -> Dict[str, torch.Tensor]:
+        """`DielectricModule.get_debris_statistics` (dielectric.py:174-182), per environment."""
+        st = self.state
+        return {"debris_volume_mm3": st.debris_volume, "debris_density": st.debris_density,
+                "cavity_volume_mm3": st.cavity_volume, "flow_condition": st.flow_rate,
+                "debris_fill_percentage": st.debris_density * 100.0}
+
+    def get_crater_count(self) -> torch.Tensor:
+        """`len(MaterialRemovalModule.crater_volumes_um3)` (material.py:133), per environment."""
+        return self.state.spark_count
+
     @property
     def workpiece_height(self) -> float:
         return self.config.workpiece_height

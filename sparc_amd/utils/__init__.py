@@ -1,0 +1,3 @@
+from .logger import LoggerConfig, SimulationLogger
+
+__all__ = ["SimulationLogger", "LoggerConfig"]

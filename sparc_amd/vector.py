@@ -1,0 +1,60 @@
+"""Gymnasium-VectorEnv-style adapter with automatic reset.
+
+The reference leaves observation and reward as TODOs (`envs/wire_edm.py:100-101,181-187`) and
+has no vector API; this adapter gives RL code the usual contract on top of the batched
+environment: `step()` advances one control interval (one fused launch), returns
+`(obs, reward, terminated, truncated, info)` with a leading batch dimension, and environments
+that terminated are reset at the start of the next `step()` ("next-step" autoreset), each with a
+fresh Philox episode stream.
+"""
+from __future__ import annotations
+
+from typing import Any, Dict, Optional
+
+import torch
+
+from . import _abi
+from .envs.wire_edm import WireEDMEnv
+
+
+class WireEDMVectorEnv:
+    def __init__(self, env: WireEDMEnv, *, max_episode_steps: Optional[int] = None, autoreset: bool = True):
+        self.env = env
+        self.num_envs = env.num_envs
+        self.single_action_space = env.single_action_space
+        self.single_observation_space = env.single_observation_space
+        self.action_space = env.action_space
+        self.observation_space = env.observation_space
+        self.autoreset = bool(autoreset)
+        self.max_episode_steps = max_episode_steps
+        self._need_reset = torch.zeros(self.num_envs, dtype=torch.bool, device=env.device)
+        self.episode_count = torch.zeros(self.num_envs, dtype=torch.int64, device=env.device)
+
+    def reset(self, *, seed: Optional[int] = None, options: Optional[Dict[str, Any]] = None):
+        obs, info = self.env.reset(seed=seed, options=options)
+        self._need_reset.zero_()
+        return obs.clone(), info
+
+    def step(self, action):
+        """One control interval for every environment (1000 us by default)."""
+        if self.autoreset and bool(self._need_reset.any().item()):
+            self.env.reset(options={"mask": self._need_reset})  # same key, next episode stream
+            self.episode_count += self._need_reset.to(torch.int64)
+            self._need_reset.zero_()
+        obs, reward, terminated, truncated, info = self.env.step_control(action)
+        terminated = terminated.clone()
+        if self.max_episode_steps is not None:
+            truncated = (self.env.state.time >= self.max_episode_steps) & ~terminated
+        else:
+            truncated = truncated.clone()
+        self._need_reset = terminated | truncated
+        info = dict(info)
+        info["episode"] = self.episode_count
+        return obs.clone(), reward, terminated, truncated, info
+
+    def close(self) -> None:
+        self.env.close()
+
+    @property
+    def obs_names(self):
+        return _abi.OBS_NAMES

@@ -395,3 +395,62 @@ def test_full_size_fusion_and_sharding_invariance():
     upper = {k: v[:, n // 2: n] for k, v in A.items()}
     assert_blocks_equal(H, upper, n // 2)
     assert int(a_env.state.spark_count.sum()) > 10000
+
+
+def test_gap_controller_driver_on_gpu_matches_reference_fixture(golden_dir):
+    """§8f-3: the reference's run_simulation.py driver with the gap controller evaluated ON the
+    GPU (no host round trip for the action), one microsecond per launch, against the reference's
+    own recording: discrete state and positions exact, the rest within the stated tolerance."""
+    from sparc_amd import GapController
+    from tests._fixture_env import check_step
+    from tests._golden import Fixture
+
+    fxs = {i: Fixture(golden_dir / f"f7_gap_controller_philox_env{i}.npz") for i in (0, 9)}
+    env = WireEDMEnv(num_envs=64, device="cuda:0")
+    env.reset(seed=77)
+    close_gap(env, 70.0, 10.0, 5000.0)
+    ctl = GapController()
+    action = ctl(env)
+    steps = 5200
+    sampled = set(range(0, steps, 37)) | set(range(990, 1010)) | set(range(4990, 5010))
+    for step in range(steps):
+        env.step(action)
+        latch = (step + 1) % 1000 == 1 and step > 0   # calls 1001, 2001, ... (host-side schedule)
+        if step in sampled or latch:
+            for i, fx in fxs.items():
+                check_step(env, fx, i, step, exact_floats=False)
+        if latch:
+            assert bool(env.state.control_step.all())
+            action = ctl(env)
+
+
+def test_run_controlled_on_gpu_matches_oracle():
+    """Fused control-interval launches + on-device controller: GPU == oracle, bit for bit."""
+    from sparc_amd import GapController, run_controlled
+
+    n = 256
+    gpu, cpu = make_pair(n)
+    for env in (gpu, cpu):
+        env.reset(seed=123)
+        close_gap(env, 40.0, 10.0, 5000.0)
+        assert run_controlled(env, GapController(desired_gap=8.0, current_mode=9), 6500) == 6500
+    check(gpu, cpu, n)
+    assert int(gpu.state.spark_count.sum()) > 100
+    assert "wedm_step_packed" in gpu._backend.last_kernel()
+
+
+def test_vector_env_autoreset_on_gpu():
+    from sparc_amd import WireEDMVectorEnv
+
+    env = WireEDMEnv(num_envs=128, device="cuda:0")
+    vec = WireEDMVectorEnv(env)
+    vec.reset(seed=3)
+    close_gap(env, 25.0, 10.0, 5000.0)
+    env.state.target_position[:64] = 25.0005
+    act = env.make_action()
+    seen = torch.zeros(128, dtype=torch.bool, device="cuda")
+    for _ in range(4):
+        _, _, term, trunc, _ = vec.step(act)
+        seen |= term
+    assert seen[:64].all() and not seen[64:].any()
+    assert (vec.episode_count[:64] >= 1).all() and (env.state.time[64:] == 4000).all()

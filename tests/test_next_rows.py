@@ -1,0 +1,136 @@
+"""SURVEY.md §8f rows built on top of the path: on-device controller + driver loop, the
+vector/auto-reset adapter, the signal logger and the module statistics.  CPU tests use the
+oracle test seam in LIBM math mode, which is bit-identical to the reference."""
+from __future__ import annotations
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import oracle as orc
+from sparc_amd import (GapController, SimulationLogger, WireEDMEnv, WireEDMVectorEnv, run_controlled)
+from tests._fixture_env import check_step
+from tests._golden import Fixture
+from tests._oracle_backend import OracleBackend
+
+
+class LibmOracleBackend(OracleBackend):
+    math_mode = orc.MATH_LIBM  # glibc pow/exp like the reference -> bit-exact against its fixtures
+
+
+def driver_env(n, seed, mode="position", backend=LibmOracleBackend, device="cpu"):
+    env = WireEDMEnv(num_envs=n, device=device, backend=backend, mechanics_control_mode=mode)
+    env.reset(seed=seed)
+    env.state.workpiece_position = 70.0   # experiments/run_simulation.py:199-201
+    env.state.wire_position = 10.0
+    env.state.target_position = 5000.0
+    return env
+
+
+@pytest.mark.parametrize("name,seed,mode,env_ids,n", [
+    ("f7_gap_controller_philox_env%d", 77, "position", (0, 9), 16),
+    ("f7_gap_controller_velocity_philox_env%d", 78, "velocity", (3,), 8),
+])
+def test_gap_controller_reproduces_the_reference_driver(golden_dir, name, seed, mode, env_ids, n):
+    """run_simulation.py's loop (controller recomputed after every control step) with the
+    on-device GapController, one microsecond per call: every recorded quantity of the reference
+    is reproduced exactly."""
+    fxs = {i: Fixture(golden_dir / ((name % i) + ".npz")) for i in env_ids}
+    env = driver_env(n, seed, mode)
+    ctl = GapController()
+    action = ctl(env)
+    steps = min(f.n_steps for f in fxs.values())
+    for step in range(steps):
+        env.step(action)
+        for i, fx in fxs.items():
+            check_step(env, fx, i, step, exact_floats=True)
+        if bool(env.state.control_step[0]):
+            action = ctl(env)
+            for i, fx in fxs.items():  # the action the reference computed at this control step
+                row = fx.actions[fx.action_idx[min(step + 1, steps - 1)]]
+                assert float(action.servo[i]) == row[0] and int(action.current_mode[i]) == int(row[4])
+    for i, fx in fxs.items():
+        assert np.array_equal(env.state.wire_temperature[i].numpy(), fx.T_snaps[-1]) or steps < fx.n_steps
+
+
+def test_run_controlled_fused_launches_equal_per_microsecond_driver():
+    a, b = driver_env(8, 5), driver_env(8, 5)
+    ctl_a, ctl_b = GapController(), GapController()
+    calls = []
+    n = run_controlled(a, ctl_a, 4300, on_control_step=lambda env, t: calls.append(t))
+    assert n == 4300 and calls == [1001, 2001, 3001, 4001]
+    action = ctl_b(b)
+    for _ in range(4300):
+        b.step(action)
+        if bool(b.state.control_step[0]):
+            action = ctl_b(b)
+    A, B = a.state.clone_blocks(), b.state.clone_blocks()
+    for k in ("i32", "i8", "T", "obs"):
+        assert torch.equal(A[k], B[k]), k
+    assert bool(((A["f64"] == B["f64"]) | (A["f64"].isnan() & B["f64"].isnan())).all())
+
+
+def test_vector_env_autoreset():
+    env = WireEDMEnv(num_envs=6, device="cpu", backend=OracleBackend)
+    vec = WireEDMVectorEnv(env)
+    obs, info = vec.reset(seed=3)
+    assert obs.shape == (6, 8)
+    env.state.workpiece_position = 25.0
+    env.state.wire_position = 10.0
+    env.state.target_position[:3] = 25.0005    # the first craters finish these three
+    act = env.make_action()
+    terminated_seen = torch.zeros(6, dtype=torch.bool)
+    for _ in range(4):
+        obs, reward, terminated, truncated, info = vec.step(act)
+        terminated_seen |= terminated
+        assert reward.shape == (6,) and not truncated.any()
+    assert terminated_seen[:3].all() and not terminated_seen[3:].any()
+    assert (vec.episode_count[:3] >= 1).all() and (vec.episode_count[3:] == 0).all()
+    assert (env.state.episode[:3] >= 1).all()            # fresh Philox stream per episode
+    assert (env.state.time[3:] == 4000).all() and (env.state.time[:3] < 4000).all()
+    vec2 = WireEDMVectorEnv(WireEDMEnv(num_envs=2, device="cpu", backend=OracleBackend), max_episode_steps=2000)
+    vec2.reset(seed=1)
+    a2 = vec2.env.make_action()
+    _, _, term, trunc, _ = vec2.step(a2)
+    assert not trunc.any()
+    _, _, term, trunc, _ = vec2.step(a2)
+    assert trunc.all() and not term.any()
+    vec2.step(a2)
+    assert (vec2.env.state.time == 1000).all()           # reset happened before the third interval
+
+
+def test_signal_logger_frequencies_and_npz(tmp_path):
+    env = driver_env(4, 9, backend=OracleBackend)
+    cfg = {"signals_to_log": ["time", "voltage", "wire_position", "spark_status", "wire_temperature"],
+           "log_frequency": {"type": "control_step"},
+           "backend": {"type": "numpy", "filepath": str(tmp_path / "log.npz"), "compress": True}}
+    logger = SimulationLogger(cfg, env_reference=env)
+    run_controlled(env, GapController(), 3500, on_control_step=lambda e, t: logger.collect(e.state, control_step=True))
+    logger.finalize()
+    data = logger.get_data()
+    assert data["time"].shape == (3, 4) and data["time"][:, 0].tolist() == [1001, 2001, 3001]
+    assert data["wire_temperature"].shape == (3, 4, env.n_segments)
+    z = np.load(tmp_path / "log.npz")
+    assert np.array_equal(z["wire_position"], data["wire_position"])
+    every = SimulationLogger({"signals_to_log": ["time"], "log_frequency": {"type": "interval", "value": 2}})
+    for _ in range(6):
+        env.step(env.make_action())
+        every.collect(env.state)
+    assert every.get_data()["time"].shape == (3, 4)
+    with pytest.raises(ValueError):
+        SimulationLogger({"log_frequency": {"type": "sometimes"}})
+
+
+def test_module_statistics_helpers():
+    env = WireEDMEnv(num_envs=4, device="cpu", backend=OracleBackend)
+    env.reset(seed=2)
+    env.state.workpiece_position = 11.0   # gap < 2 um -> debris short for 50 us
+    env.state.wire_position = 10.0
+    env.step_many(env.make_action(servo=-0.5), 10)
+    sc = env.get_short_circuit_status()
+    assert sc["has_debris_short"].all() and (sc["debris_short_remaining_us"] == 41).all()
+    assert (sc["total_short_remaining_us"] == 41).all() and not sc["has_random_short"].any()
+    deb = env.get_debris_statistics()
+    assert set(deb) == {"debris_volume_mm3", "debris_density", "cavity_volume_mm3", "flow_condition", "debris_fill_percentage"}
+    assert (env.get_crater_count() == 0).all()
+    assert env.zone_mean_temperature().shape == (4,)

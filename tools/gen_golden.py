@@ -318,6 +318,17 @@ def single_spark_forced(spark_time=50, duration=2, loc=25.0, ocv=80.0):
 
 
 def main():
+    import os
+
+    only = os.environ.get("WEDM_GOLDEN_ONLY")
+    if only:
+        global run_scenario
+        _orig = run_scenario
+
+        def run_scenario(name, **kw):  # noqa: F811
+            if only in name:
+                return _orig(name, **kw)
+            return None
     # F1 — BASELINE config 1: brass 0.25 mm wire, seed 0, quickstart action, 10 000 us
     run_scenario("f1_config1_native", n_steps=10000, seed=0, config={"wire_diameter": 0.25},
                  action=QUICKSTART, t_snap_every=1000, float_stride=7,
@@ -396,6 +407,18 @@ def main():
                              "dielectric_temperature": 293.15},
                  t_snap_every=4000, float_stride=9,
                  note="experiments/run_simulation.py:173-297 with the gap controller (float32 leaves)")
+
+    # F7p — the same driver with the build's Philox variates injected (two environments), so the
+    # batched environment + on-device controller can be compared with the reference directly
+    for env_id in (0, 9):
+        run_scenario(f"f7_gap_controller_philox_env{env_id}", n_steps=9000, seed=77, rng="philox", env_id=env_id,
+                     controller=gap_controller(),
+                     state_init={"workpiece_position": 70.0, "wire_position": 10.0, "target_position": 5000.0},
+                     t_snap_every=3000, float_stride=9, note="run_simulation.py gap controller, Philox key 77")
+    run_scenario("f7_gap_controller_velocity_philox_env3", n_steps=6000, seed=78, rng="philox", env_id=3,
+                 control_mode="velocity", controller=gap_controller(),
+                 state_init={"workpiece_position": 70.0, "wire_position": 10.0, "target_position": 5000.0},
+                 t_snap_every=3000, float_stride=9, note="velocity-mode gap controller (clip +-1000 um/s)")
 
     # geometry variants (BASELINE config 5 shapes), short Philox runs
     for i, (h, d) in enumerate(((10.0, 0.10), (15.0, 0.25), (30.0, 0.30), (12.3, 0.15))):
