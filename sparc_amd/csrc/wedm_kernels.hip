@@ -1327,9 +1327,14 @@ int32_t wedm_step(wedm_ctx* ctx, int32_t n_substeps, const wedm_action_ptrs* act
     const bool lanes_ok = glanes > 0;
     int variant = ctx->variant;
     if (variant == 0) {
-        if (n_substeps > 1 && packed_ok) variant = 4;
-        else if (n_substeps > 1 && fused_ok) variant = 3;
-        else variant = (n_substeps > 1 && lanes_ok) ? 2 : 1;
+        // single-microsecond launches: the global-memory kernel (measured 37 us vs 50+ us staged);
+        // fused launches: packed when it puts ~2 waves on every SIMD, else whichever of
+        // packed / one-chunk-per-lane yields more waves (small batches want more lanes)
+        const auto waves_for = [&](int l) { return (long)((ctx->num_envs + (256 / l) - 1) / (256 / l)) * 4; };
+        if (n_substeps <= 1) variant = 1;
+        else if (packed_ok && (waves_for(planes) >= 2048 || !fused_ok || waves_for(planes) >= waves_for(lanes))) variant = 4;
+        else if (fused_ok) variant = 3;
+        else variant = lanes_ok ? 2 : 1;
     }
     if (variant == 3 && !fused_ok)
         return fail(ctx, WEDM_ERR_UNSUPPORTED, "wedm_step: fused kernel needs uniform geometry and a chunk that fits in LDS");
