@@ -26,22 +26,21 @@ class EnvironmentConfig:
     min_gap_for_operation: float = 2.0  # [um]
     max_cutting_force: float = 100.0  # [N]
 
+    # ---- (de)serialisation: unknown keys are ignored, as in the reference ----------------------
     @classmethod
     def from_dict(cls, config_dict: Dict[str, Any]) -> "EnvironmentConfig":
-        known = {f.name for f in fields(cls)}
-        return cls(**{k: v for k, v in config_dict.items() if k in known})
+        accepted = {f.name for f in fields(cls)}
+        return cls(**{key: config_dict[key] for key in config_dict if key in accepted})
 
     @classmethod
     def from_json(cls, json_path: str | Path) -> "EnvironmentConfig":
-        with open(Path(json_path), "r") as fh:
-            return cls.from_dict(json.load(fh))
+        return cls.from_dict(json.loads(Path(json_path).read_text()))
 
     def to_dict(self) -> Dict[str, Any]:
         return asdict(self)
 
     def to_json(self, json_path: str | Path) -> None:
-        with open(Path(json_path), "w") as fh:
-            json.dump(self.to_dict(), fh, indent=2)
+        Path(json_path).write_text(json.dumps(self.to_dict(), indent=2))
 
     def validate(self) -> None:
         """Raises ``ValueError`` exactly where the reference does (env_config.py:73-90)."""

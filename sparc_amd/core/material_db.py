@@ -30,18 +30,26 @@ _BUILTIN = {
 }
 
 
+WIRE_FILE = "wire_materials.json"
+
+
 class MaterialDatabase:
+    """Name -> `WireMaterial`.  Starts from the built-in table; a directory holding a
+    `wire_materials.json` of the reference's shape adds to / overrides it."""
+
     def __init__(self, data_dir: Optional[Path] = None):
-        self.data_dir = Path(data_dir) if data_dir is not None else None
-        self._wire_materials: Dict[str, WireMaterial] = {
-            name: WireMaterial(name=name, **props) for name, props in _BUILTIN.items()
-        }
-        if self.data_dir is not None:
-            wire_file = self.data_dir / "wire_materials.json"
-            if wire_file.exists():
-                with open(wire_file, "r") as fh:
-                    for name, props in json.load(fh).items():
-                        self._wire_materials[name] = WireMaterial(name=name, **props)
+        self.data_dir = None if data_dir is None else Path(data_dir)
+        self._wire_materials: Dict[str, WireMaterial] = {}
+        self._register(_BUILTIN)
+        if self.data_dir is not None and (self.data_dir / WIRE_FILE).exists():
+            self._register(json.loads((self.data_dir / WIRE_FILE).read_text()))
+
+    def _register(self, table: Dict[str, Dict[str, float]]) -> None:
+        for key, constants in table.items():
+            self._wire_materials[key] = WireMaterial(name=key, **constants)
+
+    def names(self):
+        return sorted(self._wire_materials)
 
     def get_wire_material(self, name: str) -> WireMaterial:
         if name not in self._wire_materials:
@@ -49,16 +57,13 @@ class MaterialDatabase:
         return self._wire_materials[name]
 
     def save_materials(self) -> None:
+        """Write the current table as `<data_dir>/wire_materials.json`."""
         if self.data_dir is None:
             raise ValueError("MaterialDatabase was created without a data_dir")
         self.data_dir.mkdir(parents=True, exist_ok=True)
-        data = {}
-        for name, mat in self._wire_materials.items():
-            row = asdict(mat)
-            row.pop("name")
-            data[name] = row
-        with open(self.data_dir / "wire_materials.json", "w") as fh:
-            json.dump(data, fh, indent=2)
+        table = {key: {f: v for f, v in asdict(mat).items() if f != "name"}
+                 for key, mat in self._wire_materials.items()}
+        (self.data_dir / WIRE_FILE).write_text(json.dumps(table, indent=2))
 
 
 _material_db: Optional[MaterialDatabase] = None

@@ -396,8 +396,13 @@ __device__ __forceinline__ Coef scalar_prelude(const Hot& p, const Cold& cold, c
 #else
         w = W4{t * 2654435761u + gid, 1u, 0xffffffffu - (t ^ gid) * 40503u, 7u};
 #endif
-        const bool new_d = !timers && (u32_to_unit(w.x) < p_d);
-        const bool new_r = !timers && !new_d && (u32_to_unit(w.y) < p_r);
+        // p_d and p_r are exactly 0 in the ordinary gap regime: the rolls cannot succeed and the
+        // integer -> double conversions are skipped for the whole wave
+        bool new_d = false, new_r = false;
+        if (__any(!timers && (p_d > 0.0 || p_r > 0.0))) {
+            new_d = !timers && (u32_to_unit(w.x) < p_d);
+            new_r = !timers && !new_d && (u32_to_unit(w.y) < p_r);
+        }
         if (new_d || new_r) {  // rare: a short begins (durations are cold parameters)
             const wedm_params* c = opaque(cold.p);
             if (new_d) s.deb_rem = c->debris_short_duration;

@@ -454,3 +454,29 @@ def test_vector_env_autoreset_on_gpu():
         seen |= term
     assert seen[:64].all() and not seen[64:].any()
     assert (vec.episode_count[:64] >= 1).all() and (env.state.time[64:] == 4000).all()
+
+
+@pytest.mark.parametrize("segment_len,n_seg", [(80.0, 1), (40.0, 2), (26.0, 3), (16.0, 5), (8.5, 9), (4.7, 17)])
+def test_tiny_wires_all_kernels(segment_len, n_seg):
+    """Degenerate grids: 1..17 segments (boundary cell, last cell and zone collapse onto each
+    other), odd batch size, every kernel variant that accepts the shape."""
+    n = 77
+    kw = dict(wire_params=WireModuleParameters(segment_len=segment_len))
+    gpu, cpu = make_pair(n, **kw)
+    assert gpu.n_segments == n_seg
+    both((gpu, cpu), lambda e: (e.reset(seed=8), close_gap(e, 24.0, 10.0)))
+    from sparc_amd._lib import WedmError
+
+    ran = 0
+    for variant, lanes in KERNELS:
+        gpu.set_kernel(variant, lanes)
+        a_g, a_c = gpu.make_action(0.1, 80.0, 9, 3.0, 30.0), cpu.make_action(0.1, 80.0, 9, 3.0, 30.0)
+        try:
+            gpu.step_many(a_g, 400)
+        except WedmError as exc:
+            assert "UNSUPPORTED" in str(exc)
+            continue
+        cpu.step_many(a_c, 400)
+        check(gpu, cpu, n)
+        ran += 1
+    assert ran >= 3 and int(gpu.state.spark_count.sum()) > 0
