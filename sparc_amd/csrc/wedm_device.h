@@ -540,6 +540,67 @@ __device__ __forceinline__ Coef scalar_prelude(const Hot& p, const Cold& cold, c
     return cf;
 }
 
+// ------------------------------------------------- quiet-step fast path (wave-uniform)
+// In an ordinary microsecond nothing discrete happens to an environment: no short timer runs,
+// the generator idles or rests, the action is not latched, the gap is far from a hard short, the
+// debris sigmoid cannot fire (exponent > 24), the flow / convection caches stay valid and the
+// ignition roll fails.  For such a step scalar_prelude() reduces to the straight line below
+// (every assignment is what the general code computes under exactly these conditions).  The
+// fast path is taken only if EVERY live lane of the wave qualifies and none ignites; nothing is
+// written before that is known, so otherwise the general path runs on untouched state.
+// Returns true when the step was handled (the stencil coefficients are then {0, 0, off, none}).
+__device__ __forceinline__ bool quiet_prelude(const Hot& p, const Geom& g, uint32_t gid, Env& s) {
+    if (p.disable_ignition || p.has_random_short) return false;
+    const bool live = !s.done;
+    const double d0 = s.wp - s.x;                       // unclamped gap (>= hard_short_gap > 0.001 below)
+    const bool idle = s.state == 0, rest = s.state == -2;
+    double crit = p.base_critical_density + p.gap_coefficient * d0;
+    crit = crit < p.max_critical_density ? crit : p.max_critical_density;
+    const double ex = -p.sigmoid_steepness * (s.rho - crit);
+    bool q = (s.tss < p.servo_interval) && (s.rnd_rem == 0) && (s.deb_rem == 0) && (idle || rest) &&
+             (d0 >= p.hard_short_gap) && (ex > 24.0);
+    // dielectric (dielectric.py:87-139): this step's density and the cache test
+    const double cavity = g.cavity_coeff * (d0 * 0.001);
+    double rho = 0.0;
+    if (cavity > 0) {
+        const double qq = s.debris / cavity;
+        rho = qq < 1.0 ? qq : 1.0;
+    }
+    q = q && !(__builtin_fabs(d0 - s.last_gap) > 0.01 || __builtin_fabs(rho - s.last_rho) > 0.001) &&
+        !(__builtin_fabs(s.flow - s.wire_last_flow) > 0.01) && (d0 > 0.001);
+    if (!__all(q || !live)) return false;
+    // ignition roll of the idle lanes (ignition.py:321-327)
+    bool ign = false;
+    if (__any(idle && live)) {
+        const double lam = p.ln2 / (p.ignition_a * (d0 * d0) + p.ignition_b * d0 + p.ignition_c);
+        const W4 w = philox4(s.key0, s.key1, (uint32_t)s.time, (uint32_t)s.episode, gid, 0u);
+        ign = idle && live && (u32_to_unit(w.z) < lam);
+    }
+    if (__any(ign)) return false;
+    if (live) {
+        const double Vt = s.tvolt != 0.0 ? s.tvolt : p.default_target_voltage;
+        const double on = s.on != 0.0 ? s.on : p.default_on_time;
+        const double off = s.off != 0.0 ? s.off : p.default_off_time;
+        const int32_t dur1 = s.dur + 1;
+        const bool end_rest = rest && ((double)dur1 >= on + off);
+        s.ctrl = 0;
+        s.is_short = 0;
+        s.V = idle ? Vt : (end_rest ? Vt : 0.0);
+        s.I = 0.0;
+        s.y = end_rest ? __builtin_nan("") : s.y;
+        s.dur = idle ? s.dur : (end_rest ? 0 : dur1);
+        s.state = end_rest ? 0 : s.state;
+        s.last_crater = 0.0;
+        s.cavity = cavity;
+        s.rho = rho;
+        if (s.flow > 0.001 && s.debris > 0.001) {
+            const double nv = s.debris - p.debris_removal_per_us * s.flow;
+            s.debris = nv > 0.0 ? nv : 0.0;
+        }
+    }
+    return true;
+}
+
 // one cell of wire.py:58-123, float32 op for op; tm1/tc/tp1 are OLD temperatures
 __device__ __forceinline__ float stencil_cell(int i, int n_seg, float tm1, float tc, float tp1, const Geom& g,
                                               const Coef& c, const Persist& ps, float tref, float alpha,

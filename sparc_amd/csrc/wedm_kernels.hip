@@ -120,7 +120,7 @@ __device__ __forceinline__ void run_substeps(const KArgs& k, const Geom& g, int6
     init_persist(k.hot, k.cold, e, s, ps);
     for (int it = 0; it < k.n_substeps; ++it) {
         if (s.done) break;
-        Coef c = scalar_prelude(k.hot, k.cold, g, e, gid, s, ps);
+        Coef c = scalar_prelude(k.hot, k.cold, g, e, gid, s, ps);  // single steps: the quiet test does not pay
         float tmax = stencil_pass(T, g, c, ps, k.hot.spool, k.hot.tref, k.hot.alpha, k.hot.tdiel);
         scalar_epilogue(k.hot, s, tmax);
         if (s.ctrl) write_obs(k.cold, e, s);
@@ -195,7 +195,7 @@ __global__ void __launch_bounds__(256, 2) wedm_step_lanes(const KArgs k) {
     for (int it = 0; it < k.n_substeps; ++it) {
         if (__all(s.done)) break;
         Coef cf{0.0f, 0.0f, 0, -1};
-        if (!s.done) cf = scalar_prelude(k.hot, k.cold, g, e, gid, s, ps);
+        if (!quiet_prelude(k.hot, g, gid, s) && !s.done) cf = scalar_prelude(k.hot, k.cold, g, e, gid, s, ps);
         const float halo_l = (c > 0) ? col[(C - 1) * 256 - 1] : spool;
         const float halo_r = (c < L - 1) ? col[1] : 0.0f;
         float tmax = spool, tm1 = halo_l, tc = col[0];
@@ -366,7 +366,7 @@ __global__ void __launch_bounds__(256, 2) wedm_step_fused(const KArgs k) {
         if (__all(s.done)) break;
         WEDM_STAMP(st0);
         Coef cf{0.0f, 0.0f, 0, -1};
-        if (!s.done) cf = scalar_prelude(k.hot, k.cold, g, e, gid, s, ps);
+        if (!quiet_prelude(k.hot, g, gid, s) && !s.done) cf = scalar_prelude(k.hot, k.cold, g, e, gid, s, ps);
         WEDM_STAMP(st1);
 
         // ---- halos: OLD neighbour values, read before any lane of this wave stores.  The right
@@ -588,54 +588,70 @@ __device__ __forceinline__ f2 interior2(f2 tm1, f2 tc, f2 tp1, float k, float tu
 // order and rounding are exactly those of interior2().  old[u], old[u+1], old[u+2] are the OLD
 // (tm1, tc, tp1) of pair u.  conv/jfe: one coefficient pair per cell (PERCELL) or per tile.
 #define WEDM_STAGE_FENCE() __builtin_amdgcn_sched_barrier(0)
-template <bool JOULE, bool PERCELL>
-__device__ __forceinline__ void tile8_staged(const f2 (&old)[10], f2 (&tn)[8], float k, float tuf, const f2 (&conv)[8],
-                                             float tdiel, float adv, const f2 (&jfe)[8], float alpha, float tref) {
-    f2 a[8], e[8], f[8], r[8];
+// W pairs starting at pair `o` of the tile (W = 4: two half-tiles keep the temporaries, and
+// with them the scratch spills of the caller's state, small; 4-way ILP already covers the
+// packed-op latency).
+template <bool JOULE, bool PERCELL, int W>
+__device__ __forceinline__ void tile_staged(const f2 (&old)[10], f2 (&tn)[8], const int o, float k, float tuf,
+                                            const f2 (&conv)[8], float tdiel, float adv, const f2 (&jfe)[8],
+                                            float alpha, float tref) {
+    f2 a[W], e[W], f[W], r[W];
 #pragma unroll
-    for (int u = 0; u < 8; ++u) {
-        a[u] = old[u + 1] + old[u + 1];  // 2*T[i]
-        e[u] = old[u + 1] - tdiel;       // T[i] - T_dielectric
-        f[u] = old[u] - old[u + 1];      // T[i-1] - T[i]
-        if (JOULE) r[u] = old[u + 1] - tref;
+    for (int u = 0; u < W; ++u) {
+        a[u] = old[o + u + 1] + old[o + u + 1];  // 2*T[i]
+        e[u] = old[o + u + 1] - tdiel;           // T[i] - T_dielectric
+        f[u] = old[o + u] - old[o + u + 1];      // T[i-1] - T[i]
+        if (JOULE) r[u] = old[o + u + 1] - tref;
     }
     WEDM_STAGE_FENCE();
 #pragma unroll
-    for (int u = 0; u < 8; ++u) {
-        a[u] = old[u] - a[u];
-        e[u] = (PERCELL ? conv[u] : conv[0]) * e[u];
+    for (int u = 0; u < W; ++u) {
+        a[u] = old[o + u] - a[u];
+        e[u] = (PERCELL ? conv[o + u] : conv[0]) * e[u];
         f[u] = adv * f[u];
         if (JOULE) r[u] = alpha * r[u];
     }
     WEDM_STAGE_FENCE();
 #pragma unroll
-    for (int u = 0; u < 8; ++u) {
-        a[u] = a[u] + old[u + 2];
+    for (int u = 0; u < W; ++u) {
+        a[u] = a[u] + old[o + u + 2];
         if (JOULE) r[u] = 1.0f + r[u];
     }
     WEDM_STAGE_FENCE();
 #pragma unroll
-    for (int u = 0; u < 8; ++u) {
+    for (int u = 0; u < W; ++u) {
         a[u] = k * a[u];
-        if (JOULE) r[u] = (PERCELL ? jfe[u] : jfe[0]) * r[u];
+        if (JOULE) r[u] = (PERCELL ? jfe[o + u] : jfe[0]) * r[u];
     }
     WEDM_STAGE_FENCE();
     if (JOULE) {
 #pragma unroll
-        for (int u = 0; u < 8; ++u) a[u] = a[u] + r[u];
+        for (int u = 0; u < W; ++u) a[u] = a[u] + r[u];
         WEDM_STAGE_FENCE();
     }
 #pragma unroll
-    for (int u = 0; u < 8; ++u) a[u] = a[u] - e[u];
+    for (int u = 0; u < W; ++u) a[u] = a[u] - e[u];
     WEDM_STAGE_FENCE();
 #pragma unroll
-    for (int u = 0; u < 8; ++u) a[u] = a[u] + f[u];
+    for (int u = 0; u < W; ++u) a[u] = a[u] + f[u];
     WEDM_STAGE_FENCE();
 #pragma unroll
-    for (int u = 0; u < 8; ++u) a[u] = a[u] * tuf;
+    for (int u = 0; u < W; ++u) a[u] = a[u] * tuf;
     WEDM_STAGE_FENCE();
 #pragma unroll
-    for (int u = 0; u < 8; ++u) tn[u] = old[u + 1] + a[u];
+    for (int u = 0; u < W; ++u) tn[o + u] = old[o + u + 1] + a[u];
+    WEDM_STAGE_FENCE();
+}
+
+#ifndef WEDM_STAGE_W
+#define WEDM_STAGE_W 4
+#endif
+template <bool JOULE, bool PERCELL>
+__device__ __forceinline__ void tile8_staged(const f2 (&old)[10], f2 (&tn)[8], float k, float tuf, const f2 (&conv)[8],
+                                             float tdiel, float adv, const f2 (&jfe)[8], float alpha, float tref) {
+#pragma unroll
+    for (int o = 0; o < 8; o += WEDM_STAGE_W)
+        tile_staged<JOULE, PERCELL, WEDM_STAGE_W>(old, tn, o, k, tuf, conv, tdiel, adv, jfe, alpha, tref);
 }
 
 template <int L>
@@ -717,7 +733,7 @@ __global__ void __launch_bounds__(256, 2) wedm_step_packed(const KArgs k) {
         if (__all(s.done)) break;
         WEDM_STAMP(st0);
         Coef cf{0.0f, 0.0f, 0, -1};
-        if (!s.done) cf = scalar_prelude(k.hot, k.cold, g, e, gid, s, ps);
+        if (!quiet_prelude(k.hot, g, gid, s) && !s.done) cf = scalar_prelude(k.hot, k.cold, g, e, gid, s, ps);
         WEDM_STAMP(st1);
 
         // ---- halos (OLD values, read before any store of this step)

@@ -436,7 +436,7 @@ def test_run_controlled_on_gpu_matches_oracle():
         assert run_controlled(env, GapController(desired_gap=8.0, current_mode=9), 6500) == 6500
     check(gpu, cpu, n)
     assert int(gpu.state.spark_count.sum()) > 100
-    assert "wedm_step_packed" in gpu._backend.last_kernel()
+    assert "wedm_step_packed" in gpu._backend.last_kernel() or "wedm_step_fused" in gpu._backend.last_kernel()
 
 
 def test_vector_env_autoreset_on_gpu():
