@@ -292,6 +292,81 @@ __device__ __forceinline__ float interior_cell(float tm1, float tc, float tp1, f
     return tc + d * tuf;
 }
 
+typedef float f2 __attribute__((ext_vector_type(2)));
+
+// Eight cells (V = float) or eight packed cell pairs (V = float2) evaluated STAGE-MAJOR: every stage applies one operation
+// of interior2() to all eight pairs, and a scheduling barrier separates the stages, so dependent
+// packed ops are always >= 8 instructions apart.  Left to itself the scheduler emits the eight
+// chains one after the other (each op waiting on the previous, s_nop in between).  Operation
+// order and rounding are exactly those of interior2().  old[u], old[u+1], old[u+2] are the OLD
+// (tm1, tc, tp1) of pair u.  conv/jfe: one coefficient pair per cell (PERCELL) or per tile.
+#define WEDM_STAGE_FENCE() __builtin_amdgcn_sched_barrier(0)
+// W pairs starting at pair `o` of the tile (W = 4: two half-tiles keep the temporaries, and
+// with them the scratch spills of the caller's state, small; 4-way ILP already covers the
+// packed-op latency).
+template <class V, bool JOULE, bool PERCELL, int W>
+__device__ __forceinline__ void tile_staged(const V (&old)[10], V (&tn)[8], const int o, float k, float tuf,
+                                            const V (&conv)[8], float tdiel, float adv, const V (&jfe)[8],
+                                            float alpha, float tref) {
+    V a[W], e[W], f[W], r[W];
+#pragma unroll
+    for (int u = 0; u < W; ++u) {
+        a[u] = old[o + u + 1] + old[o + u + 1];  // 2*T[i]
+        e[u] = old[o + u + 1] - tdiel;           // T[i] - T_dielectric
+        f[u] = old[o + u] - old[o + u + 1];      // T[i-1] - T[i]
+        if (JOULE) r[u] = old[o + u + 1] - tref;
+    }
+    WEDM_STAGE_FENCE();
+#pragma unroll
+    for (int u = 0; u < W; ++u) {
+        a[u] = old[o + u] - a[u];
+        e[u] = (PERCELL ? conv[o + u] : conv[0]) * e[u];
+        f[u] = adv * f[u];
+        if (JOULE) r[u] = alpha * r[u];
+    }
+    WEDM_STAGE_FENCE();
+#pragma unroll
+    for (int u = 0; u < W; ++u) {
+        a[u] = a[u] + old[o + u + 2];
+        if (JOULE) r[u] = 1.0f + r[u];
+    }
+    WEDM_STAGE_FENCE();
+#pragma unroll
+    for (int u = 0; u < W; ++u) {
+        a[u] = k * a[u];
+        if (JOULE) r[u] = (PERCELL ? jfe[o + u] : jfe[0]) * r[u];
+    }
+    WEDM_STAGE_FENCE();
+    if (JOULE) {
+#pragma unroll
+        for (int u = 0; u < W; ++u) a[u] = a[u] + r[u];
+        WEDM_STAGE_FENCE();
+    }
+#pragma unroll
+    for (int u = 0; u < W; ++u) a[u] = a[u] - e[u];
+    WEDM_STAGE_FENCE();
+#pragma unroll
+    for (int u = 0; u < W; ++u) a[u] = a[u] + f[u];
+    WEDM_STAGE_FENCE();
+#pragma unroll
+    for (int u = 0; u < W; ++u) a[u] = a[u] * tuf;
+    WEDM_STAGE_FENCE();
+#pragma unroll
+    for (int u = 0; u < W; ++u) tn[o + u] = old[o + u + 1] + a[u];
+    WEDM_STAGE_FENCE();
+}
+
+#ifndef WEDM_STAGE_W
+#define WEDM_STAGE_W 4
+#endif
+template <class V, bool JOULE, bool PERCELL>
+__device__ __forceinline__ void tile8_staged(const V (&old)[10], V (&tn)[8], float k, float tuf, const V (&conv)[8],
+                                             float tdiel, float adv, const V (&jfe)[8], float alpha, float tref) {
+#pragma unroll
+    for (int o = 0; o < 8; o += WEDM_STAGE_W)
+        tile_staged<V, JOULE, PERCELL, WEDM_STAGE_W>(old, tn, o, k, tuf, conv, tdiel, adv, jfe, alpha, tref);
+}
+
 template <int L>
 __global__ void __launch_bounds__(256, 2) wedm_step_fused(const KArgs k) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
@@ -432,25 +507,23 @@ __global__ void __launch_bounds__(256, 2) wedm_step_fused(const KArgs k) {
                 const int tkind = (((kind_n & ~slow_now) >> t) & 1u) ? 0 : (!((slow_now >> t) & 1u) ? 1 : 2);
 #endif
                 if (((kind_n & ~slow_now) >> t) & 1u) {
-                    if (joule_wave && __any(jfe_lo != 0.0f)) {
+                    float old[10], tn[8], cv[8], jv[8];
+                    old[0] = tm1; old[1] = tc;
 #pragma unroll
-                        for (int u = 0; u < 8; ++u) {
-                            float tn = interior_cell<true>(tm1, tc, cur[u], g.k, g.tuf, conv_lo, tdiel, ps.adv, jfe_lo, alpha, tref);
-                            col[(j + u) * 256] = tn;
-                            tmax = fmax_gt(tmax, tn);
-                            tm1 = tc;
-                            tc = cur[u];
-                        }
-                    } else {
+                    for (int u = 0; u < 8; ++u) old[u + 2] = cur[u];
+                    cv[0] = conv_lo; jv[0] = jfe_lo;
+                    if (joule_wave && __any(jfe_lo != 0.0f))
+                        tile8_staged<float, true, false>(old, tn, g.k, g.tuf, cv, tdiel, ps.adv, jv, alpha, tref);
+                    else
+                        tile8_staged<float, false, false>(old, tn, g.k, g.tuf, cv, tdiel, ps.adv, jv, alpha, tref);
 #pragma unroll
-                        for (int u = 0; u < 8; ++u) {
-                            float tn = interior_cell<false>(tm1, tc, cur[u], g.k, g.tuf, conv_lo, tdiel, ps.adv, jfe_lo, alpha, tref);
-                            col[(j + u) * 256] = tn;
-                            tmax = fmax_gt(tmax, tn);
-                            tm1 = tc;
-                            tc = cur[u];
-                        }
-                    }
+                    for (int u = 0; u < 8; ++u) col[(j + u) * 256] = tn[u];
+                    float m0 = fmax_gt(tn[0], tn[1]), m1 = fmax_gt(tn[2], tn[3]);
+                    m0 = fmax_gt(m0, fmax_gt(tn[4], tn[5]));
+                    m1 = fmax_gt(m1, fmax_gt(tn[6], tn[7]));
+                    tmax = fmax_gt(tmax, fmax_gt(m0, m1));
+                    tm1 = cur[6];
+                    tc = cur[7];
                 } else if (!((slow_now >> t) & 1u)) {
                     // TILE_B: interior formula everywhere, one flag change at `split`, boundary and
                     // out-of-wire cells excluded from the max (they are patched / never read)
@@ -565,7 +638,6 @@ __global__ void __launch_bounds__(256, 2) wedm_step_fused(const KArgs k) {
 // halves the instructions the wave has to issue.  Rows of A and B are interleaved in the lane's
 // LDS column (row 2r = A[r], row 2r+1 = B[r]; rows 2Cv, 2Cv+1 hold the right halos), so a pair
 // is one ds_read2st64_b32 / ds_write2st64_b32.  The walk table is the one built for 2L chunks.
-typedef float f2 __attribute__((ext_vector_type(2)));
 
 template <bool JOULE>
 __device__ __forceinline__ f2 interior2(f2 tm1, f2 tc, f2 tp1, float k, float tuf, f2 conv, float tdiel, float adv,
@@ -579,79 +651,6 @@ __device__ __forceinline__ f2 interior2(f2 tm1, f2 tc, f2 tp1, float k, float tu
     d = d - conv * (tc - tdiel);
     d = d + adv * (tm1 - tc);
     return tc + d * tuf;
-}
-
-// Eight packed cells (16 wire cells) evaluated STAGE-MAJOR: every stage applies one operation
-// of interior2() to all eight pairs, and a scheduling barrier separates the stages, so dependent
-// packed ops are always >= 8 instructions apart.  Left to itself the scheduler emits the eight
-// chains one after the other (each op waiting on the previous, s_nop in between).  Operation
-// order and rounding are exactly those of interior2().  old[u], old[u+1], old[u+2] are the OLD
-// (tm1, tc, tp1) of pair u.  conv/jfe: one coefficient pair per cell (PERCELL) or per tile.
-#define WEDM_STAGE_FENCE() __builtin_amdgcn_sched_barrier(0)
-// W pairs starting at pair `o` of the tile (W = 4: two half-tiles keep the temporaries, and
-// with them the scratch spills of the caller's state, small; 4-way ILP already covers the
-// packed-op latency).
-template <bool JOULE, bool PERCELL, int W>
-__device__ __forceinline__ void tile_staged(const f2 (&old)[10], f2 (&tn)[8], const int o, float k, float tuf,
-                                            const f2 (&conv)[8], float tdiel, float adv, const f2 (&jfe)[8],
-                                            float alpha, float tref) {
-    f2 a[W], e[W], f[W], r[W];
-#pragma unroll
-    for (int u = 0; u < W; ++u) {
-        a[u] = old[o + u + 1] + old[o + u + 1];  // 2*T[i]
-        e[u] = old[o + u + 1] - tdiel;           // T[i] - T_dielectric
-        f[u] = old[o + u] - old[o + u + 1];      // T[i-1] - T[i]
-        if (JOULE) r[u] = old[o + u + 1] - tref;
-    }
-    WEDM_STAGE_FENCE();
-#pragma unroll
-    for (int u = 0; u < W; ++u) {
-        a[u] = old[o + u] - a[u];
-        e[u] = (PERCELL ? conv[o + u] : conv[0]) * e[u];
-        f[u] = adv * f[u];
-        if (JOULE) r[u] = alpha * r[u];
-    }
-    WEDM_STAGE_FENCE();
-#pragma unroll
-    for (int u = 0; u < W; ++u) {
-        a[u] = a[u] + old[o + u + 2];
-        if (JOULE) r[u] = 1.0f + r[u];
-    }
-    WEDM_STAGE_FENCE();
-#pragma unroll
-    for (int u = 0; u < W; ++u) {
-        a[u] = k * a[u];
-        if (JOULE) r[u] = (PERCELL ? jfe[o + u] : jfe[0]) * r[u];
-    }
-    WEDM_STAGE_FENCE();
-    if (JOULE) {
-#pragma unroll
-        for (int u = 0; u < W; ++u) a[u] = a[u] + r[u];
-        WEDM_STAGE_FENCE();
-    }
-#pragma unroll
-    for (int u = 0; u < W; ++u) a[u] = a[u] - e[u];
-    WEDM_STAGE_FENCE();
-#pragma unroll
-    for (int u = 0; u < W; ++u) a[u] = a[u] + f[u];
-    WEDM_STAGE_FENCE();
-#pragma unroll
-    for (int u = 0; u < W; ++u) a[u] = a[u] * tuf;
-    WEDM_STAGE_FENCE();
-#pragma unroll
-    for (int u = 0; u < W; ++u) tn[o + u] = old[o + u + 1] + a[u];
-    WEDM_STAGE_FENCE();
-}
-
-#ifndef WEDM_STAGE_W
-#define WEDM_STAGE_W 4
-#endif
-template <bool JOULE, bool PERCELL>
-__device__ __forceinline__ void tile8_staged(const f2 (&old)[10], f2 (&tn)[8], float k, float tuf, const f2 (&conv)[8],
-                                             float tdiel, float adv, const f2 (&jfe)[8], float alpha, float tref) {
-#pragma unroll
-    for (int o = 0; o < 8; o += WEDM_STAGE_W)
-        tile_staged<JOULE, PERCELL, WEDM_STAGE_W>(old, tn, o, k, tuf, conv, tdiel, adv, jfe, alpha, tref);
 }
 
 template <int L>
@@ -800,9 +799,9 @@ __global__ void __launch_bounds__(256, 2) wedm_step_packed(const KArgs k) {
                     for (int u = 0; u < 8; ++u) old[u + 2] = cur[u];
                     cv[0] = conv_lo; jv[0] = jfe_lo;
                     if (joule_wave && __any(jfe_lo.x != 0.0f || jfe_lo.y != 0.0f))
-                        tile8_staged<true, false>(old, tn, g.k, g.tuf, cv, tdiel, ps.adv, jv, alpha, tref);
+                        tile8_staged<f2, true, false>(old, tn, g.k, g.tuf, cv, tdiel, ps.adv, jv, alpha, tref);
                     else
-                        tile8_staged<false, false>(old, tn, g.k, g.tuf, cv, tdiel, ps.adv, jv, alpha, tref);
+                        tile8_staged<f2, false, false>(old, tn, g.k, g.tuf, cv, tdiel, ps.adv, jv, alpha, tref);
                     float m0 = fmax_gt(tn[0].x, tn[0].y), m1 = fmax_gt(tn[1].x, tn[1].y);
 #pragma unroll
                     for (int u = 0; u < 8; ++u) store2(r0 + u, tn[u]);
@@ -831,8 +830,8 @@ __global__ void __launch_bounds__(256, 2) wedm_step_packed(const KArgs k) {
                         cv[u] = u < split ? conv_lo : conv_hi;
                         jv[u] = u < split ? jfe_lo : jfe_hi;
                     }
-                    if (joule_wave) tile8_staged<true, true>(old, tn, g.k, g.tuf, cv, tdiel, ps.adv, jv, alpha, tref);
-                    else tile8_staged<false, true>(old, tn, g.k, g.tuf, cv, tdiel, ps.adv, jv, alpha, tref);
+                    if (joule_wave) tile8_staged<f2, true, true>(old, tn, g.k, g.tuf, cv, tdiel, ps.adv, jv, alpha, tref);
+                    else tile8_staged<f2, false, true>(old, tn, g.k, g.tuf, cv, tdiel, ps.adv, jv, alpha, tref);
 #pragma unroll
                     for (int u = 0; u < 8; ++u) {
                         if (u < cnt) {
@@ -1004,6 +1003,7 @@ struct wedm_ctx {
     Tables tb{};
     int32_t variant = 0;
     int32_t lanes = 0;                 // lanes per environment for the fused kernel (0 = auto)
+    bool auto_prefers_packed = true;
     unsigned long long* dbg = nullptr; // diagnostic builds: phase stamp buffer
     int lds_limit = 0;
     WalkTable* walk_dev = nullptr;     // [5] tables for L = 1, 2, 4, 8, 16
@@ -1065,12 +1065,6 @@ static bool build_walk(const wedm_params& p, int L, WalkTable& t) {
 }
 
 static int lanes_index(int L) { return L == 1 ? 0 : L == 2 ? 1 : L == 4 ? 2 : L == 8 ? 3 : L == 16 ? 4 : -1; }
-
-// Lanes per environment when the caller does not choose: the smallest L that (a) fits the
-// chunk in LDS and (b) puts at least ~2 waves on every SIMD (1024 SIMDs), preferring more
-// lanes only while the per-lane wire work still outweighs the replicated scalar work.
-static int auto_lanes(const wedm_ctx* ctx);
-static int auto_lanes_packed(const wedm_ctx* ctx);
 
 static thread_local std::string g_create_error;
 
@@ -1180,37 +1174,6 @@ int32_t wedm_create(const wedm_params* params, int32_t num_envs, int32_t n_seg_m
     return WEDM_OK;
 }
 
-static int auto_lanes(const wedm_ctx* ctx) {
-    const int Ls[5] = {1, 2, 4, 8, 16};
-    int best = 0;
-    for (int i = 0; i < 5; ++i) {
-        if (!ctx->walk_ok[i]) continue;
-        const size_t lds = ((size_t)ctx->walk_C[i] + 1) * 1024;
-        if (lds > (size_t)ctx->lds_limit) continue;
-        if (!best) best = Ls[i];
-        const long waves = (long)((ctx->num_envs + (256 / Ls[i]) - 1) / (256 / Ls[i])) * 4;
-        best = Ls[i];
-        if (waves >= 2048 || ctx->walk_C[i] <= 32) break;
-    }
-    return best;
-}
-
-// packed kernel: the smallest L in {1,2,4,8} whose two chunks fit in LDS, raised until the
-// launch has ~2 waves per SIMD or the chunks get shorter than two tiles
-static int auto_lanes_packed(const wedm_ctx* ctx) {
-    const int Ls[4] = {1, 2, 4, 8};
-    int best = 0;
-    for (int i = 0; i < 4; ++i) {
-        const int ti = lanes_index(2 * Ls[i]);
-        if (!ctx->walk_ok[ti]) continue;
-        if ((2 * (size_t)ctx->walk_C[ti] + 2) * 1024 > (size_t)ctx->lds_limit) continue;
-        best = Ls[i];
-        const long waves = (long)((ctx->num_envs + (256 / Ls[i]) - 1) / (256 / Ls[i])) * 4;
-        if (waves >= 2048 || ctx->walk_C[ti] <= 16) break;
-    }
-    return best;
-}
-
 int32_t wedm_destroy(wedm_ctx* ctx) {
     if (!ctx) return WEDM_ERR_BAD_ARG;
     if (ctx->tables_dev) (void)hipFree(ctx->tables_dev);
@@ -1316,13 +1279,47 @@ int32_t wedm_step(wedm_ctx* ctx, int32_t n_substeps, const wedm_action_ptrs* act
     k.walk = nullptr;
     k.dbg = ctx->dbg;
 
-    // kernel 3 (one chunk per lane) and kernel 4 (two packed chunks per lane, table of 2L chunks)
-    int lanes = ctx->lanes ? ctx->lanes : auto_lanes(ctx);
-    const int li = lanes_index(lanes);
+    // kernel 3 (one chunk per lane) and kernel 4 (two packed chunks per lane, table of 2L chunks).
+    // Auto-selection by a small cost model fitted to measurements:
+    //   cycles per step ~ rounds * (4500 + tiles_per_lane * 8 * cell_cost),
+    //   rounds = ceil(blocks / (256 CUs * resident blocks per CU)), resident = min(2 [VGPRs], LDS fit),
+    //   cell_cost = 90 per cell, a packed pair = 2 * 90 * 0.93.
     const bool uniform = !ctx->p.per_env_geometry && ctx->walk_dev;
+    int lanes = ctx->lanes, planes = ctx->lanes;
+    {
+        double best3 = 1e300, best4 = 1e300;
+        int l3 = 0, l4 = 0;
+        const int Ls[5] = {1, 2, 4, 8, 16};
+        for (int i = 0; i < 5 && uniform; ++i) {
+            const int Lc = Ls[i];
+            const long blocks = (ctx->num_envs + (256 / Lc) - 1) / (256 / Lc);
+            if (ctx->walk_ok[i]) {  // kernel 3 with Lc lanes: table i
+                const size_t lds = ((size_t)ctx->walk_C[i] + 1) * 1024;
+                if (lds <= (size_t)ctx->lds_limit) {
+                    const long rb = std::min<long>(2, (long)(160 * 1024 / lds));
+                    const long rounds = (blocks + 256 * rb - 1) / (256 * rb);
+                    const double cost = rounds * (4500.0 + ((ctx->walk_C[i] + 7) / 8) * 8 * 90.0);
+                    if (cost < best3) { best3 = cost; l3 = Lc; }
+                }
+            }
+            if (Lc <= 8 && ctx->walk_ok[lanes_index(2 * Lc)]) {  // kernel 4 with Lc lanes: table of 2*Lc chunks
+                const int ti = lanes_index(2 * Lc);
+                const size_t lds = (2 * (size_t)ctx->walk_C[ti] + 2) * 1024;
+                if (lds <= (size_t)ctx->lds_limit) {
+                    const long rb = std::min<long>(2, (long)(160 * 1024 / lds));
+                    const long rounds = (blocks + 256 * rb - 1) / (256 * rb);
+                    const double cost = rounds * (4500.0 + ((ctx->walk_C[ti] + 7) / 8) * 8 * 2 * 90.0 * 0.93);
+                    if (cost < best4) { best4 = cost; l4 = Lc; }
+                }
+            }
+        }
+        if (!lanes) lanes = l3;
+        if (!planes) planes = l4;
+        ctx->auto_prefers_packed = best4 <= best3;
+    }
+    const int li = lanes_index(lanes);
     const bool fused_ok = uniform && li >= 0 && ctx->walk_ok[li] &&
                           ((size_t)ctx->walk_C[li] + 1) * 1024 <= (size_t)ctx->lds_limit;
-    int planes = ctx->lanes ? ctx->lanes : auto_lanes_packed(ctx);
     const int pli = (planes >= 1 && planes <= 8) ? lanes_index(2 * planes) : -1;
     const bool packed_ok = uniform && pli >= 0 && ctx->walk_ok[pli] &&
                            (2 * (size_t)ctx->walk_C[pli] + 2) * 1024 <= (size_t)ctx->lds_limit;
@@ -1343,12 +1340,9 @@ int32_t wedm_step(wedm_ctx* ctx, int32_t n_substeps, const wedm_action_ptrs* act
     const bool lanes_ok = glanes > 0;
     int variant = ctx->variant;
     if (variant == 0) {
-        // single-microsecond launches: the global-memory kernel (measured 37 us vs 50+ us staged);
-        // fused launches: packed when it puts ~2 waves on every SIMD, else whichever of
-        // packed / one-chunk-per-lane yields more waves (small batches want more lanes)
-        const auto waves_for = [&](int l) { return (long)((ctx->num_envs + (256 / l) - 1) / (256 / l)) * 4; };
+        // single-microsecond launches: the global-memory kernel (measured 37 us vs 50+ us staged)
         if (n_substeps <= 1) variant = 1;
-        else if (packed_ok && (waves_for(planes) >= 2048 || !fused_ok || waves_for(planes) >= waves_for(lanes))) variant = 4;
+        else if (packed_ok && (ctx->auto_prefers_packed || !fused_ok)) variant = 4;
         else if (fused_ok) variant = 3;
         else variant = lanes_ok ? 2 : 1;
     }
