@@ -789,7 +789,12 @@ __global__ void __launch_bounds__(256, 2) wedm_step_packed(const KArgs k) {
             };
             auto tile = [&](int t, f2 (&cur)[8], f2 (&nxt)[8]) {
                 const int r0 = 8 * t;
-                if (t + 1 < n_tiles) load8(nxt, r0 + 8);
+                // One buffer only: the tile's eight "next" pairs are loaded at the tile's start.  A
+                // second (prefetch) buffer cost 16 VGPRs, pushed the kernel into scratch spills
+                // (236 B/lane, ~30 GB of L2 traffic per launch) and was 7 % slower; the other wave of
+                // the SIMD covers the LDS latency instead.
+                (void)nxt;
+                load8(cur, r0);
                 const f2 conv_lo = {((zlA >> t) & 1u) ? cz : cb, ((zlB >> t) & 1u) ? cz : cb};
                 const f2 jfe_lo = {((jlA >> t) & 1u) ? jf_lane : 0.0f, ((jlB >> t) & 1u) ? jf_lane : 0.0f};
                 if (((kind_n & ~slow_now) >> t) & 1u) {
@@ -882,12 +887,8 @@ __global__ void __launch_bounds__(256, 2) wedm_step_packed(const KArgs k) {
                     }
                 }
             };
-            f2 bufA[8], bufB[8];
-            load8(bufA, 0);
-            for (int t = 0; t < n_tiles; t += 2) {
-                tile(t, bufA, bufB);
-                if (t + 1 < n_tiles) tile(t + 1, bufB, bufA);
-            }
+            f2 bufA[8];
+            for (int t = 0; t < n_tiles; ++t) tile(t, bufA, bufA);
         }
         WEDM_STAMP(st2);
         // ---- patches (after every store of the walk): boundary condition, last cell, plasma cell
