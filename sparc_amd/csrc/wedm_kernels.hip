@@ -497,9 +497,10 @@ __global__ void __launch_bounds__(256, 2) wedm_step_fused(const KArgs k) {
                     dst[u] = col[row * 256];
                 }
             };
-            auto tile = [&](int t, const float (&cur)[8], float (&nxt)[8]) {
+            auto tile = [&](int t, float (&cur)[8], float (&nxt)[8]) {
                 const int j = 8 * t;
-                if (t + 1 < n_tiles) load8(nxt, j + 8);
+                (void)nxt;
+                load8(cur, j);
                 const float conv_lo = ((zone_lo >> t) & 1u) ? ps.conv_zone : ps.conv_base;
                 const float jfe_lo = ((joule_lo >> t) & 1u) ? jf_lane : 0.0f;
 #ifdef WEDM_STAMPS_TILES
@@ -582,12 +583,8 @@ __global__ void __launch_bounds__(256, 2) wedm_step_fused(const KArgs k) {
                 if (tkind == 0) { accN += tk1 - tk0; ++cntN; } else if (tkind == 1) { accB += tk1 - tk0; ++cntB; } else { accS += tk1 - tk0; ++cntS; }
 #endif
             };
-            float bufA[8], bufB[8];
-            load8(bufA, 0);
-            for (int t = 0; t < n_tiles; t += 2) {
-                tile(t, bufA, bufB);
-                if (t + 1 < n_tiles) tile(t + 1, bufB, bufA);
-            }
+            float bufA[8];
+            for (int t = 0; t < n_tiles; ++t) tile(t, bufA, bufA);
         }
         WEDM_STAMP(st2);
         // ---- patches (after every store of the walk): boundary condition, last cell, plasma cell
