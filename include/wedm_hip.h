@@ -35,7 +35,7 @@
 extern "C" {
 #endif
 
-#define WEDM_ABI_VERSION 1
+#define WEDM_ABI_VERSION 2
 
 /* ------------------------------------------------------------------ status */
 typedef enum wedm_status {
@@ -222,6 +222,29 @@ typedef struct wedm_action_ptrs {
     const int32_t* current_mode;   /* -> state.current_mode "I<n>" */
 } wedm_action_ptrs;
 
+/* Device-side signal trace: while wedm_step runs, the kernels copy the selected rows of the
+ * state blocks (and optionally the whole wire temperature) of a contiguous range of
+ * environments into caller-owned ring buffers every `every` microseconds.  Replaces the
+ * per-microsecond `SimulationLogger.collect(env.state, info)` of the reference driver
+ * (utils/logger.py:110-160, experiments/run_simulation.py:257) and its 1 ms voltage history
+ * (run_simulation.py:262-270) without leaving the fused launch.  Sample m (1-based count of
+ * microseconds stepped since wedm_bind_trace) is taken after the step when m % every == 0 and
+ * lands in ring slot (m / every - 1) % capacity.  Rows are packed in ascending row order.   */
+typedef struct wedm_trace_desc {
+    double* f64;        /* [capacity][popcount(f64_mask)][env_count], NULL iff f64_mask == 0 */
+    int32_t* i32;       /* [capacity][popcount(i32_mask)][env_count], NULL iff i32_mask == 0 */
+    int8_t* i8;         /* [capacity][popcount(i8_mask) ][env_count], NULL iff i8_mask  == 0 */
+    float* T;           /* [capacity][n_seg_max][env_count] or NULL (no temperature trace)   */
+    uint32_t f64_mask;  /* bit r: record row r of wedm_f64_field */
+    uint32_t i32_mask;  /* bit r: record row r of wedm_i32_field */
+    uint32_t i8_mask;   /* bit r: record row r of wedm_i8_field  */
+    int32_t env_lo;     /* first traced environment (local index) */
+    int32_t env_count;  /* number of traced environments          */
+    int32_t every;      /* sample period in microseconds, >= 1    */
+    int32_t capacity;   /* ring capacity in samples, >= 1         */
+    int32_t reserved0;
+} wedm_trace_desc;
+
 typedef struct wedm_ctx wedm_ctx;
 
 /* version of this header the library was built against */
@@ -246,6 +269,14 @@ int32_t wedm_reset(wedm_ctx* ctx, const uint8_t* mask, uint64_t seed, int32_t re
  * (wire_edm.py:116-157) with the same action.  n_substeps == 1 is the
  * reference's 1 us step.                                                      */
 int32_t wedm_step(wedm_ctx* ctx, int32_t n_substeps, const wedm_action_ptrs* action, void* stream);
+
+/* binds (desc != NULL) or removes (desc == NULL) the signal trace; resets the sample counter.
+ * Terminated environments keep being sampled (their frozen state).                        */
+int32_t wedm_bind_trace(wedm_ctx* ctx, const wedm_trace_desc* desc);
+
+/* samples written since wedm_bind_trace (host-side count; the ring holds the last
+ * min(count, capacity) of them, the newest in slot (count - 1) % capacity)                */
+int64_t wedm_trace_samples(wedm_ctx* ctx);
 
 /* selects the kernel used by wedm_step: 0 = auto, 1 = global-memory stencil (one pass
  * over T in HBM per substep), 2 = LDS-staged predicated stencil (any geometry),

@@ -23,7 +23,8 @@ from .modules.parameters import (
     WireModuleParameters,
 )
 
-from .controllers import GapController, run_controlled
+from .controllers import GapController, VoltageController, run_controlled
+from .trace import DeviceTrace
 from .utils.logger import LoggerConfig, SimulationLogger
 from .vector import WireEDMVectorEnv
 
@@ -33,7 +34,7 @@ __version__ = "0.1.0"
 
 __all__ = [
     "EDMState", "BatchedEDMState", "EnvironmentConfig", "MaterialDatabase", "WireMaterial", "get_material_db",
-    "WireEDMEnv", "DeviceAction", "WireEDMVectorEnv", "GapController", "run_controlled",
+    "WireEDMEnv", "DeviceAction", "WireEDMVectorEnv", "GapController", "VoltageController", "run_controlled", "DeviceTrace",
     "SimulationLogger", "LoggerConfig",
     "IgnitionModuleParameters", "WireModuleParameters", "MaterialModuleParameters",
     "DielectricModuleParameters", "MechanicsModuleParameters",

@@ -9,7 +9,7 @@ from __future__ import annotations
 import ctypes as C
 import enum
 
-ABI_VERSION = 1
+ABI_VERSION = 2
 MAX_MODE = 19
 
 # status codes -----------------------------------------------------------------
@@ -192,4 +192,15 @@ class ActionPtrs(C.Structure):
     _fields_ = [
         ("servo", C.c_void_p), ("target_voltage", C.c_void_p), ("on_time", C.c_void_p),
         ("off_time", C.c_void_p), ("current_mode", C.c_void_p),
+    ]
+
+
+class TraceDesc(C.Structure):
+    """``struct wedm_trace_desc``."""
+
+    _fields_ = [
+        ("f64", C.c_void_p), ("i32", C.c_void_p), ("i8", C.c_void_p), ("T", C.c_void_p),
+        ("f64_mask", C.c_uint32), ("i32_mask", C.c_uint32), ("i8_mask", C.c_uint32),
+        ("env_lo", C.c_int32), ("env_count", C.c_int32), ("every", C.c_int32), ("capacity", C.c_int32),
+        ("reserved0", C.c_int32),
     ]

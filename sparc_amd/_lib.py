@@ -56,6 +56,10 @@ def load() -> C.CDLL:
     L.wedm_reset.restype = C.c_int32
     L.wedm_step.argtypes = [ctx, C.c_int32, C.POINTER(_abi.ActionPtrs), C.c_void_p]
     L.wedm_step.restype = C.c_int32
+    L.wedm_bind_trace.argtypes = [ctx, C.POINTER(_abi.TraceDesc)]
+    L.wedm_bind_trace.restype = C.c_int32
+    L.wedm_trace_samples.argtypes = [ctx]
+    L.wedm_trace_samples.restype = C.c_int64
     L.wedm_set_kernel.argtypes = [ctx, C.c_int32]
     L.wedm_set_kernel.restype = C.c_int32
     L.wedm_set_lanes.argtypes = [ctx, C.c_int32]
@@ -72,7 +76,7 @@ def load() -> C.CDLL:
 
 EXPORTS = (
     "wedm_abi_version", "wedm_create", "wedm_destroy", "wedm_bind_state", "wedm_bind_geometry",
-    "wedm_reset", "wedm_step", "wedm_set_kernel", "wedm_set_lanes", "wedm_last_kernel", "wedm_last_error",
+    "wedm_reset", "wedm_step", "wedm_bind_trace", "wedm_trace_samples", "wedm_set_kernel", "wedm_set_lanes", "wedm_last_kernel", "wedm_last_error",
     "wedm_sizeof_params", "wedm_debug_math",
 )
 
@@ -117,6 +121,13 @@ class HipBackend:
 
     def step(self, n_substeps: int, action: _abi.ActionPtrs) -> None:
         self._check(self._L.wedm_step(self._ctx, n_substeps, C.byref(action), self._stream()))
+
+    def bind_trace(self, desc) -> None:
+        """`desc` is an `_abi.TraceDesc` or None (unbind)."""
+        self._check(self._L.wedm_bind_trace(self._ctx, C.byref(desc) if desc is not None else None))
+
+    def trace_samples(self) -> int:
+        return int(self._L.wedm_trace_samples(self._ctx))
 
     def set_kernel(self, variant: int) -> None:
         self._check(self._L.wedm_set_kernel(self._ctx, variant))

@@ -61,6 +61,9 @@ class BatchedEDMState:
         object.__setattr__(self, "b", self.i8.view(torch.bool))  # zero-copy 0/1 view of the flags
         object.__setattr__(self, "T", torch.zeros((n_seg_max, stride), dtype=torch.float32, **kw))
         object.__setattr__(self, "obs", torch.zeros((max(obs_dim, 1), stride), dtype=torch.float32, **kw))
+        # read-only attributes computed on access (registered by the environment):
+        # dielectric_flow_rate (dielectric.py:160-162), wire_average_temperature (wire.py:339-347)
+        object.__setattr__(self, "derived", {})
 
     # ------------------------------------------------------------------ views
     def _view(self, name: str) -> torch.Tensor:
@@ -70,6 +73,9 @@ class BatchedEDMState:
     def __getattr__(self, name: str):
         if name in _FIELDS:
             return self._view(name)
+        derived = self.__dict__.get("derived", {})
+        if name in derived:
+            return derived[name]()
         raise AttributeError(name)
 
     def __setattr__(self, name: str, value) -> None:

@@ -223,6 +223,7 @@ struct Cold {  // everything reachable only through rare branches
     wedm_action_ptrs a;
     wedm_state_ptrs s;
     Tables tb;
+    const wedm_trace_desc* tr;  // device copy of the bound trace descriptor (NULL: none)
 };
 
 // Hide a pointer from loop-invariant code motion: loads through the result cannot be
@@ -299,6 +300,99 @@ __device__ __forceinline__ void store_env(const wedm_state_ptrs& s, int64_t e, c
     *WEDM_ROW(s.i8, WEDM_B_WIRE_BROKEN) = (int8_t)v.broken; *WEDM_ROW(s.i8, WEDM_B_TARGET_REACHED) = (int8_t)v.reached;
     *WEDM_ROW(s.i8, WEDM_B_DONE) = (int8_t)v.done; *WEDM_ROW(s.i8, WEDM_B_CTRL_STEP) = (int8_t)v.ctrl;
     *WEDM_ROW(s.i8, WEDM_B_ERROR) = (int8_t)v.err;
+}
+
+// ----------------------------------------------------------------- signal trace
+// Row r of each state block as the registers hold it (the value store_env would write).
+__device__ __forceinline__ double env_f64_row(const Env& v, int row) {
+    switch (row) {
+        case WEDM_F_WORKPIECE_POS: return v.wp;
+        case WEDM_F_WIRE_POS: return v.x;
+        case WEDM_F_WIRE_VEL: return v.v;
+        case WEDM_F_PREV_ACCEL: return v.prev_a;
+        case WEDM_F_DEBRIS_VOLUME: return v.debris;
+        case WEDM_F_DEBRIS_DENSITY: return v.rho;
+        case WEDM_F_FLOW: return v.flow;
+        case WEDM_F_LAST_GAP: return v.last_gap;
+        case WEDM_F_LAST_DENSITY: return v.last_rho;
+        case WEDM_F_WIRE_LAST_FLOW: return v.wire_last_flow;
+        case WEDM_F_VOLTAGE: return v.V;
+        case WEDM_F_CURRENT: return v.I;
+        case WEDM_F_SPARK_Y: return v.y;
+        case WEDM_F_LAST_CRATER: return v.last_crater;
+        case WEDM_F_CAVITY: return v.cavity;
+        case WEDM_F_TARGET_DELTA: return v.tdelta;
+        case WEDM_F_TARGET_VOLTAGE: return v.tvolt;
+        case WEDM_F_ON_TIME: return v.on;
+        case WEDM_F_OFF_TIME: return v.off;
+        case WEDM_F_TARGET_POS: return v.tpos;
+        case WEDM_F_UNWIND_VEL: return v.unwind;
+        case WEDM_F_H_BASE: return (double)v.h_base;
+        case WEDM_F_H_ZONE: return (double)v.h_zone;
+        case WEDM_F_TMAX: return (double)v.tmax;
+    }
+    return 0.0;
+}
+__device__ __forceinline__ int32_t env_i32_row(const Env& v, int row) {
+    switch (row) {
+        case WEDM_I_TIME: return v.time;
+        case WEDM_I_SINCE_SERVO: return v.tss;
+        case WEDM_I_SINCE_OPEN_V: return v.tsov;
+        case WEDM_I_SINCE_IGNITION: return v.tsi;
+        case WEDM_I_SINCE_SPARK_END: return v.tse;
+        case WEDM_I_SPARK_DUR: return v.dur;
+        case WEDM_I_RANDOM_SHORT_REM: return v.rnd_rem;
+        case WEDM_I_DEBRIS_SHORT_REM: return v.deb_rem;
+        case WEDM_I_TIME_CRITICAL: return v.tcrit;
+        case WEDM_I_CURRENT_MODE: return v.mode;
+        case WEDM_I_EPISODE: return v.episode;
+        case WEDM_I_KEY_LO: return (int32_t)v.key0;
+        case WEDM_I_KEY_HI: return (int32_t)v.key1;
+        case WEDM_I_SPARK_COUNT: return v.sparks;
+    }
+    return 0;
+}
+__device__ __forceinline__ int32_t env_i8_row(const Env& v, int row) {
+    switch (row) {
+        case WEDM_B_SPARK_STATE: return v.state;
+        case WEDM_B_IS_SHORT: return v.is_short;
+        case WEDM_B_WIRE_BROKEN: return v.broken;
+        case WEDM_B_TARGET_REACHED: return v.reached;
+        case WEDM_B_DONE: return v.done;
+        case WEDM_B_CTRL_STEP: return v.ctrl;
+        case WEDM_B_ERROR: return v.err;
+    }
+    return 0;
+}
+
+// Column of environment e in the trace buffers, or -1 when it is not traced.
+__device__ __forceinline__ int64_t trace_column(const wedm_trace_desc* tr, int64_t e) {
+    const int64_t col = e - tr->env_lo;
+    return (col >= 0 && col < tr->env_count) ? col : -1;
+}
+
+// The selected scalar rows of one environment into ring slot `slot` (one lane per environment).
+__device__ __forceinline__ void trace_scalars(const wedm_trace_desc* tr, int64_t col, const Env& v, int slot) {
+    const int64_t cnt = tr->env_count;
+    const uint32_t mf = tr->f64_mask, mi = tr->i32_mask, mb = tr->i8_mask;
+    if (mf) {
+        double* dst = tr->f64 + (int64_t)slot * __builtin_popcount(mf) * cnt + col;
+#pragma unroll
+        for (int r = 0; r < WEDM_F64_COUNT; ++r)
+            if ((mf >> r) & 1u) { *dst = env_f64_row(v, r); dst += cnt; }
+    }
+    if (mi) {
+        int32_t* dst = tr->i32 + (int64_t)slot * __builtin_popcount(mi) * cnt + col;
+#pragma unroll
+        for (int r = 0; r < WEDM_I32_COUNT; ++r)
+            if ((mi >> r) & 1u) { *dst = env_i32_row(v, r); dst += cnt; }
+    }
+    if (mb) {
+        int8_t* dst = tr->i8 + (int64_t)slot * __builtin_popcount(mb) * cnt + col;
+#pragma unroll
+        for (int r = 0; r < WEDM_I8_COUNT; ++r)
+            if ((mb >> r) & 1u) { *dst = (int8_t)env_i8_row(v, r); dst += cnt; }
+    }
 }
 
 __device__ __forceinline__ void load_geom(const Hot& hot, const Cold& cold, int64_t e, Geom& g) {

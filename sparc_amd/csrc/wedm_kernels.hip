@@ -27,6 +27,8 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <climits>
+#include <cstdint>
 #include <cstdio>
 #include <cstring>
 #include <new>
@@ -68,8 +70,37 @@ struct KArgs {
     int32_t n_substeps;
     int32_t n_seg_max;
     const WalkTable* walk;  // device copy of the table for the L in use (fused kernel only)
+    int32_t trace_next;     // substep index after which the next trace sample is due (INT32_MAX: no trace)
+    int32_t trace_slot;     // ring slot of that sample
     unsigned long long* dbg; // diagnostic builds only (WEDM_STAMPS): per-wave phase cycle sums
 };
+
+// ------------------------------------------------------------ signal trace
+// The sample schedule is host-made and identical for every wave: `it == trace_next` is a scalar
+// compare per microsecond; the descriptor is only touched inside the (rare) branch.  While a
+// trace is due in this launch the kernels keep iterating over terminated environments so that
+// every slot receives a sample (their frozen state).
+// Kernels are instantiated with and without the trace point (template parameter TRACE): the
+// inlined sampling code costs the packed kernel 4 more spilled VGPRs (scratch 80 -> 100 B/lane)
+// and the global kernel half its occupancy, so launches without a bound trace run the
+// instantiation that does not contain it.
+#define WEDM_TRACING(k) (TRACE && (k).trace_next < (k).n_substeps)
+// CELLS: statement that copies this lane's wire cells, given `tT` (slot base + column) and `tcnt`
+#define WEDM_TRACE_POINT(k, it, e, s, SCALAR_LANE, CELLS)                                        \
+    if (TRACE && (it) == trace_next) {                                                           \
+        const wedm_trace_desc* tr = opaque((k).cold.tr);                                         \
+        const int64_t tcol = trace_column(tr, (e));                                              \
+        if (tcol >= 0) {                                                                         \
+            if (SCALAR_LANE) trace_scalars(tr, tcol, (s), trace_slot);                           \
+            if (tr->T) {                                                                         \
+                const int64_t tcnt = tr->env_count;                                              \
+                float* tT = tr->T + (int64_t)trace_slot * (k).n_seg_max * tcnt + tcol;           \
+                CELLS;                                                                           \
+            }                                                                                    \
+        }                                                                                        \
+        trace_next += tr->every;                                                                 \
+        trace_slot = (trace_slot + 1 == tr->capacity) ? 0 : trace_slot + 1;                      \
+    }
 
 // ------------------------------------------------------------ T accessors
 struct GlobalT {
@@ -113,31 +144,40 @@ __device__ __forceinline__ float stencil_pass(const TA& T, const Geom& g, const 
     return tmax;
 }
 
-template <class TA>
+template <bool TRACE, class TA>
 __device__ __forceinline__ void run_substeps(const KArgs& k, const Geom& g, int64_t e, uint32_t gid, Env& s,
                                              const TA& T) {
     Persist ps;
     init_persist(k.hot, k.cold, e, s, ps);
+    const bool tracing = WEDM_TRACING(k);
+    int trace_next = k.trace_next, trace_slot = k.trace_slot;
+    (void)trace_next; (void)trace_slot;
     for (int it = 0; it < k.n_substeps; ++it) {
-        if (s.done) break;
-        Coef c = scalar_prelude(k.hot, k.cold, g, e, gid, s, ps);  // single steps: the quiet test does not pay
-        float tmax = stencil_pass(T, g, c, ps, k.hot.spool, k.hot.tref, k.hot.alpha, k.hot.tdiel);
-        scalar_epilogue(k.hot, s, tmax);
-        if (s.ctrl) write_obs(k.cold, e, s);
+        if (!s.done) {
+            Coef c = scalar_prelude(k.hot, k.cold, g, e, gid, s, ps);  // single steps: the quiet test does not pay
+            float tmax = stencil_pass(T, g, c, ps, k.hot.spool, k.hot.tref, k.hot.alpha, k.hot.tdiel);
+            scalar_epilogue(k.hot, s, tmax);
+            if (s.ctrl) write_obs(k.cold, e, s);
+        } else if (!tracing) {
+            break;
+        }
+        WEDM_TRACE_POINT(k, it, e, s, true,
+                         for (int i = 0; i < g.n_seg; ++i) tT[(int64_t)i * tcnt] = T.ld(i));
     }
 }
 
+template <bool TRACE>
 __global__ void __launch_bounds__(256) wedm_step_global(const KArgs k) {
     const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (e >= k.num_envs) return;
     Env s;
     load_env(k.cold.s, e, s);
-    if (s.done) return;
-    s.ipk = peak_current(k.cold, s.mode);
+    if (s.done && !WEDM_TRACING(k)) return;
+    s.ipk = s.done ? 0.0 : peak_current(k.cold, s.mode);
     Geom g;
     load_geom(k.hot, k.cold, e, g);
     GlobalT T{k.cold.s.T + e, k.cold.s.stride};
-    run_substeps(k, g, e, k.hot.env_id_offset + (uint32_t)e, s, T);
+    run_substeps<TRACE>(k, g, e, k.hot.env_id_offset + (uint32_t)e, s, T);
     store_env(k.cold.s, e, s);
 }
 
@@ -148,7 +188,7 @@ __device__ __forceinline__ float fmax_gt(float a, float b) { return __builtin_fm
 // predicated formula with the lane's own n_seg / zone / contact indices.  LDS layout and halo
 // exchange as in the fused kernels; the chunk length is uniform, C = ceil(n_seg_max / L), so an
 // environment with a shorter wire simply leaves the tail of its last chunks unused.
-template <int L>
+template <int L, bool TRACE>
 __global__ void __launch_bounds__(256, 2) wedm_step_lanes(const KArgs k) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     constexpr int EPB = 256 / L;
@@ -192,8 +232,11 @@ __global__ void __launch_bounds__(256, 2) wedm_step_lanes(const KArgs k) {
     const float spool = k.hot.spool, tref = k.hot.tref, alpha = k.hot.alpha, tdiel = k.hot.tdiel;
     if (c == 0) col[0] = spool;
 
+    const bool tracing = WEDM_TRACING(k);
+    int trace_next = k.trace_next, trace_slot = k.trace_slot;
+    (void)trace_next; (void)trace_slot;
     for (int it = 0; it < k.n_substeps; ++it) {
-        if (__all(s.done)) break;
+        if (__all(s.done) && !tracing) break;
         Coef cf{0.0f, 0.0f, 0, -1};
         if (!quiet_prelude(k.hot, g, gid, s) && !s.done) cf = scalar_prelude(k.hot, k.cold, g, e, gid, s, ps);
         const float halo_l = (c > 0) ? col[(C - 1) * 256 - 1] : spool;
@@ -228,6 +271,8 @@ __global__ void __launch_bounds__(256, 2) wedm_step_lanes(const KArgs k) {
             scalar_epilogue(k.hot, s, tmax);
             if (s.ctrl && c == 0) write_obs(k.cold, e, s);
         }
+        WEDM_TRACE_POINT(k, it, e, s, c == 0,
+                         for (int j = 0; j < C && cbase + j < n; ++j) tT[(int64_t)(cbase + j) * tcnt] = col[j * 256]);
     }
 
     __syncthreads();
@@ -367,7 +412,7 @@ __device__ __forceinline__ void tile8_staged(const V (&old)[10], V (&tn)[8], flo
         tile_staged<V, JOULE, PERCELL, WEDM_STAGE_W>(old, tn, o, k, tuf, conv, tdiel, adv, jfe, alpha, tref);
 }
 
-template <int L>
+template <int L, bool TRACE>
 __global__ void __launch_bounds__(256, 2) wedm_step_fused(const KArgs k) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     constexpr int EPB = 256 / L;  // environments per block
@@ -437,8 +482,11 @@ __global__ void __launch_bounds__(256, 2) wedm_step_fused(const KArgs k) {
     const bool owns_last = (n >= 2) && (n - 1 >= cbase) && (n - 1 < cbase + C);
 
     WEDM_STAMP_DECL;
+    const bool tracing = WEDM_TRACING(k);
+    int trace_next = k.trace_next, trace_slot = k.trace_slot;
+    (void)trace_next; (void)trace_slot;
     for (int it = 0; it < k.n_substeps; ++it) {
-        if (__all(s.done)) break;
+        if (__all(s.done) && !tracing) break;
         WEDM_STAMP(st0);
         Coef cf{0.0f, 0.0f, 0, -1};
         if (!quiet_prelude(k.hot, g, gid, s) && !s.done) cf = scalar_prelude(k.hot, k.cold, g, e, gid, s, ps);
@@ -604,6 +652,8 @@ __global__ void __launch_bounds__(256, 2) wedm_step_fused(const KArgs k) {
             scalar_epilogue(k.hot, s, tmax);
             if (s.ctrl && c == 0) write_obs(k.cold, e, s);
         }
+        WEDM_TRACE_POINT(k, it, e, s, c == 0,
+                         for (int j = 0; j < C && cbase + j < n; ++j) tT[(int64_t)(cbase + j) * tcnt] = col[j * 256]);
         WEDM_STAMP(st4);
         WEDM_STAMP_ACC();
     }
@@ -650,7 +700,7 @@ __device__ __forceinline__ f2 interior2(f2 tm1, f2 tc, f2 tp1, float k, float tu
     return tc + d * tuf;
 }
 
-template <int L>
+template <int L, bool TRACE>
 __global__ void __launch_bounds__(256, 2) wedm_step_packed(const KArgs k) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     constexpr int EPB = 256 / L;
@@ -725,8 +775,11 @@ __global__ void __launch_bounds__(256, 2) wedm_step_packed(const KArgs k) {
     const int own_last = (n >= 2) ? owner(n - 1) : 0;
 
     WEDM_STAMP_DECL;
+    const bool tracing = WEDM_TRACING(k);
+    int trace_next = k.trace_next, trace_slot = k.trace_slot;
+    (void)trace_next; (void)trace_slot;
     for (int it = 0; it < k.n_substeps; ++it) {
-        if (__all(s.done)) break;
+        if (__all(s.done) && !tracing) break;
         WEDM_STAMP(st0);
         Coef cf{0.0f, 0.0f, 0, -1};
         if (!quiet_prelude(k.hot, g, gid, s) && !s.done) cf = scalar_prelude(k.hot, k.cold, g, e, gid, s, ps);
@@ -907,6 +960,11 @@ __global__ void __launch_bounds__(256, 2) wedm_step_packed(const KArgs k) {
             scalar_epilogue(k.hot, s, tmax);
             if (s.ctrl && c == 0) write_obs(k.cold, e, s);
         }
+        WEDM_TRACE_POINT(k, it, e, s, c == 0,
+                         for (int r = 0; r < Cv; ++r) {
+                             if (baseA + r < n) tT[(int64_t)(baseA + r) * tcnt] = col[(2 * r) * 256];
+                             if (baseB + r < n) tT[(int64_t)(baseB + r) * tcnt] = col[(2 * r + 1) * 256];
+                         });
         WEDM_STAMP(st4);
         WEDM_STAMP_ACC();
     }
@@ -1007,6 +1065,12 @@ struct wedm_ctx {
     WalkTable* walk_dev = nullptr;     // [5] tables for L = 1, 2, 4, 8, 16
     bool walk_ok[5] = {false, false, false, false, false};
     int32_t walk_C[5] = {0, 0, 0, 0, 0};
+    // signal trace (wedm_bind_trace): descriptor, its device copy, microseconds stepped and samples
+    // written since the bind
+    bool trace_on = false;
+    wedm_trace_desc trace{};
+    wedm_trace_desc* trace_dev = nullptr;
+    int64_t trace_us = 0, trace_count = 0;
     std::string err;
     std::string last_kernel;
 };
@@ -1060,6 +1124,33 @@ static bool build_walk(const wedm_params& p, int L, WalkTable& t) {
         else t.kind[tile] = TILE_B;
     }
     return true;
+}
+
+template <bool TR> static const void* pick_lanes(int L) {
+    switch (L) {
+        case 1: return (const void*)wedm_step_lanes<1, TR>;
+        case 2: return (const void*)wedm_step_lanes<2, TR>;
+        case 4: return (const void*)wedm_step_lanes<4, TR>;
+        case 8: return (const void*)wedm_step_lanes<8, TR>;
+        default: return (const void*)wedm_step_lanes<16, TR>;
+    }
+}
+template <bool TR> static const void* pick_fused(int L) {
+    switch (L) {
+        case 1: return (const void*)wedm_step_fused<1, TR>;
+        case 2: return (const void*)wedm_step_fused<2, TR>;
+        case 4: return (const void*)wedm_step_fused<4, TR>;
+        case 8: return (const void*)wedm_step_fused<8, TR>;
+        default: return (const void*)wedm_step_fused<16, TR>;
+    }
+}
+template <bool TR> static const void* pick_packed(int L) {
+    switch (L) {
+        case 1: return (const void*)wedm_step_packed<1, TR>;
+        case 2: return (const void*)wedm_step_packed<2, TR>;
+        case 4: return (const void*)wedm_step_packed<4, TR>;
+        default: return (const void*)wedm_step_packed<8, TR>;
+    }
 }
 
 static int lanes_index(int L) { return L == 1 ? 0 : L == 2 ? 1 : L == 4 ? 2 : L == 8 ? 3 : L == 16 ? 4 : -1; }
@@ -1177,6 +1268,7 @@ int32_t wedm_destroy(wedm_ctx* ctx) {
     if (ctx->tables_dev) (void)hipFree(ctx->tables_dev);
     if (ctx->walk_dev) (void)hipFree(ctx->walk_dev);
     if (ctx->params_dev) (void)hipFree(ctx->params_dev);
+    if (ctx->trace_dev) (void)hipFree(ctx->trace_dev);
     delete ctx;
     return WEDM_OK;
 }
@@ -1199,6 +1291,38 @@ int32_t wedm_bind_geometry(wedm_ctx* ctx, const wedm_geom_ptrs* geom) {
     ctx->geom_bound = true;
     return WEDM_OK;
 }
+
+int32_t wedm_bind_trace(wedm_ctx* ctx, const wedm_trace_desc* desc) {
+    if (!ctx) return WEDM_ERR_BAD_ARG;
+    ctx->trace_on = false;
+    ctx->trace_us = ctx->trace_count = 0;
+    if (!desc) return WEDM_OK;
+    const uint32_t f64_all = (1u << WEDM_F64_COUNT) - 1u, i32_all = (1u << WEDM_I32_COUNT) - 1u,
+                   i8_all = (1u << WEDM_I8_COUNT) - 1u;
+    if ((desc->f64_mask & ~f64_all) || (desc->i32_mask & ~i32_all) || (desc->i8_mask & ~i8_all))
+        return fail(ctx, WEDM_ERR_BAD_ARG, "wedm_bind_trace: mask names a row that does not exist");
+    if ((desc->f64_mask != 0) != (desc->f64 != nullptr) || (desc->i32_mask != 0) != (desc->i32 != nullptr) ||
+        (desc->i8_mask != 0) != (desc->i8 != nullptr))
+        return fail(ctx, WEDM_ERR_BAD_ARG, "wedm_bind_trace: a buffer must be given exactly for the non-empty masks");
+    if (!desc->f64_mask && !desc->i32_mask && !desc->i8_mask && !desc->T)
+        return fail(ctx, WEDM_ERR_BAD_ARG, "wedm_bind_trace: nothing selected");
+    if (desc->every < 1 || desc->capacity < 1)
+        return fail(ctx, WEDM_ERR_BAD_ARG, "wedm_bind_trace: every and capacity must be >= 1");
+    if (desc->env_lo < 0 || desc->env_count < 1 || (int64_t)desc->env_lo + desc->env_count > ctx->num_envs)
+        return fail(ctx, WEDM_ERR_BAD_ARG, "wedm_bind_trace: environment range outside [0, num_envs)");
+    hipError_t e;
+    if (!ctx->trace_dev && (e = hipMalloc((void**)&ctx->trace_dev, sizeof(wedm_trace_desc))) != hipSuccess)
+        return hip_fail(ctx, e, "hipMalloc(trace descriptor)");
+    // synchronous copy: a launch of an earlier wedm_step may still be reading the old descriptor
+    if ((e = hipDeviceSynchronize()) != hipSuccess) return hip_fail(ctx, e, "hipDeviceSynchronize");
+    if ((e = hipMemcpy(ctx->trace_dev, desc, sizeof(wedm_trace_desc), hipMemcpyHostToDevice)) != hipSuccess)
+        return hip_fail(ctx, e, "hipMemcpy(trace descriptor)");
+    ctx->trace = *desc;
+    ctx->trace_on = true;
+    return WEDM_OK;
+}
+
+int64_t wedm_trace_samples(wedm_ctx* ctx) { return ctx ? ctx->trace_count : 0; }
 
 int32_t wedm_set_kernel(wedm_ctx* ctx, int32_t variant) {
     if (!ctx) return WEDM_ERR_BAD_ARG;
@@ -1276,6 +1400,14 @@ int32_t wedm_step(wedm_ctx* ctx, int32_t n_substeps, const wedm_action_ptrs* act
     k.n_seg_max = ctx->n_seg_max;
     k.walk = nullptr;
     k.dbg = ctx->dbg;
+    k.cold.tr = ctx->trace_dev;
+    k.trace_next = INT32_MAX;
+    k.trace_slot = 0;
+    if (ctx->trace_on) {
+        const int64_t every = ctx->trace.every;
+        k.trace_next = (int32_t)(every - ctx->trace_us % every - 1);  // 0-based substep of the next sample
+        k.trace_slot = (int32_t)(ctx->trace_count % ctx->trace.capacity);
+    }
 
     // kernel 3 (one chunk per lane) and kernel 4 (two packed chunks per lane, table of 2L chunks).
     // Auto-selection by a small cost model fitted to measurements:
@@ -1352,67 +1484,47 @@ int32_t wedm_step(wedm_ctx* ctx, int32_t n_substeps, const wedm_action_ptrs* act
         return fail(ctx, WEDM_ERR_UNSUPPORTED, "wedm_step: no lane count puts a chunk of the wire in LDS");
 
     char name[160];
+    const bool tr = ctx->trace_on && k.trace_next < n_substeps;  // a sample falls into this launch
+    const void* fn = nullptr;
+    int grid = 0;
+    size_t fl = 0;
     if (variant == 1) {
-        const int block = 256;
-        const int grid = (ctx->num_envs + block - 1) / block;
-        hipLaunchKernelGGL(wedm_step_global, dim3(grid), dim3(block), 0, (hipStream_t)stream, k);
-        std::snprintf(name, sizeof(name), "wedm_step_global<<<%d,%d>>> n_sub=%d", grid, block, n_substeps);
+        grid = (ctx->num_envs + 255) / 256;
+        fn = tr ? (const void*)wedm_step_global<true> : (const void*)wedm_step_global<false>;
+        std::snprintf(name, sizeof(name), "wedm_step_global<<<%d,256>>> n_sub=%d", grid, n_substeps);
     } else if (variant == 2) {
-        const int gl = glanes;
-        const int epb = 256 / gl;
-        const int grid = (ctx->num_envs + epb - 1) / epb;
-        const size_t fl = (size_t)((ctx->n_seg_max + gl - 1) / gl) * 1024;
-        const void* fn = gl == 1 ? (const void*)wedm_step_lanes<1> : gl == 2 ? (const void*)wedm_step_lanes<2>
-                       : gl == 4 ? (const void*)wedm_step_lanes<4> : gl == 8 ? (const void*)wedm_step_lanes<8>
-                                                                             : (const void*)wedm_step_lanes<16>;
-        hipError_t ea = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)fl);
-        if (ea != hipSuccess) return hip_fail(ctx, ea, "hipFuncSetAttribute(wedm_step_lanes)");
-        switch (gl) {
-            case 1: hipLaunchKernelGGL(wedm_step_lanes<1>, dim3(grid), dim3(256), fl, (hipStream_t)stream, k); break;
-            case 2: hipLaunchKernelGGL(wedm_step_lanes<2>, dim3(grid), dim3(256), fl, (hipStream_t)stream, k); break;
-            case 4: hipLaunchKernelGGL(wedm_step_lanes<4>, dim3(grid), dim3(256), fl, (hipStream_t)stream, k); break;
-            case 8: hipLaunchKernelGGL(wedm_step_lanes<8>, dim3(grid), dim3(256), fl, (hipStream_t)stream, k); break;
-            default: hipLaunchKernelGGL(wedm_step_lanes<16>, dim3(grid), dim3(256), fl, (hipStream_t)stream, k); break;
-        }
-        std::snprintf(name, sizeof(name), "wedm_step_lanes<%d><<<%d,256,%zuB>>> n_sub=%d", gl, grid, fl, n_substeps);
+        grid = (ctx->num_envs + 256 / glanes - 1) / (256 / glanes);
+        fl = (size_t)((ctx->n_seg_max + glanes - 1) / glanes) * 1024;
+        fn = tr ? pick_lanes<true>(glanes) : pick_lanes<false>(glanes);
+        std::snprintf(name, sizeof(name), "wedm_step_lanes<%d><<<%d,256,%zuB>>> n_sub=%d", glanes, grid, fl, n_substeps);
     } else if (variant == 4) {
-        const int epb = 256 / planes;
-        const int grid = (ctx->num_envs + epb - 1) / epb;
-        const size_t fl = (2 * (size_t)ctx->walk_C[pli] + 2) * 1024;
+        grid = (ctx->num_envs + 256 / planes - 1) / (256 / planes);
+        fl = (2 * (size_t)ctx->walk_C[pli] + 2) * 1024;
         k.walk = ctx->walk_dev + pli;
-        const void* fn = planes == 1 ? (const void*)wedm_step_packed<1> : planes == 2 ? (const void*)wedm_step_packed<2>
-                       : planes == 4 ? (const void*)wedm_step_packed<4> : (const void*)wedm_step_packed<8>;
-        hipError_t ea = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)fl);
-        if (ea != hipSuccess) return hip_fail(ctx, ea, "hipFuncSetAttribute(wedm_step_packed)");
-        switch (planes) {
-            case 1: hipLaunchKernelGGL(wedm_step_packed<1>, dim3(grid), dim3(256), fl, (hipStream_t)stream, k); break;
-            case 2: hipLaunchKernelGGL(wedm_step_packed<2>, dim3(grid), dim3(256), fl, (hipStream_t)stream, k); break;
-            case 4: hipLaunchKernelGGL(wedm_step_packed<4>, dim3(grid), dim3(256), fl, (hipStream_t)stream, k); break;
-            default: hipLaunchKernelGGL(wedm_step_packed<8>, dim3(grid), dim3(256), fl, (hipStream_t)stream, k); break;
-        }
+        fn = tr ? pick_packed<true>(planes) : pick_packed<false>(planes);
         std::snprintf(name, sizeof(name), "wedm_step_packed<%d><<<%d,256,%zuB>>> n_sub=%d", planes, grid, fl, n_substeps);
     } else {
-        const int epb = 256 / lanes;
-        const int grid = (ctx->num_envs + epb - 1) / epb;
-        const size_t fl = ((size_t)ctx->walk_C[li] + 1) * 1024;
+        grid = (ctx->num_envs + 256 / lanes - 1) / (256 / lanes);
+        fl = ((size_t)ctx->walk_C[li] + 1) * 1024;
         k.walk = ctx->walk_dev + li;
-        const void* fn = lanes == 1 ? (const void*)wedm_step_fused<1> : lanes == 2 ? (const void*)wedm_step_fused<2>
-                       : lanes == 4 ? (const void*)wedm_step_fused<4> : lanes == 8 ? (const void*)wedm_step_fused<8>
-                                                                                   : (const void*)wedm_step_fused<16>;
-        hipError_t ea = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)fl);
-        if (ea != hipSuccess) return hip_fail(ctx, ea, "hipFuncSetAttribute(wedm_step_fused)");
-        switch (lanes) {
-            case 1: hipLaunchKernelGGL(wedm_step_fused<1>, dim3(grid), dim3(256), fl, (hipStream_t)stream, k); break;
-            case 2: hipLaunchKernelGGL(wedm_step_fused<2>, dim3(grid), dim3(256), fl, (hipStream_t)stream, k); break;
-            case 4: hipLaunchKernelGGL(wedm_step_fused<4>, dim3(grid), dim3(256), fl, (hipStream_t)stream, k); break;
-            case 8: hipLaunchKernelGGL(wedm_step_fused<8>, dim3(grid), dim3(256), fl, (hipStream_t)stream, k); break;
-            default: hipLaunchKernelGGL(wedm_step_fused<16>, dim3(grid), dim3(256), fl, (hipStream_t)stream, k); break;
-        }
+        fn = tr ? pick_fused<true>(lanes) : pick_fused<false>(lanes);
         std::snprintf(name, sizeof(name), "wedm_step_fused<%d><<<%d,256,%zuB>>> n_sub=%d", lanes, grid, fl, n_substeps);
     }
+    if (fl) {
+        hipError_t ea = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)fl);
+        if (ea != hipSuccess) return hip_fail(ctx, ea, "hipFuncSetAttribute(MaxDynamicSharedMemorySize)");
+    }
+    void* kargs[] = {(void*)&k};
+    hipError_t el = hipLaunchKernel(fn, dim3(grid), dim3(256), kargs, fl, (hipStream_t)stream);
+    if (el != hipSuccess) return hip_fail(ctx, el, "wedm_step launch");
     ctx->last_kernel = name;
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return hip_fail(ctx, e, "wedm_step launch");
+    if (ctx->trace_on) {
+        const int64_t every = ctx->trace.every;
+        ctx->trace_count += (ctx->trace_us % every + n_substeps) / every;
+        ctx->trace_us += n_substeps;
+    }
     return WEDM_OK;
 }
 

@@ -160,6 +160,10 @@ class WireEDMEnv:
 
         # ---- state (caller-owned memory) + backend
         self.state = BatchedEDMState(self.num_envs, self.n_segments, _abi.OBS_DIM, self.device)
+        base_flow = float(self.dielectric_params.base_flow_rate)
+        self.state.derived["dielectric_flow_rate"] = lambda: self.state.flow_rate * base_flow  # legacy alias
+        if not self.per_env_geometry:
+            self.state.derived["wire_average_temperature"] = self.zone_mean_temperature
         if backend is None:
             from .._lib import HipBackend
 
@@ -196,6 +200,7 @@ class WireEDMEnv:
         self._reward = torch.zeros(self.num_envs, dtype=torch.float32, device=self.device)
         self._truncated = torch.zeros(self.num_envs, dtype=torch.bool, device=self.device)
         self._mask_buf = None
+        self._trace = None
         self._seed = int.from_bytes(os.urandom(8), "little")
         self._backend.reset(None, self._seed, True)
 
@@ -308,6 +313,23 @@ class WireEDMEnv:
         self._backend.set_kernel(variant)
         if hasattr(self._backend, "set_lanes"):
             self._backend.set_lanes(lanes)
+
+    def bind_trace(self, signals, *, every: int = 1, capacity: int = 1000, envs=None, wire_temperature: bool = False):
+        """Record `signals` (EDMState attribute names, plus ``"wire_temperature"``) of the
+        environments ``envs=(first, count)`` (default: all) every ``every`` microseconds INSIDE
+        the step kernels, into a ring of ``capacity`` samples — what the reference does with
+        `SimulationLogger.collect` after each 1-us step (utils/logger.py:110-160).  Returns the
+        `DeviceTrace`; a previously bound trace is replaced."""
+        from ..trace import DeviceTrace
+
+        trace = DeviceTrace(self, signals, every=every, capacity=capacity, envs=envs, wire_temperature=wire_temperature)
+        self._backend.bind_trace(trace.desc)
+        self._trace = trace
+        return trace
+
+    def unbind_trace(self) -> None:
+        self._backend.bind_trace(None)
+        self._trace = None
 
     def zone_mean_temperature(self) -> torch.Tensor:
         """Mean wire temperature over the workpiece zone (wire.py:390-398), per environment."""

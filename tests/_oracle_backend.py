@@ -30,6 +30,7 @@ class OracleBackend:
         self.state = None
         self.geom = _abi.GeomPtrs(None, None)
         self._L = orc.lib()
+        self._trace, self._trace_us, self._trace_count = None, 0, 0
 
     def bind_state(self, ptrs):
         self.state = ptrs
@@ -54,11 +55,54 @@ class OracleBackend:
             T[:, : self.num_envs][:, m] = np.float32(self.params.spool_T)
             obs[:, : self.num_envs][:, m] = 0
 
-    def step(self, n_substeps, action):
+    def _run(self, n_substeps, action):
         rc = self._L.wedm_oracle_step_batch(C.byref(self.params), C.byref(self.state), C.byref(self.geom),
                                             C.byref(action), self.num_envs, n_substeps, self.math_mode,
                                             self.stencil_mode, self.n_threads)
         assert rc == 0, rc
+
+    def step(self, n_substeps, action):
+        """wedm_step, including the sampling schedule of wedm_bind_trace (include/wedm_hip.h):
+        sample m (microseconds since the bind) is taken when m % every == 0, into ring slot
+        (m / every - 1) % capacity; rows packed in ascending row order."""
+        tr = self._trace
+        if tr is None:
+            self._run(n_substeps, action)
+            return
+        left = n_substeps
+        while left > 0:
+            chunk = min(left, tr.every - self._trace_us % tr.every)
+            self._run(chunk, action)
+            left -= chunk
+            self._trace_us += chunk
+            if self._trace_us % tr.every == 0:
+                self._sample(self._trace_count % tr.capacity)
+                self._trace_count += 1
+
+    def _block(self, ptr, ctype, rows):
+        return np.ctypeslib.as_array(C.cast(ptr, C.POINTER(ctype)), shape=(rows, self.state.stride))
+
+    def _sample(self, slot):
+        tr = self._trace
+        lo, cnt = tr.env_lo, tr.env_count
+        for ptr, mask, src, ctype, nrows in (
+                (tr.f64, tr.f64_mask, self.state.f64, C.c_double, _abi.F64_COUNT),
+                (tr.i32, tr.i32_mask, self.state.i32, C.c_int32, _abi.I32_COUNT),
+                (tr.i8, tr.i8_mask, self.state.i8, C.c_int8, _abi.I8_COUNT)):
+            rows = [r for r in range(nrows) if (mask >> r) & 1]
+            if not rows:
+                continue
+            dst = np.ctypeslib.as_array(C.cast(ptr, C.POINTER(ctype)), shape=(tr.capacity, len(rows), cnt))
+            dst[slot] = self._block(src, ctype, nrows)[rows, lo:lo + cnt]
+        if tr.T:
+            dst = np.ctypeslib.as_array(C.cast(tr.T, C.POINTER(C.c_float)), shape=(tr.capacity, self.n_seg_max, cnt))
+            dst[slot] = self._block(self.state.T, C.c_float, self.n_seg_max)[:, lo:lo + cnt]
+
+    def bind_trace(self, desc):
+        self._trace, self._trace_us, self._trace_count = desc, 0, 0
+
+    def trace_samples(self):
+        return self._trace_count
 
     def set_kernel(self, variant):
         pass

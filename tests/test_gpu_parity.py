@@ -480,3 +480,181 @@ def test_tiny_wires_all_kernels(segment_len, n_seg):
         check(gpu, cpu, n)
         ran += 1
     assert ran >= 3 and int(gpu.state.spark_count.sum()) > 0
+
+
+# ------------------------------------------------------------------ device trace
+TRACE_SIGNALS = ["voltage", "current", "wire_position", "workpiece_position", "debris_density", "flow_rate",
+                 "wire_max_temperature", "time", "spark_duration", "spark_count", "spark_state", "is_short_circuit",
+                 "done", "control_step"]
+
+
+def assert_rings_equal(tg, tc, rows=None):
+    torch.cuda.synchronize()
+    assert tg.count == tc.count
+    for b in ("f64", "i32", "i8"):
+        if tg._buf[b] is None:
+            assert tc._buf[b] is None
+            continue
+        G, Cc = tg._buf[b].cpu(), tc._buf[b]
+        same = (G == Cc) | ((G != G) & (Cc != Cc)) if b == "f64" else (G == Cc)
+        assert bool(same.all()), f"trace block {b}: {int((~same).sum())} of {same.numel()} differ"
+    if tg._T is not None:
+        G, Cc = tg._T.cpu(), tc._T
+        if rows is not None:   # per-environment wires: rows past the environment's own n_seg are not written
+            keep = torch.arange(G.shape[1])[None, :, None] < rows[None, None, :]
+            G, Cc = torch.where(keep, G, 0), torch.where(keep, Cc, 0)
+        assert torch.equal(G, Cc), f"trace T: {int((G != Cc).sum())} of {G.numel()} differ"
+
+
+@pytest.mark.parametrize("variant,lanes", KERNELS)
+def test_device_trace_ring_matches_oracle(variant, lanes):
+    """The ring the kernels fill inside fused launches == the ring the oracle seam fills by
+    sampling after single microseconds: every slot, every traced row, wire temperature included."""
+    n = 200
+    gpu, cpu = make_pair(n)
+    gpu.set_kernel(variant, lanes)
+    both((gpu, cpu), lambda e: (e.reset(seed=321), close_gap(e)))
+    if (variant == 3 and (-(-gpu.n_segments // lanes) + 1) > 160) or \
+       (variant == 4 and (2 * -(-gpu.n_segments // (2 * lanes)) + 2) > 160):
+        pytest.skip("chunk does not fit in LDS (covered by test_default_config_fused_matches_oracle)")
+    gpu.state.target_position[20] = 25.0005   # one traced environment terminates early
+    cpu.state.target_position[20] = 25.0005
+    traces = [e.bind_trace(TRACE_SIGNALS, every=3, capacity=300, envs=(13, 150), wire_temperature=True)
+              for e in (gpu, cpu)]
+    for env in (gpu, cpu):
+        a = env.make_action(0.1, 80.0, 5, 3.0, 80.0)
+        for k in (700, 1, 2, 650):          # 1353 us -> 451 samples through a 300-slot ring
+            env.step_many(a, k)
+    assert traces[0].count == 451
+    assert_rings_equal(*traces)
+    check(gpu, cpu, n)
+    got = traces[0].read()
+    assert bool(got["done"][-1, 7]) and int((got["spark_state"] == 1).sum()) > 0
+    assert got["wire_temperature"].shape == (300, 150, gpu.n_segments)
+    # no trace bound -> the instantiation without the trace point runs, results unchanged
+    for env in (gpu, cpu):
+        env.unbind_trace()
+        env.step_many(env.make_action(0.1, 80.0, 5, 3.0, 80.0), 300)
+    check(gpu, cpu, n)
+
+
+def test_device_trace_config3_every_microsecond_all_envs():
+    n = 1024
+    kw = dict(wire_params=WireModuleParameters(segment_len=0.625))
+    gpu, cpu = make_pair(n, **kw)
+    gpu.set_kernel(4, 2)   # the kernel the 65 536-environment headline workload runs
+    both((gpu, cpu), lambda e: (e.reset(seed=9), close_gap(e)))
+    traces = [e.bind_trace(["voltage", "spark_state", "time"], every=1, capacity=1001) for e in (gpu, cpu)]
+    for env in (gpu, cpu):
+        a = env.make_action(0.1, 80.0, 9, 3.0, 30.0)
+        env.step_many(a, 1000)
+        env.step_many(a, 500)
+    assert "wedm_step_packed" in gpu._backend.last_kernel()
+    assert_rings_equal(*traces)
+    check(gpu, cpu, n)
+    v = traces[0].read(last=1001)["voltage"]
+    assert v.shape == (1001, n) and float(v.min()) == 0.0 and float(v.max()) == 80.0
+
+
+def test_device_trace_per_environment_geometry():
+    n = 96
+    rng = np.random.default_rng(7)
+    h = rng.uniform(10.0, 30.0, n)
+    d = rng.choice([0.10, 0.20, 0.30], n)
+    kw = dict(workpiece_height=h, wire_diameter=d, config=EnvironmentConfig(target_cutting_distance=5000.0))
+    gpu, cpu = make_pair(n, **kw)
+    both((gpu, cpu), lambda e: (e.reset(seed=4), close_gap(e, 24.0, 10.0)))
+    n_seg = gpu._geom_i32[0, :n].cpu()   # WEDM_GI_N_SEG
+    for variant in (2, 1):
+        gpu.set_kernel(variant, 0)
+        traces = [e.bind_trace(["voltage", "time", "spark_state"], every=10, capacity=64, envs=(5, 80),
+                               wire_temperature=True) for e in (gpu, cpu)]
+        for env in (gpu, cpu):
+            env.step_many(env.make_action(0.1, 80.0, 7, 3.0, 40.0), 400)
+        assert_rings_equal(*traces, rows=n_seg[5:85])
+        check(gpu, cpu, n)
+
+
+def test_single_microsecond_launches_feed_the_trace():
+    n = 64
+    gpu, cpu = make_pair(n)
+    both((gpu, cpu), lambda e: (e.reset(seed=2), close_gap(e)))
+    traces = [e.bind_trace(["voltage", "time"], every=2, capacity=16, wire_temperature=True) for e in (gpu, cpu)]
+    for env in (gpu, cpu):
+        a = env.make_action()
+        for _ in range(41):
+            env.step(a)
+    assert "wedm_step_global" in gpu._backend.last_kernel() and traces[0].count == 20
+    assert_rings_equal(*traces)
+    check(gpu, cpu, n)
+
+
+def test_bind_trace_rejects_bad_descriptors():
+    from sparc_amd import _abi
+    from sparc_amd._lib import WedmError
+
+    env = WireEDMEnv(num_envs=64, device="cuda:0")
+    buf = torch.zeros(1024, dtype=torch.float64, device="cuda:0")
+    ok = dict(f64=buf.data_ptr(), i32=None, i8=None, T=None, f64_mask=1, i32_mask=0, i8_mask=0, env_lo=0, env_count=8,
+              every=1, capacity=4, reserved0=0)
+    for bad in (dict(f64_mask=1 << 24), dict(f64=None), dict(i32_mask=1), dict(every=0), dict(capacity=0),
+                dict(env_lo=60, env_count=8), dict(env_count=0), dict(f64=None, f64_mask=0)):
+        with pytest.raises(WedmError, match="WEDM_ERR_BAD_ARG"):
+            env._backend.bind_trace(_abi.TraceDesc(**{**ok, **bad}))
+    env._backend.bind_trace(_abi.TraceDesc(**ok))
+    env.step_many(env.make_action(), 3)
+    assert env._backend.trace_samples() == 3
+    env._backend.bind_trace(None)
+    assert env._backend.trace_samples() == 0
+
+
+def test_voltage_controller_on_gpu_matches_oracle():
+    """§8f-3: PI voltage controller averaging the kernel-side 1 ms voltage ring, fused control
+    intervals: GPU == oracle bit for bit (state, integrators, averaged voltage)."""
+    from sparc_amd import SimulationLogger, VoltageController, run_controlled
+
+    n = 256
+    gpu, cpu = make_pair(n)
+    ctls, logs = [], []
+    for env in (gpu, cpu):
+        env.reset(seed=31)
+        close_gap(env, 22.0, 10.0, 5000.0)
+        trace = env.bind_trace(["voltage", "time", "wire_position"], every=1, capacity=1101)
+        ctl = VoltageController(30.0).bind(env, trace)
+        lg = SimulationLogger({"signals_to_log": ["time", "voltage", "wire_position"], "log_frequency": {"type": "every_step"}})
+        lg.attach(env, trace=trace)
+        assert run_controlled(env, ctl, 5400, logger=lg) == 5400
+        ctls.append(ctl)
+        logs.append(lg.get_data())
+    check(gpu, cpu, n)
+    assert torch.equal(ctls[0].integral_error.cpu(), ctls[1].integral_error)
+    assert torch.equal(ctls[0].average_voltage().cpu(), ctls[1].average_voltage())
+    for k in ("time", "voltage", "wire_position"):
+        assert logs[0][k].shape == (5400, n) and np.array_equal(logs[0][k], logs[1][k]), k
+    assert int(gpu.state.spark_count.sum()) > 1000
+
+
+def test_voltage_controller_driver_on_gpu_matches_reference_fixture(golden_dir):
+    """The reference's run_simulation.py loop with ITS voltage controller (fixture) against the
+    GPU: one microsecond per launch, the voltage ring filled by the kernel, commands computed on
+    the device.  Discrete state, positions, voltages and servo commands exact."""
+    from sparc_amd import VoltageController
+    from tests._fixture_env import check_step
+    from tests._golden import Fixture
+
+    fx = Fixture(golden_dir / "f9_voltage_controller_philox_env2.npz")
+    env = WireEDMEnv(num_envs=64, device="cuda:0")
+    env.reset(seed=79)
+    close_gap(env, 70.0, 10.0, 5000.0)
+    ctl = VoltageController(30.0)
+    action = ctl(env)
+    steps = 4300
+    sampled = set(range(0, steps, 41)) | set(range(990, 1010)) | set(range(3990, 4010))
+    for step in range(steps):
+        env.step(action)
+        latch = (step + 1) % 1000 == 1 and step > 0
+        if step in sampled or latch:
+            check_step(env, fx, 2, step, exact_floats=False)
+        if latch:
+            action = ctl(env)
+            assert float(action.servo[2]) == fx.actions[fx.action_idx[step + 1], 0], step

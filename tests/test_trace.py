@@ -1,0 +1,215 @@
+"""SURVEY.md §8f-1/-3 on top of the device trace: the per-microsecond signal ring, the logger fed
+from it, and the PI voltage controller of the reference's driver.  CPU tests run the host logic
+against the oracle test seam (which restates the sampling schedule of include/wedm_hip.h); the
+GPU tests in test_gpu_parity.py compare the kernels' rings with these, bit for bit."""
+from __future__ import annotations
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import oracle as orc
+from sparc_amd import GapController, SimulationLogger, VoltageController, WireEDMEnv, run_controlled
+from tests._fixture_env import check_step
+from tests._golden import Fixture
+from tests._oracle_backend import OracleBackend
+
+
+class LibmOracleBackend(OracleBackend):
+    math_mode = orc.MATH_LIBM  # glibc pow/exp like the reference -> bit-exact against its fixtures
+
+
+def driver_env(n, seed, mode="position", backend=LibmOracleBackend):
+    env = WireEDMEnv(num_envs=n, device="cpu", backend=backend, mechanics_control_mode=mode)
+    env.reset(seed=seed)
+    env.state.workpiece_position = 70.0   # experiments/run_simulation.py:199-201
+    env.state.wire_position = 10.0
+    env.state.target_position = 5000.0
+    return env
+
+
+def sparking_env(n, seed=5, backend=OracleBackend):
+    env = WireEDMEnv(num_envs=n, device="cpu", backend=backend)
+    env.reset(seed=seed)
+    env.state.workpiece_position = 25.0
+    env.state.wire_position = 10.0
+    env.state.target_position = 5000.0
+    return env
+
+
+def test_trace_equals_per_microsecond_reads_and_ring_wraps():
+    a, b = sparking_env(6), sparking_env(6)
+    names = ["voltage", "current", "time", "spark_state", "is_short_circuit", "wire_position", "spark_status"]
+    trace = a.bind_trace(names, every=1, capacity=700, envs=(2, 3), wire_temperature=True)
+    act_a, act_b = a.make_action(), b.make_action()
+    want = {k: [] for k in names + ["wire_temperature"]}
+    for launch in (300, 250, 400):       # 950 samples through a 700-slot ring
+        a.step_many(act_a, launch)
+        for _ in range(launch):
+            b.step(act_b)
+            for k in names:
+                v = getattr(b.state, "spark_state" if k == "spark_status" else k)
+                want[k].append(v[2:5].clone())
+            want["wire_temperature"].append(b.state.wire_temperature[2:5].clone())
+    assert trace.count == 950
+    got = trace.read()
+    for k in names + ["wire_temperature"]:
+        ref = torch.stack(want[k])[-700:]
+        assert got[k].shape == ref.shape and got[k].dtype == ref.dtype, k
+        assert torch.equal(got[k], ref), k
+    assert int((got["spark_state"] == 1).sum()) > 0            # the window really contains sparks
+    last = trace.read(last=10, names=["time"])["time"]
+    assert last[:, 0].tolist() == list(range(941, 951))
+    mid = trace.read_range(400, 420, ["voltage"])["voltage"]
+    assert torch.equal(mid, torch.stack(want["voltage"])[400:420])
+    with pytest.raises(RuntimeError, match="overrun"):
+        trace.read_range(100, 120)
+    assert trace.sample_times(0, 3).tolist() == [1, 2, 3]
+
+
+def test_trace_interval_phase_across_launches_and_rebind():
+    a, b = sparking_env(4), sparking_env(4)
+    trace = a.bind_trace(["time", "workpiece_position"], every=7, capacity=64)
+    act = a.make_action()
+    for launch in (10, 3, 1, 30, 6):     # 50 us -> samples at 7, 14, ..., 49
+        a.step_many(act, launch)
+    assert trace.count == 7
+    assert trace.read()["time"][:, 0].tolist() == [7, 14, 21, 28, 35, 42, 49]
+    wp = []
+    for t in range(50):
+        b.step(b.make_action())
+        if (t + 1) % 7 == 0:
+            wp.append(b.state.workpiece_position.clone())
+    assert torch.equal(trace.read()["workpiece_position"], torch.stack(wp))
+    # binding again restarts the count and the phase
+    t2 = a.bind_trace(["time"], every=5, capacity=4)
+    assert trace.count == 0 and t2.count == 0
+    a.step_many(act, 12)
+    assert t2.read()["time"][:, 0].tolist() == [55, 60]
+    a.unbind_trace()
+    a.step_many(act, 5)
+    assert t2.count == 0
+    for bad in (dict(every=0), dict(capacity=0), dict(envs=(3, 2)), dict(envs=(-1, 2))):
+        with pytest.raises(ValueError):
+            a.bind_trace(["time"], **bad)
+    with pytest.raises(ValueError, match="unknown signal"):
+        a.bind_trace(["no_such_field"])
+    with pytest.raises(ValueError, match="nothing"):
+        a.bind_trace([])
+
+
+def test_terminated_environments_keep_being_sampled():
+    env = sparking_env(3)
+    env.state.target_position[0] = 25.0005          # the first crater finishes environment 0
+    trace = env.bind_trace(["time", "done", "workpiece_position"], capacity=3000)
+    env.step_many(env.make_action(), 3000)
+    got = trace.read()
+    done0 = got["done"][:, 0]
+    assert bool(done0[-1]) and not bool(done0[0]) and not got["done"][:, 1:].any()
+    first = int(torch.nonzero(done0)[0])
+    assert (got["time"][first:, 0] == got["time"][first, 0]).all()      # frozen state, sampled on
+    assert got["time"][:, 1].tolist() == list(range(1, 3001))
+
+
+@pytest.mark.parametrize("name,seed,mode,env_id,n", [
+    ("f9_voltage_controller_philox_env2", 79, "position", 2, 4),
+    ("f9_voltage_controller_velocity_philox_env5", 80, "velocity", 5, 8),
+])
+def test_voltage_controller_reproduces_the_reference_driver(golden_dir, name, seed, mode, env_id, n):
+    """run_simulation.py's loop with the reference's OWN `create_voltage_controller` (fixture
+    generated by importing it) against the on-device VoltageController averaging the kernel-side
+    voltage ring: every recorded quantity and every servo command equal, bit for bit."""
+    fx = Fixture(golden_dir / (name + ".npz"))
+    env = driver_env(n, seed, mode)
+    ctl = VoltageController(30.0)
+    action = ctl(env)
+    assert float(action.servo[env_id]) == fx.actions[fx.action_idx[0], 0]
+    checked = 0
+    for step in range(fx.n_steps):
+        env.step(action)
+        check_step(env, fx, env_id, step, exact_floats=True)
+        if bool(env.state.control_step[0]):
+            action = ctl(env)
+            if step + 1 < fx.n_steps:   # the float32 servo leaf the reference computed at this control step
+                assert float(action.servo[env_id]) == fx.actions[fx.action_idx[step + 1], 0], step
+                checked += 1
+    assert checked >= 5 and len(fx.actions) >= 5
+    assert np.array_equal(env.state.wire_temperature[env_id].numpy(), fx.T_snaps[-1])
+
+
+def test_voltage_controller_fused_launches_equal_per_microsecond_driver():
+    a, b = driver_env(8, 6, backend=OracleBackend), driver_env(8, 6, backend=OracleBackend)
+    for env in (a, b):
+        env.state.workpiece_position = 22.0       # close enough to spark: a non-trivial voltage average
+    ctl_a, ctl_b = VoltageController(30.0), VoltageController(30.0)
+    assert run_controlled(a, ctl_a, 5300) == 5300
+    action = ctl_b(b)
+    for _ in range(5300):
+        b.step(action)
+        if bool(b.state.control_step[0]):
+            action = ctl_b(b)
+    A, B = a.state.clone_blocks(), b.state.clone_blocks()
+    for k in ("i32", "i8", "T", "obs"):
+        assert torch.equal(A[k], B[k]), k
+    assert bool(((A["f64"] == B["f64"]) | (A["f64"].isnan() & B["f64"].isnan())).all())
+    assert torch.equal(ctl_a.integral_error, ctl_b.integral_error)
+    avg = ctl_a.average_voltage()
+    assert bool(((avg > 0) & (avg < 80)).all()) and int(a.state.spark_count.sum()) > 50
+
+
+def test_logger_attached_to_the_device_trace(tmp_path):
+    """every_step / interval logging of a fused run == the reference-style collect() after every
+    1-us step, including the signals of run_simulation.py:127-147."""
+    signals = ["time", "voltage", "current", "wire_position", "wire_velocity", "workpiece_position", "target_delta",
+               "debris_concentration", "dielectric_flow_rate", "is_short_circuit", "flow_rate", "wire_temperature",
+               "wire_average_temperature", "spark_status"]
+    a, b = driver_env(3, 4, backend=OracleBackend), driver_env(3, 4, backend=OracleBackend)
+    for env in (a, b):
+        env.state.workpiece_position = 24.0
+    cfg = {"signals_to_log": signals, "log_frequency": {"type": "every_step"},
+           "backend": {"type": "numpy", "filepath": str(tmp_path / "run.npz"), "compress": True}}
+    fused = SimulationLogger(cfg, env_reference=a)
+    fused.attach(a)
+    run_controlled(a, GapController(), 2300, logger=fused)
+    per_us = SimulationLogger({**cfg, "backend": {"type": "memory"}}, env_reference=b)
+    ctl = GapController()
+    action = ctl(b)
+    for _ in range(2300):
+        _, _, _, _, info = b.step(action)
+        per_us.collect(b.state, info)
+        if bool(b.state.control_step[0]):
+            action = ctl(b)
+    F, P = fused.get_data(), per_us.get_data()
+    for k in signals:
+        assert F[k].shape == P[k].shape and F[k].shape[:2] == (2300, 3), k
+        if k == "wire_average_temperature":
+            assert np.allclose(F[k], P[k], rtol=0, atol=1e-4), k
+        else:
+            assert np.array_equal(F[k], P[k], equal_nan=True), k
+    assert (F["dielectric_flow_rate"] == F["flow_rate"] * 100.0).all()
+    z = np.load(tmp_path / "run.npz")
+    assert np.array_equal(z["voltage"], F["voltage"]) and z["wire_temperature"].shape == (2300, 3, a.n_segments)
+    # interval logging: every 50th microsecond (logger.py:130-132), on a sub-range of environments
+    c = driver_env(5, 4, backend=OracleBackend)
+    lg = SimulationLogger({"signals_to_log": ["time", "voltage"], "log_frequency": {"type": "interval", "value": 50}})
+    lg.attach(c, envs=(1, 2))
+    run_controlled(c, GapController(), 1230, logger=lg)
+    t = lg.get_data()["time"]
+    assert t.shape == (24, 2) and t[:, 0].tolist() == list(range(50, 1201, 50))
+    with pytest.raises(ValueError):
+        SimulationLogger({"log_frequency": {"type": "control_step"}}).attach(c)
+
+
+def test_logger_and_voltage_controller_share_one_trace():
+    env = driver_env(4, 11, backend=OracleBackend)
+    env.state.workpiece_position = 22.0
+    trace = env.bind_trace(["voltage", "time", "current"], every=1, capacity=2048)
+    ctl = VoltageController(30.0).bind(env, trace)
+    lg = SimulationLogger({"signals_to_log": ["time", "voltage"], "log_frequency": {"type": "every_step"}})
+    lg.attach(env, trace=trace)
+    run_controlled(env, ctl, 3200, logger=lg)
+    d = lg.get_data()
+    assert d["time"][:, 0].tolist() == list(range(1, 3201))
+    assert float(ctl.average_voltage()[0]) == float(d["voltage"][-1001:, 0].sum() / 1001)
+    with pytest.raises(ValueError):
+        VoltageController().bind(env, env.bind_trace(["voltage"], every=2, capacity=2000))

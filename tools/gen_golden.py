@@ -237,6 +237,8 @@ def run_scenario(name, *, n_steps, seed=0, config=None, control_mode="position",
             raised = (step, str(exc))
             break
         ctrl = info.get("control_step", False)  # early return on wire break has no key
+        if hasattr(controller, "observe"):
+            controller.observe(env)
         f, i = snapshot(env, terminated, ctrl, rec.n_step)
         for k in INT_FIELDS:
             ints[k].append(i[k])
@@ -303,6 +305,40 @@ def gap_controller(desired_gap=5.0):
         return make_action(delta, 80.0, 7, 2.0, 33.0, dtype=np.float32)
 
     return controller
+
+
+def reference_driver_module():
+    """The reference's own experiments/run_simulation.py (its controllers are used as they are)."""
+    import importlib.util
+
+    if "/root/reference" not in sys.path:
+        sys.path.insert(0, "/root/reference")
+    spec = importlib.util.spec_from_file_location("ref_run_simulation", "/root/reference/experiments/run_simulation.py")
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    return mod
+
+
+class VoltageDriver:
+    """The reference's PI voltage controller (`create_voltage_controller`, run_simulation.py:58-109,
+    imported, not restated) fed the way `run_simulation()` feeds it (run_simulation.py:258-281):
+    the voltage of every microsecond is appended to a history that keeps the samples whose time
+    is >= state.time - 1000, and the controller receives a copy at each control step."""
+
+    def __init__(self, target_voltage=30.0):
+        self.ctl = reference_driver_module().create_voltage_controller(target_voltage)
+        self.vh, self.th = [], []
+
+    def observe(self, env):
+        self.vh.append(env.state.voltage if env.state.voltage is not None else 0.0)
+        self.th.append(env.state.time)
+        cutoff = env.state.time - 1000.0
+        while self.th and self.th[0] < cutoff:
+            self.vh.pop(0)
+            self.th.pop(0)
+
+    def __call__(self, env):
+        return self.ctl(env, list(self.vh))
 
 
 def single_spark_forced(spark_time=50, duration=2, loc=25.0, ocv=80.0):
@@ -419,6 +455,16 @@ def main():
                  control_mode="velocity", controller=gap_controller(),
                  state_init={"workpiece_position": 70.0, "wire_position": 10.0, "target_position": 5000.0},
                  t_snap_every=3000, float_stride=9, note="velocity-mode gap controller (clip +-1000 um/s)")
+
+    # F9 — the driver's PI voltage controller (1 ms moving-average voltage), Philox variates
+    run_scenario("f9_voltage_controller_philox_env2", n_steps=8000, seed=79, rng="philox", env_id=2,
+                 controller=VoltageDriver(30.0),
+                 state_init={"workpiece_position": 70.0, "wire_position": 10.0, "target_position": 5000.0},
+                 t_snap_every=4000, float_stride=9, note="run_simulation.py voltage controller, position mode")
+    run_scenario("f9_voltage_controller_velocity_philox_env5", n_steps=6000, seed=80, rng="philox", env_id=5,
+                 control_mode="velocity", controller=VoltageDriver(30.0),
+                 state_init={"workpiece_position": 70.0, "wire_position": 10.0, "target_position": 5000.0},
+                 t_snap_every=3000, float_stride=9, note="run_simulation.py voltage controller, velocity mode")
 
     # geometry variants (BASELINE config 5 shapes), short Philox runs
     for i, (h, d) in enumerate(((10.0, 0.10), (15.0, 0.25), (30.0, 0.30), (12.3, 0.15))):
