@@ -111,6 +111,20 @@ enum wedm_i8_field {
     WEDM_I8_COUNT
 };
 
+/* ------------------------------------------------ running statistics (optional)
+ * Accumulated inside the kernels at every fresh spark with fire-and-forget float64 atomics
+ * (one lane per environment, so the order of the additions is the order of the sparks); what
+ * the reference computes from its `crater_volumes_um3` list in
+ * `MaterialRemovalModule.get_crater_statistics` (material.py:207-227).  Count =
+ * WEDM_I_SPARK_COUNT; mean = sum / n; std = sqrt(sumsq / n - mean^2).                        */
+enum wedm_stat_field {
+    WEDM_S_CRATER_SUM = 0,     /* sum of the sampled crater volumes            [um^3]   */
+    WEDM_S_CRATER_SUMSQ,       /* sum of their squares                         [um^6]   */
+    WEDM_S_CRATER_MIN,         /* smallest crater volume so far (+inf while n == 0)     */
+    WEDM_S_CRATER_MAX,         /* largest crater volume so far  (-inf while n == 0)     */
+    WEDM_STAT_COUNT
+};
+
 /* -------------------------------------- per-environment geometry (optional)
  * BASELINE config 5: workpiece_height / wire_diameter differ per environment.
  * When bound, these rows override the uniform values in wedm_params.       */
@@ -204,6 +218,7 @@ typedef struct wedm_state_ptrs {
     float* T;           /* [n_seg_max][stride]      */
     float* obs;         /* [obs_dim][stride] or NULL */
     int64_t stride;     /* >= num_envs, multiple of 64 recommended */
+    double* stats;      /* [WEDM_STAT_COUNT][stride] or NULL (statistics not kept) */
 } wedm_state_ptrs;
 
 typedef struct wedm_geom_ptrs {

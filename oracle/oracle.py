@@ -109,7 +109,9 @@ class Env(C.Structure):
         ("random_short_remaining", _i), ("debris_short_remaining", _i),
         ("diel_last_gap", _d), ("diel_last_density", _d), ("wire_last_flow", _d),
         ("h_base", C.c_float), ("h_zone", C.c_float),
-        ("prev_accel", _d), ("spark_count", _i), ("tmax", C.c_float),
+        ("prev_accel", _d), ("spark_count", _i),
+        ("crater_stat_sum", _d), ("crater_stat_sumsq", _d), ("crater_stat_min", _d), ("crater_stat_max", _d),
+        ("tmax", C.c_float),
         ("last_terminated", _i), ("last_ctrl_step", _i), ("last_early_return", _i),
         ("T", C.c_float * MAX_SEG), ("dT", C.c_float * MAX_SEG),
     ]

@@ -413,6 +413,7 @@ void wedm_oracle_reset(wedm_oracle_env* e) {
     e->h_base = 0.0f; e->h_zone = 0.0f;                    /* wire.py:205 np.zeros */
     e->prev_accel = 0.0;
     e->spark_count = 0;
+    e->crater_stat_sum = 0.0; e->crater_stat_sumsq = 0.0; e->crater_stat_min = INFINITY; e->crater_stat_max = -INFINITY;
     e->last_terminated = 0; e->last_ctrl_step = 0; e->last_early_return = 0;
     for (int i = 0; i < c->n_seg; ++i) { e->T[i] = (float)c->spool_T; e->dT[i] = 0.0f; } /* wire.py:264-269 */
     e->tmax = (float)c->spool_T;
@@ -578,6 +579,11 @@ static void material_update(wedm_oracle_env* e) {
         double sampled_um3 = rng_normal(e, c->crater_mean[mode], c->crater_std[mode]); /* :127 */
         if (!(sampled_um3 > 0)) sampled_um3 = 0; /* max(0, x) :130 */
         e->spark_count += 1;                     /* :133 */
+        /* running form of get_crater_statistics (material.py:207-227) */
+        e->crater_stat_sum += sampled_um3;
+        e->crater_stat_sumsq += sampled_um3 * sampled_um3;
+        if (sampled_um3 < e->crater_stat_min) e->crater_stat_min = sampled_um3;
+        if (sampled_um3 > e->crater_stat_max) e->crater_stat_max = sampled_um3;
         double crater_volume = sampled_um3 / 1e9; /* :136 */
         e->last_crater_volume = crater_volume;
         if (crater_volume > 0) {
@@ -925,6 +931,7 @@ static void apply_geometry(const wedm_geom_ptrs* g, int64_t stride, int64_t e, w
 #define F64(row) s->f64[(int64_t)(row) * stride + e]
 #define I32(row) s->i32[(int64_t)(row) * stride + e]
 #define I8(row) s->i8[(int64_t)(row) * stride + e]
+#define STAT(row) s->stats[(int64_t)(row) * stride + e]
 
 static void gather_env(const wedm_state_ptrs* s, int64_t e, wedm_oracle_env* v) {
     int64_t stride = s->stride;
@@ -950,6 +957,10 @@ static void gather_env(const wedm_state_ptrs* s, int64_t e, wedm_oracle_env* v) 
     v->rng.episode = (uint32_t)I32(WEDM_I_EPISODE);
     v->rng.seed = (uint64_t)(uint32_t)I32(WEDM_I_KEY_LO) | ((uint64_t)(uint32_t)I32(WEDM_I_KEY_HI) << 32);
     v->spark_count = I32(WEDM_I_SPARK_COUNT);
+    if (s->stats) {
+        v->crater_stat_sum = STAT(WEDM_S_CRATER_SUM); v->crater_stat_sumsq = STAT(WEDM_S_CRATER_SUMSQ);
+        v->crater_stat_min = STAT(WEDM_S_CRATER_MIN); v->crater_stat_max = STAT(WEDM_S_CRATER_MAX);
+    }
     v->spark_state = I8(WEDM_B_SPARK_STATE); v->is_short_circuit = I8(WEDM_B_IS_SHORT);
     v->is_wire_broken = I8(WEDM_B_WIRE_BROKEN); v->is_target_reached = I8(WEDM_B_TARGET_REACHED);
     v->error = I8(WEDM_B_ERROR);
@@ -979,6 +990,10 @@ static void scatter_env(const wedm_state_ptrs* s, int64_t e, const wedm_oracle_e
     I32(WEDM_I_DEBRIS_SHORT_REM) = v->debris_short_remaining;
     I32(WEDM_I_TIME_CRITICAL) = v->time_in_critical_temp; I32(WEDM_I_CURRENT_MODE) = v->current_mode;
     I32(WEDM_I_SPARK_COUNT) = v->spark_count;
+    if (s->stats) {
+        STAT(WEDM_S_CRATER_SUM) = v->crater_stat_sum; STAT(WEDM_S_CRATER_SUMSQ) = v->crater_stat_sumsq;
+        STAT(WEDM_S_CRATER_MIN) = v->crater_stat_min; STAT(WEDM_S_CRATER_MAX) = v->crater_stat_max;
+    }
     I8(WEDM_B_SPARK_STATE) = (int8_t)v->spark_state; I8(WEDM_B_IS_SHORT) = (int8_t)v->is_short_circuit;
     I8(WEDM_B_WIRE_BROKEN) = (int8_t)v->is_wire_broken; I8(WEDM_B_TARGET_REACHED) = (int8_t)v->is_target_reached;
     I8(WEDM_B_DONE) = (int8_t)done; I8(WEDM_B_CTRL_STEP) = (int8_t)v->last_ctrl_step;
@@ -1021,6 +1036,10 @@ int32_t wedm_oracle_reset_batch(const wedm_params* p, const wedm_state_ptrs* s, 
         int32_t episode = I32(WEDM_I_EPISODE), klo = I32(WEDM_I_KEY_LO), khi = I32(WEDM_I_KEY_HI);
         for (int f = 0; f < WEDM_I32_COUNT; ++f) I32(f) = 0;
         for (int f = 0; f < WEDM_I8_COUNT; ++f) I8(f) = 0;
+        if (s->stats) {
+            STAT(WEDM_S_CRATER_SUM) = 0.0; STAT(WEDM_S_CRATER_SUMSQ) = 0.0;
+            STAT(WEDM_S_CRATER_MIN) = INFINITY; STAT(WEDM_S_CRATER_MAX) = -INFINITY;
+        }
         if (reseed) {
             I32(WEDM_I_EPISODE) = 0;
             I32(WEDM_I_KEY_LO) = (int32_t)(uint32_t)seed;

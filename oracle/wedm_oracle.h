@@ -152,6 +152,8 @@ typedef struct wedm_oracle_env {
     float h_base, h_zone;                                   /* wire.py:205 (two distinct values) */
     double prev_accel;                                      /* mechanics.py:60 */
     int32_t spark_count;                                    /* len(crater_volumes_um3) */
+    /* running statistics of crater_volumes_um3 (material.py:207-227): sum, sum of squares, min, max */
+    double crater_stat_sum, crater_stat_sumsq, crater_stat_min, crater_stat_max;
     float tmax;
     /* step() outputs */
     int32_t last_terminated, last_ctrl_step, last_early_return;

@@ -101,6 +101,18 @@ class I8(enum.IntEnum):
 I8_COUNT = 7
 
 
+class STAT(enum.IntEnum):
+    """Rows of the optional statistics block (``enum wedm_stat_field``)."""
+
+    CRATER_SUM = 0
+    CRATER_SUMSQ = 1
+    CRATER_MIN = 2
+    CRATER_MAX = 3
+
+
+STAT_COUNT = 4
+
+
 class GF64(enum.IntEnum):
     """Rows of the per-environment geometry float64 block."""
 
@@ -176,7 +188,7 @@ class StatePtrs(C.Structure):
 
     _fields_ = [
         ("f64", C.c_void_p), ("i32", C.c_void_p), ("i8", C.c_void_p), ("T", C.c_void_p),
-        ("obs", C.c_void_p), ("stride", C.c_int64),
+        ("obs", C.c_void_p), ("stride", C.c_int64), ("stats", C.c_void_p),
     ]
 
 

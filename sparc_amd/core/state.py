@@ -61,6 +61,8 @@ class BatchedEDMState:
         object.__setattr__(self, "b", self.i8.view(torch.bool))  # zero-copy 0/1 view of the flags
         object.__setattr__(self, "T", torch.zeros((n_seg_max, stride), dtype=torch.float32, **kw))
         object.__setattr__(self, "obs", torch.zeros((max(obs_dim, 1), stride), dtype=torch.float32, **kw))
+        # running statistics the kernels accumulate (material.py:207-227)
+        object.__setattr__(self, "stats", torch.zeros((_abi.STAT_COUNT, stride), dtype=torch.float64, **kw))
         # read-only attributes computed on access (registered by the environment):
         # dielectric_flow_rate (dielectric.py:160-162), wire_average_temperature (wire.py:339-347)
         object.__setattr__(self, "derived", {})
@@ -102,15 +104,16 @@ class BatchedEDMState:
 
     def pointers(self, with_obs: bool) -> _abi.StatePtrs:
         return _abi.StatePtrs(self.f64.data_ptr(), self.i32.data_ptr(), self.i8.data_ptr(), self.T.data_ptr(),
-                              self.obs.data_ptr() if with_obs else None, self.stride)
+                              self.obs.data_ptr() if with_obs else None, self.stride, self.stats.data_ptr())
 
     def field_names(self):
         return tuple(_FIELDS)
 
     def clone_blocks(self):
         """Host copies of the raw blocks (used by checkpointing and by the parity tests)."""
-        return {k: getattr(self, k).detach().cpu().clone() for k in ("f64", "i32", "i8", "T", "obs")}
+        return {k: getattr(self, k).detach().cpu().clone() for k in ("f64", "i32", "i8", "T", "obs", "stats")}
 
     def load_blocks(self, blocks) -> None:
-        for k in ("f64", "i32", "i8", "T", "obs"):
-            getattr(self, k).copy_(blocks[k].to(self.device))
+        for k in ("f64", "i32", "i8", "T", "obs", "stats"):
+            if k in blocks:
+                getattr(self, k).copy_(blocks[k].to(self.device))

@@ -226,6 +226,23 @@ struct Cold {  // everything reachable only through rare branches
     const wedm_trace_desc* tr;  // device copy of the bound trace descriptor (NULL: none)
 };
 
+// The kernels never touch their by-value `Cold` argument directly: they read it THROUGH the
+// kernel-argument segment (constant address space -> s_load at the point of use), with the
+// segment pointer laundered at every use so that no load is hoisted out of the rare branch it
+// sits in.  By value, the ~40 SGPRs of pointers competed with the every-step constants and the
+// substep loop carried 200-370 v_readlane / v_writelane SGPR-spill instructions.
+#define WEDM_AS4 __attribute__((address_space(4)))
+typedef const WEDM_AS4 Cold* ColdPtr;
+struct ColdRef {
+    ColdPtr base;
+    __device__ __forceinline__ ColdPtr get() const {
+        ColdPtr p = base;
+        asm volatile("" : "+s"(p));
+        return p;
+    }
+    __device__ __forceinline__ ColdPtr operator->() const { return get(); }
+};
+
 // Hide a pointer from loop-invariant code motion: loads through the result cannot be
 // hoisted out of the (rare) branch they sit in, so they cost SGPRs only there.
 template <class T>
@@ -238,16 +255,18 @@ __device__ __forceinline__ const T* opaque(const T* p) {
 
 // cold geometry scalars: the env's row when geometry is per environment, else the uniform value
 #define WEDM_COLD_GEOM_F64(cold, hot, row, field) \
-    ((hot).per_env_geometry ? (cold).g.f64[(int64_t)(row) * (cold).s.stride + e] : opaque((cold).p)->field)
+    ((hot).per_env_geometry ? (cold)->g.f64[(int64_t)(row) * (cold)->s.stride + e] : opaque((cold)->p)->field)
 #define WEDM_COLD_GEOM_I32(cold, hot, row, field) \
-    ((hot).per_env_geometry ? (cold).g.i32[(int64_t)(row) * (cold).s.stride + e] : opaque((cold).p)->field)
+    ((hot).per_env_geometry ? (cold)->g.i32[(int64_t)(row) * (cold)->s.stride + e] : opaque((cold)->p)->field)
 
-__device__ __forceinline__ double peak_current(const Cold& cold, int32_t mode) {
-    return (mode >= 1 && mode <= WEDM_MAX_MODE) ? cold.tb.mode_current[mode] : opaque(cold.p)->default_current;
+__device__ __forceinline__ double peak_current(const ColdRef cold, int32_t mode) {
+    return (mode >= 1 && mode <= WEDM_MAX_MODE) ? cold->tb.mode_current[mode] : opaque(cold->p)->default_current;
 }
 
-__device__ __forceinline__ void load_env(const wedm_state_ptrs& s, int64_t e, Env& v) {
-    const int64_t stride = s.stride;
+__device__ __forceinline__ void load_env(const ColdRef cold, int64_t e, Env& v) {
+    const ColdPtr c = cold.get();
+    const int64_t stride = c->s.stride;
+    const struct { const double* f64; const int32_t* i32; const int8_t* i8; } s{c->s.f64, c->s.i32, c->s.i8};
     v.wp = *WEDM_ROW(s.f64, WEDM_F_WORKPIECE_POS); v.x = *WEDM_ROW(s.f64, WEDM_F_WIRE_POS);
     v.v = *WEDM_ROW(s.f64, WEDM_F_WIRE_VEL); v.prev_a = *WEDM_ROW(s.f64, WEDM_F_PREV_ACCEL);
     v.debris = *WEDM_ROW(s.f64, WEDM_F_DEBRIS_VOLUME); v.rho = *WEDM_ROW(s.f64, WEDM_F_DEBRIS_DENSITY);
@@ -276,8 +295,10 @@ __device__ __forceinline__ void load_env(const wedm_state_ptrs& s, int64_t e, En
     v.ipk = 0.0;
 }
 
-__device__ __forceinline__ void store_env(const wedm_state_ptrs& s, int64_t e, const Env& v) {
-    const int64_t stride = s.stride;
+__device__ __forceinline__ void store_env(const ColdRef cold, int64_t e, const Env& v) {
+    const ColdPtr c = cold.get();
+    const int64_t stride = c->s.stride;
+    const struct { double* f64; int32_t* i32; int8_t* i8; } s{c->s.f64, c->s.i32, c->s.i8};
     *WEDM_ROW(s.f64, WEDM_F_WORKPIECE_POS) = v.wp; *WEDM_ROW(s.f64, WEDM_F_WIRE_POS) = v.x;
     *WEDM_ROW(s.f64, WEDM_F_WIRE_VEL) = v.v; *WEDM_ROW(s.f64, WEDM_F_PREV_ACCEL) = v.prev_a;
     *WEDM_ROW(s.f64, WEDM_F_DEBRIS_VOLUME) = v.debris; *WEDM_ROW(s.f64, WEDM_F_DEBRIS_DENSITY) = v.rho;
@@ -395,17 +416,18 @@ __device__ __forceinline__ void trace_scalars(const wedm_trace_desc* tr, int64_t
     }
 }
 
-__device__ __forceinline__ void load_geom(const Hot& hot, const Cold& cold, int64_t e, Geom& g) {
-    const int64_t stride = cold.s.stride;
+__device__ __forceinline__ void load_geom(const Hot& hot, const ColdRef cold, int64_t e, Geom& g) {
+    const ColdPtr c = cold.get();
+    const int64_t stride = c->s.stride;
     if (hot.per_env_geometry) {
-        const wedm_geom_ptrs& gp = cold.g;
+        const struct { const double* f64; const int32_t* i32; } gp{c->g.f64, c->g.i32};
         g.cavity_coeff = *WEDM_ROW(gp.f64, WEDM_G_CAVITY_COEFF);
         g.k = (float)*WEDM_ROW(gp.f64, WEDM_G_K_COND); g.tuf = (float)*WEDM_ROW(gp.f64, WEDM_G_TUF);
         g.n_seg = *WEDM_ROW(gp.i32, WEDM_GI_N_SEG);
         g.az_start = *WEDM_ROW(gp.i32, WEDM_GI_AZ_START); g.az_end = *WEDM_ROW(gp.i32, WEDM_GI_AZ_END);
         g.cb = *WEDM_ROW(gp.i32, WEDM_GI_CONTACT_BOTTOM); g.ct = *WEDM_ROW(gp.i32, WEDM_GI_CONTACT_TOP);
     } else {
-        const wedm_params* p = cold.p;
+        const wedm_params* p = c->p;
         g.cavity_coeff = p->cavity_coeff;
         g.k = (float)p->k_cond; g.tuf = (float)p->tuf;
         g.n_seg = p->n_seg; g.az_start = p->az_start; g.az_end = p->az_end;
@@ -414,7 +436,7 @@ __device__ __forceinline__ void load_geom(const Hot& hot, const Cold& cold, int6
 }
 
 // wire.py:349-374: h_eff * A products the stencil uses (float32 x float32, wire.py:109)
-__device__ __forceinline__ void refresh_convection(const Hot& hot, const Cold& cold, int64_t e, const Env& s,
+__device__ __forceinline__ void refresh_convection(const Hot& hot, const ColdRef cold, int64_t e, const Env& s,
                                                    Persist& ps) {
     const float A = (float)WEDM_COLD_GEOM_F64(cold, hot, WEDM_G_A_SURF, a_surf);
     ps.conv_base = s.h_base * A;
@@ -422,11 +444,11 @@ __device__ __forceinline__ void refresh_convection(const Hot& hot, const Cold& c
 }
 
 // once per launch: coefficients whose inputs no module changes (wire.py:304-312)
-__device__ __forceinline__ void init_persist(const Hot& hot, const Cold& cold, int64_t e, const Env& s, Persist& ps) {
+__device__ __forceinline__ void init_persist(const Hot& hot, const ColdRef cold, int64_t e, const Env& s, Persist& ps) {
     double adv = 0.0;
     if (__builtin_fabs(s.unwind) > 1e-6) {
         const double s_area = WEDM_COLD_GEOM_F64(cold, hot, WEDM_G_S_AREA, s_area);
-        adv = cold.p->rho_c * __builtin_fabs(s.unwind) * s_area;
+        adv = cold->p->rho_c * __builtin_fabs(s.unwind) * s_area;
     }
     ps.adv_on = __builtin_fabs(adv) > 1e-9;  // wire.py:115
     ps.adv = ps.adv_on ? (float)adv : 0.0f;
@@ -436,17 +458,31 @@ __device__ __forceinline__ void init_persist(const Hot& hot, const Cold& cold, i
 // --------------------------------------------------- scalar prelude (modules 1-4a)
 // wire_edm.py:117-121 latch, ignition.py:175-319, material.py:79-174,
 // dielectric.py:82-163, wire.py:271-312.  Returns the per-step stencil coefficients.
-__device__ __forceinline__ Coef scalar_prelude(const Hot& p, const Cold& cold, const Geom& g, int64_t e,
-                                               uint32_t gid, Env& s, Persist& ps) {
+// Running get_crater_statistics (material.py:207-227), kept in HBM.  No-return atomics: the
+// wave does not wait for memory (a load-modify-store here stalled the wave for two HBM round
+// trips at almost every third microsecond, since some lane of a wave nearly always sparks:
+// -5 % on the 400-segment workload).  One lane per environment updates, in spark order, so the
+// sums are the same sequence of IEEE additions as the oracle's.
+__device__ __forceinline__ void crater_stats_update(double* st, int64_t sd, double vol) {
+    (void)__hip_atomic_fetch_add(st + WEDM_S_CRATER_SUM * sd, vol, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    (void)__hip_atomic_fetch_add(st + WEDM_S_CRATER_SUMSQ * sd, vol * vol, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    (void)__hip_atomic_fetch_min(st + WEDM_S_CRATER_MIN * sd, vol, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    (void)__hip_atomic_fetch_max(st + WEDM_S_CRATER_MAX * sd, vol, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+// `writer`: the one lane of an environment's L lanes that updates per-environment global memory
+// beyond the state blocks (the running statistics).
+__device__ __forceinline__ Coef scalar_prelude(const Hot& p, const ColdRef cold, const Geom& g, int64_t e,
+                                               uint32_t gid, Env& s, Persist& ps, bool writer) {
     // ---- control-step latch (wire_edm.py:117-121,162-170)
     s.ctrl = s.tss >= p.servo_interval;
     if (s.ctrl) {
-        const wedm_action_ptrs& act = cold.a;
-        s.tdelta = act.servo[e];
-        s.tvolt = act.target_voltage[e];
-        s.mode = act.current_mode[e];
-        s.on = act.on_time[e];
-        s.off = act.off_time[e];
+        const ColdPtr c = cold.get();
+        s.tdelta = c->a.servo[e];
+        s.tvolt = c->a.target_voltage[e];
+        s.mode = c->a.current_mode[e];
+        s.on = c->a.on_time[e];
+        s.off = c->a.off_time[e];
         s.tss = 0;
         s.ipk = peak_current(cold, s.mode);
     }
@@ -476,7 +512,7 @@ __device__ __forceinline__ Coef scalar_prelude(const Hot& p, const Cold& cold, c
         if (!timers && !hard && ex <= 24.0 && ex >= -500) p_d = 1.0 / (1.0 + portable_exp(ex));
         double p_r = 0.0;
         if (p.has_random_short) {  // ignition.py:221-230; max_probability == 0 by default
-            const wedm_params* c = opaque(cold.p);
+            const wedm_params* c = opaque(cold->p);
             if (gap >= c->random_short_max_gap) p_r = 0.0;
             else if (gap <= c->random_short_min_gap) p_r = c->random_short_max_probability;
             else
@@ -498,7 +534,7 @@ __device__ __forceinline__ Coef scalar_prelude(const Hot& p, const Cold& cold, c
             new_r = !timers && !new_d && (u32_to_unit(w.y) < p_r);
         }
         if (new_d || new_r) {  // rare: a short begins (durations are cold parameters)
-            const wedm_params* c = opaque(cold.p);
+            const wedm_params* c = opaque(cold->p);
             if (new_d) s.deb_rem = c->debris_short_duration;
             else s.rnd_rem = c->random_short_duration;
         }
@@ -542,13 +578,15 @@ __device__ __forceinline__ Coef scalar_prelude(const Hot& p, const Cold& cold, c
 
     // ---- material removal (material.py:79-174)
     if (fresh) {
-        const Tables& tb = cold.tb;
+        const ColdPtr cc = cold.get();
+        const Tables tb{cc->tb.mode_current, cc->tb.crater_mean, cc->tb.crater_std, cc->tb.crater_depth, cc->tb.crater_valid};
         int m = s.mode == 0 ? 1 : s.mode;  // None -> "I1" (material.py:104-105)
         if (m < 1 || m > WEDM_MAX_MODE || !tb.crater_valid[m]) { s.err = 1; m = 1; }
         double z = philox_std_normal(s.key0, s.key1, t, ep, gid);
         double vol = tb.crater_mean[m] + tb.crater_std[m] * z;
         if (!(vol > 0)) vol = 0;
         s.sparks += 1;
+        if (writer && cc->s.stats) crater_stats_update(cc->s.stats + e, cc->s.stride, vol);
         double crater = vol / 1e9;
         s.last_crater = crater;
         if (crater > 0) {
@@ -577,7 +615,7 @@ __device__ __forceinline__ Coef scalar_prelude(const Hot& p, const Cold& cold, c
             s.rho = 0.0;
         }
         if (__builtin_fabs(gap_um - s.last_gap) > 0.01 || __builtin_fabs(s.rho - s.last_rho) > 0.001) {
-            const wedm_params* c = opaque(cold.p);
+            const wedm_params* c = opaque(cold->p);
             double cube = cube_cr(gap_um / c->reference_gap);
             double gap_factor = cube < 1.0 ? cube : 1.0;
             double kd = c->debris_obstruction_coeff * s.rho;
@@ -600,7 +638,7 @@ __device__ __forceinline__ Coef scalar_prelude(const Hot& p, const Cold& cold, c
     {
         const double I = s.I, I2 = I * I;
         if (__builtin_fabs(s.flow - s.wire_last_flow) > 0.01) {
-            const wedm_params* c = opaque(cold.p);
+            const wedm_params* c = opaque(cold->p);
             double ve = c->convection_velocity_factor * s.unwind;
             ve = ve > -0.9 ? ve : -0.9;
             double hb = c->base_convection * (1.0 + ve);
@@ -615,7 +653,7 @@ __device__ __forceinline__ Coef scalar_prelude(const Hot& p, const Cold& cold, c
         cf.pidx = -1;
         cf.q = 0.0f;
         if (s.state == 1 && s.y == s.y) {
-            const wedm_params* c = opaque(cold.p);
+            const wedm_params* c = opaque(cold->p);
             const int zone_start = WEDM_COLD_GEOM_I32(cold, p, WEDM_GI_ZONE_START, zone_start);
             const double seg = c->segment_len;
             int idx = seg != 0 ? zone_start + (int)py_floordiv(s.y, seg) : zone_start;
@@ -628,7 +666,7 @@ __device__ __forceinline__ Coef scalar_prelude(const Hot& p, const Cold& cold, c
         cf.jf = 0.0f;
         if (cf.joule_on) {
             const double joule_geom = WEDM_COLD_GEOM_F64(cold, p, WEDM_G_JOULE_GEOM, joule_geom);
-            cf.jf = (float)(joule_geom * I2 * opaque(cold.p)->rho_elec);
+            cf.jf = (float)(joule_geom * I2 * opaque(cold->p)->rho_elec);
         }
     }
     return cf;
@@ -763,11 +801,12 @@ __device__ __forceinline__ void scalar_epilogue(const Hot& p, Env& s, float tmax
     else if (s.wp >= s.tpos) { s.reached = 1; s.done = 1; }
 }
 
-__device__ __forceinline__ void write_obs(const Cold& cold, int64_t e, const Env& s) {
-    const wedm_state_ptrs& st = cold.s;
-    if (!st.obs || cold.p->obs_dim < 8) return;
-    const int64_t stride = st.stride;
-    float* o = st.obs + e;
+__device__ __forceinline__ void write_obs(const ColdRef cold, int64_t e, const Env& s) {
+    const ColdPtr c = cold.get();
+    float* obs = c->s.obs;
+    if (!obs || c->p->obs_dim < 8) return;
+    const int64_t stride = c->s.stride;
+    float* o = obs + e;
     o[0 * stride] = (float)(s.wp - s.x);
     o[1 * stride] = (float)s.v;
     o[2 * stride] = (float)s.V;

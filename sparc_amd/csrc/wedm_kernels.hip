@@ -28,6 +28,7 @@
 
 #include <algorithm>
 #include <climits>
+#include <cstddef>
 #include <cstdint>
 #include <cstdio>
 #include <cstring>
@@ -75,6 +76,11 @@ struct KArgs {
     unsigned long long* dbg; // diagnostic builds only (WEDM_STAMPS): per-wave phase cycle sums
 };
 
+// The by-value `cold` member as the kernels read it: through the kernarg segment (wedm_device.h).
+__device__ __forceinline__ ColdRef kernarg_cold() {
+    return ColdRef{(ColdPtr)((const WEDM_AS4 char*)__builtin_amdgcn_kernarg_segment_ptr() + offsetof(KArgs, cold))};
+}
+
 // ------------------------------------------------------------ signal trace
 // The sample schedule is host-made and identical for every wave: `it == trace_next` is a scalar
 // compare per microsecond; the descriptor is only touched inside the (rare) branch.  While a
@@ -88,7 +94,7 @@ struct KArgs {
 // CELLS: statement that copies this lane's wire cells, given `tT` (slot base + column) and `tcnt`
 #define WEDM_TRACE_POINT(k, it, e, s, SCALAR_LANE, CELLS)                                        \
     if (TRACE && (it) == trace_next) {                                                           \
-        const wedm_trace_desc* tr = opaque((k).cold.tr);                                         \
+        const wedm_trace_desc* tr = opaque(cold->tr);                                         \
         const int64_t tcol = trace_column(tr, (e));                                              \
         if (tcol >= 0) {                                                                         \
             if (SCALAR_LANE) trace_scalars(tr, tcol, (s), trace_slot);                           \
@@ -145,19 +151,19 @@ __device__ __forceinline__ float stencil_pass(const TA& T, const Geom& g, const 
 }
 
 template <bool TRACE, class TA>
-__device__ __forceinline__ void run_substeps(const KArgs& k, const Geom& g, int64_t e, uint32_t gid, Env& s,
-                                             const TA& T) {
+__device__ __forceinline__ void run_substeps(const KArgs& k, const ColdRef cold, const Geom& g, int64_t e,
+                                             uint32_t gid, Env& s, const TA& T) {
     Persist ps;
-    init_persist(k.hot, k.cold, e, s, ps);
+    init_persist(k.hot, cold, e, s, ps);
     const bool tracing = WEDM_TRACING(k);
     int trace_next = k.trace_next, trace_slot = k.trace_slot;
     (void)trace_next; (void)trace_slot;
     for (int it = 0; it < k.n_substeps; ++it) {
         if (!s.done) {
-            Coef c = scalar_prelude(k.hot, k.cold, g, e, gid, s, ps);  // single steps: the quiet test does not pay
+            Coef c = scalar_prelude(k.hot, cold, g, e, gid, s, ps, true);  // single steps: the quiet test does not pay
             float tmax = stencil_pass(T, g, c, ps, k.hot.spool, k.hot.tref, k.hot.alpha, k.hot.tdiel);
             scalar_epilogue(k.hot, s, tmax);
-            if (s.ctrl) write_obs(k.cold, e, s);
+            if (s.ctrl) write_obs(cold, e, s);
         } else if (!tracing) {
             break;
         }
@@ -168,17 +174,18 @@ __device__ __forceinline__ void run_substeps(const KArgs& k, const Geom& g, int6
 
 template <bool TRACE>
 __global__ void __launch_bounds__(256) wedm_step_global(const KArgs k) {
+    const ColdRef cold = kernarg_cold();
     const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (e >= k.num_envs) return;
     Env s;
-    load_env(k.cold.s, e, s);
+    load_env(cold, e, s);
     if (s.done && !WEDM_TRACING(k)) return;
-    s.ipk = s.done ? 0.0 : peak_current(k.cold, s.mode);
+    s.ipk = s.done ? 0.0 : peak_current(cold, s.mode);
     Geom g;
-    load_geom(k.hot, k.cold, e, g);
-    GlobalT T{k.cold.s.T + e, k.cold.s.stride};
-    run_substeps<TRACE>(k, g, e, k.hot.env_id_offset + (uint32_t)e, s, T);
-    store_env(k.cold.s, e, s);
+    load_geom(k.hot, cold, e, g);
+    GlobalT T{cold->s.T + e, cold->s.stride};
+    run_substeps<TRACE>(k, cold, g, e, k.hot.env_id_offset + (uint32_t)e, s, T);
+    store_env(cold, e, s);
 }
 
 // np.max over finite temperatures; maps to v_max_f32 / v_max3_f32
@@ -190,6 +197,7 @@ __device__ __forceinline__ float fmax_gt(float a, float b) { return __builtin_fm
 // environment with a shorter wire simply leaves the tail of its last chunks unused.
 template <int L, bool TRACE>
 __global__ void __launch_bounds__(256, 2) wedm_step_lanes(const KArgs k) {
+    const ColdRef cold = kernarg_cold();
     extern __shared__ __attribute__((aligned(16))) float lds[];
     constexpr int EPB = 256 / L;
     const int tid = threadIdx.x;
@@ -199,13 +207,13 @@ __global__ void __launch_bounds__(256, 2) wedm_step_lanes(const KArgs k) {
     const bool live = e < k.num_envs;
     const int nmax = k.n_seg_max;
     const int C = (nmax + L - 1) / L;
-    const int64_t stride = k.cold.s.stride;
+    const int64_t stride = cold->s.stride;
     {
         const int r = tid / EPB, sel = tid % EPB;
         int ci = 0, ji = r;
         while (ji >= C) { ji -= C; ++ci; }
         const bool ok = e0 + sel < k.num_envs;
-        const float* src = k.cold.s.T + e0 + sel;
+        const float* src = cold->s.T + e0 + sel;
         for (int i0 = 0; i0 < nmax; i0 += L) {
             const int i = i0 + r;
             if (i < nmax && ok) lds[ji * 256 + sel * L + ci] = src[(int64_t)i * stride];
@@ -218,12 +226,12 @@ __global__ void __launch_bounds__(256, 2) wedm_step_lanes(const KArgs k) {
     Env s;
     Geom g;
     Persist ps{0.0f, 0.0f, 0.0f, 0};
-    load_geom(k.hot, k.cold, live ? e : 0, g);
-    if (live) load_env(k.cold.s, e, s);
+    load_geom(k.hot, cold, live ? e : 0, g);
+    if (live) load_env(cold, e, s);
     else { s.done = 1; s.unwind = 0.0; s.h_base = 0.0f; s.h_zone = 0.0f; }
     if (!s.done) {
-        s.ipk = peak_current(k.cold, s.mode);
-        init_persist(k.hot, k.cold, e, s, ps);
+        s.ipk = peak_current(cold, s.mode);
+        init_persist(k.hot, cold, e, s, ps);
     }
     const uint32_t gid = k.hot.env_id_offset + (uint32_t)e;
     float* col = lds + tid;
@@ -238,7 +246,7 @@ __global__ void __launch_bounds__(256, 2) wedm_step_lanes(const KArgs k) {
     for (int it = 0; it < k.n_substeps; ++it) {
         if (__all(s.done) && !tracing) break;
         Coef cf{0.0f, 0.0f, 0, -1};
-        if (!quiet_prelude(k.hot, g, gid, s) && !s.done) cf = scalar_prelude(k.hot, k.cold, g, e, gid, s, ps);
+        if (!quiet_prelude(k.hot, g, gid, s) && !s.done) cf = scalar_prelude(k.hot, cold, g, e, gid, s, ps, c == 0);
         const float halo_l = (c > 0) ? col[(C - 1) * 256 - 1] : spool;
         const float halo_r = (c < L - 1) ? col[1] : 0.0f;
         float tmax = spool, tm1 = halo_l, tc = col[0];
@@ -269,7 +277,7 @@ __global__ void __launch_bounds__(256, 2) wedm_step_lanes(const KArgs k) {
         for (int m = 1; m < L; m <<= 1) tmax = fmax_gt(tmax, __shfl_xor(tmax, m));
         if (!s.done) {
             scalar_epilogue(k.hot, s, tmax);
-            if (s.ctrl && c == 0) write_obs(k.cold, e, s);
+            if (s.ctrl && c == 0) write_obs(cold, e, s);
         }
         WEDM_TRACE_POINT(k, it, e, s, c == 0,
                          for (int j = 0; j < C && cbase + j < n; ++j) tT[(int64_t)(cbase + j) * tcnt] = col[j * 256]);
@@ -281,7 +289,7 @@ __global__ void __launch_bounds__(256, 2) wedm_step_lanes(const KArgs k) {
         int ci = 0, ji = r;
         while (ji >= C) { ji -= C; ++ci; }
         const bool ok = e0 + sel < k.num_envs;
-        float* dst = k.cold.s.T + e0 + sel;
+        float* dst = cold->s.T + e0 + sel;
         for (int i0 = 0; i0 < nmax; i0 += L) {
             const int i = i0 + r;
             if (i < nmax && ok) dst[(int64_t)i * stride] = lds[ji * 256 + sel * L + ci];
@@ -289,7 +297,7 @@ __global__ void __launch_bounds__(256, 2) wedm_step_lanes(const KArgs k) {
             while (ji >= C) { ji -= C; ++ci; }
         }
     }
-    if (live && c == 0) store_env(k.cold.s, e, s);
+    if (live && c == 0) store_env(cold, e, s);
 }
 
 // In-kernel phase stamps (diagnostic build -DWEDM_STAMPS only; never in the shipped library).
@@ -414,6 +422,7 @@ __device__ __forceinline__ void tile8_staged(const V (&old)[10], V (&tn)[8], flo
 
 template <int L, bool TRACE>
 __global__ void __launch_bounds__(256, 2) wedm_step_fused(const KArgs k) {
+    const ColdRef cold = kernarg_cold();
     extern __shared__ __attribute__((aligned(16))) float lds[];
     constexpr int EPB = 256 / L;  // environments per block
     const int tid = threadIdx.x;
@@ -424,7 +433,7 @@ __global__ void __launch_bounds__(256, 2) wedm_step_fused(const KArgs k) {
     const WalkTable* __restrict__ wt = k.walk;
     const int C = wt->C;
     const int n = k.hot.n_seg;
-    const int64_t stride = k.cold.s.stride;
+    const int64_t stride = cold->s.stride;
 
     // ---- stage the block's EPB wire columns: coalesced rows of T[seg][env] -> LDS
     {
@@ -432,7 +441,7 @@ __global__ void __launch_bounds__(256, 2) wedm_step_fused(const KArgs k) {
         int ci = 0, ji = r;                        // (chunk, cell) of row i = i0 + r
         while (ji >= C) { ji -= C; ++ci; }
         const bool ok = e0 + sel < k.num_envs;
-        const float* src = k.cold.s.T + e0 + sel;
+        const float* src = cold->s.T + e0 + sel;
         for (int i0 = 0; i0 < n; i0 += L) {
             const int i = i0 + r;
             if (i < n && ok) lds[ji * 256 + sel * L + ci] = src[(int64_t)i * stride];
@@ -445,12 +454,12 @@ __global__ void __launch_bounds__(256, 2) wedm_step_fused(const KArgs k) {
     Env s;
     Geom g;
     Persist ps{0.0f, 0.0f, 0.0f, 0};
-    load_geom(k.hot, k.cold, live ? e : 0, g);
-    if (live) load_env(k.cold.s, e, s);
+    load_geom(k.hot, cold, live ? e : 0, g);
+    if (live) load_env(cold, e, s);
     else { s.done = 1; s.unwind = 0.0; s.h_base = 0.0f; s.h_zone = 0.0f; }
     if (!s.done) {
-        s.ipk = peak_current(k.cold, s.mode);
-        init_persist(k.hot, k.cold, e, s, ps);
+        s.ipk = peak_current(cold, s.mode);
+        init_persist(k.hot, cold, e, s, ps);
     }
     const uint32_t gid = k.hot.env_id_offset + (uint32_t)e;
 
@@ -489,7 +498,7 @@ __global__ void __launch_bounds__(256, 2) wedm_step_fused(const KArgs k) {
         if (__all(s.done) && !tracing) break;
         WEDM_STAMP(st0);
         Coef cf{0.0f, 0.0f, 0, -1};
-        if (!quiet_prelude(k.hot, g, gid, s) && !s.done) cf = scalar_prelude(k.hot, k.cold, g, e, gid, s, ps);
+        if (!quiet_prelude(k.hot, g, gid, s) && !s.done) cf = scalar_prelude(k.hot, cold, g, e, gid, s, ps, c == 0);
         WEDM_STAMP(st1);
 
         // ---- halos: OLD neighbour values, read before any lane of this wave stores.  The right
@@ -650,7 +659,7 @@ __global__ void __launch_bounds__(256, 2) wedm_step_fused(const KArgs k) {
         WEDM_STAMP(st3);
         if (!s.done) {
             scalar_epilogue(k.hot, s, tmax);
-            if (s.ctrl && c == 0) write_obs(k.cold, e, s);
+            if (s.ctrl && c == 0) write_obs(cold, e, s);
         }
         WEDM_TRACE_POINT(k, it, e, s, c == 0,
                          for (int j = 0; j < C && cbase + j < n; ++j) tT[(int64_t)(cbase + j) * tcnt] = col[j * 256]);
@@ -665,7 +674,7 @@ __global__ void __launch_bounds__(256, 2) wedm_step_fused(const KArgs k) {
         int ci = 0, ji = r;
         while (ji >= C) { ji -= C; ++ci; }
         const bool ok = e0 + sel < k.num_envs;
-        float* dst = k.cold.s.T + e0 + sel;
+        float* dst = cold->s.T + e0 + sel;
         for (int i0 = 0; i0 < n; i0 += L) {
             const int i = i0 + r;
             if (i < n && ok) dst[(int64_t)i * stride] = lds[ji * 256 + sel * L + ci];
@@ -673,7 +682,7 @@ __global__ void __launch_bounds__(256, 2) wedm_step_fused(const KArgs k) {
             while (ji >= C) { ji -= C; ++ci; }
         }
     }
-    if (live && c == 0) store_env(k.cold.s, e, s);
+    if (live && c == 0) store_env(cold, e, s);
 }
 
 
@@ -702,6 +711,7 @@ __device__ __forceinline__ f2 interior2(f2 tm1, f2 tc, f2 tp1, float k, float tu
 
 template <int L, bool TRACE>
 __global__ void __launch_bounds__(256, 2) wedm_step_packed(const KArgs k) {
+    const ColdRef cold = kernarg_cold();
     extern __shared__ __attribute__((aligned(16))) float lds[];
     constexpr int EPB = 256 / L;
     const int tid = threadIdx.x;
@@ -713,7 +723,7 @@ __global__ void __launch_bounds__(256, 2) wedm_step_packed(const KArgs k) {
     const int Cv = wt->C;
     const int R = 2 * Cv;  // data rows per lane; rows R and R+1 are the halo pair
     const int n = k.hot.n_seg;
-    const int64_t stride = k.cold.s.stride;
+    const int64_t stride = cold->s.stride;
 
     // ---- stage: wire cell i -> virtual chunk vc = i / Cv, cell r = i % Cv -> lane vc/2, row 2r + vc%2
     {
@@ -721,7 +731,7 @@ __global__ void __launch_bounds__(256, 2) wedm_step_packed(const KArgs k) {
         int vc = 0, r = rr;
         while (r >= Cv) { r -= Cv; ++vc; }
         const bool ok = e0 + sel < k.num_envs;
-        const float* src = k.cold.s.T + e0 + sel;
+        const float* src = cold->s.T + e0 + sel;
         for (int i0 = 0; i0 < n; i0 += L) {
             const int i = i0 + rr;
             if (i < n && ok) lds[(2 * r + (vc & 1)) * 256 + sel * L + (vc >> 1)] = src[(int64_t)i * stride];
@@ -734,12 +744,12 @@ __global__ void __launch_bounds__(256, 2) wedm_step_packed(const KArgs k) {
     Env s;
     Geom g;
     Persist ps{0.0f, 0.0f, 0.0f, 0};
-    load_geom(k.hot, k.cold, live ? e : 0, g);
-    if (live) load_env(k.cold.s, e, s);
+    load_geom(k.hot, cold, live ? e : 0, g);
+    if (live) load_env(cold, e, s);
     else { s.done = 1; s.unwind = 0.0; s.h_base = 0.0f; s.h_zone = 0.0f; }
     if (!s.done) {
-        s.ipk = peak_current(k.cold, s.mode);
-        init_persist(k.hot, k.cold, e, s, ps);
+        s.ipk = peak_current(cold, s.mode);
+        init_persist(k.hot, cold, e, s, ps);
     }
     const uint32_t gid = k.hot.env_id_offset + (uint32_t)e;
 
@@ -782,7 +792,7 @@ __global__ void __launch_bounds__(256, 2) wedm_step_packed(const KArgs k) {
         if (__all(s.done) && !tracing) break;
         WEDM_STAMP(st0);
         Coef cf{0.0f, 0.0f, 0, -1};
-        if (!quiet_prelude(k.hot, g, gid, s) && !s.done) cf = scalar_prelude(k.hot, k.cold, g, e, gid, s, ps);
+        if (!quiet_prelude(k.hot, g, gid, s) && !s.done) cf = scalar_prelude(k.hot, cold, g, e, gid, s, ps, c == 0);
         WEDM_STAMP(st1);
 
         // ---- halos (OLD values, read before any store of this step)
@@ -958,7 +968,7 @@ __global__ void __launch_bounds__(256, 2) wedm_step_packed(const KArgs k) {
         WEDM_STAMP(st3);
         if (!s.done) {
             scalar_epilogue(k.hot, s, tmax);
-            if (s.ctrl && c == 0) write_obs(k.cold, e, s);
+            if (s.ctrl && c == 0) write_obs(cold, e, s);
         }
         WEDM_TRACE_POINT(k, it, e, s, c == 0,
                          for (int r = 0; r < Cv; ++r) {
@@ -976,7 +986,7 @@ __global__ void __launch_bounds__(256, 2) wedm_step_packed(const KArgs k) {
         int vc = 0, r = rr;
         while (r >= Cv) { r -= Cv; ++vc; }
         const bool ok = e0 + sel < k.num_envs;
-        float* dst = k.cold.s.T + e0 + sel;
+        float* dst = cold->s.T + e0 + sel;
         for (int i0 = 0; i0 < n; i0 += L) {
             const int i = i0 + rr;
             if (i < n && ok) dst[(int64_t)i * stride] = lds[(2 * r + (vc & 1)) * 256 + sel * L + (vc >> 1)];
@@ -984,7 +994,7 @@ __global__ void __launch_bounds__(256, 2) wedm_step_packed(const KArgs k) {
             while (r >= Cv) { r -= Cv; ++vc; }
         }
     }
-    if (live && c == 0) store_env(k.cold.s, e, s);
+    if (live && c == 0) store_env(cold, e, s);
 }
 
 
@@ -1000,6 +1010,10 @@ wedm_reset_kernel(const wedm_params p, const wedm_state_ptrs s, int32_t num_envs
     for (int f = 0; f < WEDM_F64_COUNT; ++f) *WEDM_ROW(s.f64, f) = 0.0;
     for (int f = 0; f < WEDM_I32_COUNT; ++f) *WEDM_ROW(s.i32, f) = 0;
     for (int f = 0; f < WEDM_I8_COUNT; ++f) *WEDM_ROW(s.i8, f) = 0;
+    if (s.stats) {
+        *WEDM_ROW(s.stats, WEDM_S_CRATER_SUM) = 0.0; *WEDM_ROW(s.stats, WEDM_S_CRATER_SUMSQ) = 0.0;
+        *WEDM_ROW(s.stats, WEDM_S_CRATER_MIN) = __builtin_inf(); *WEDM_ROW(s.stats, WEDM_S_CRATER_MAX) = -__builtin_inf();
+    }
     if (reseed) {
         *WEDM_ROW(s.i32, WEDM_I_EPISODE) = 0;
         *WEDM_ROW(s.i32, WEDM_I_KEY_LO) = (int32_t)key_lo;

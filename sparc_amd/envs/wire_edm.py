@@ -356,6 +356,23 @@ class WireEDMEnv:
                 "cavity_volume_mm3": st.cavity_volume, "flow_condition": st.flow_rate,
                 "debris_fill_percentage": st.debris_density * 100.0}
 
+    def get_crater_statistics(self) -> Dict[str, torch.Tensor]:
+        """`MaterialRemovalModule.get_crater_statistics` (material.py:207-227), per environment, from
+        the running sum / sum of squares / min / max the kernels keep at every fresh spark (the
+        list of all volumes, ``volumes_um3``, is not kept; trace ``last_crater_volume`` to get it).
+        Zeros while an environment has had no crater, as in the reference."""
+        from .._abi import STAT
+
+        st, n = self.state.stats[:, : self.num_envs], self.state.spark_count
+        none = n == 0
+        denom = torch.clamp(n, min=1).to(torch.float64)
+        mean = st[STAT.CRATER_SUM] / denom
+        var = torch.clamp(st[STAT.CRATER_SUMSQ] / denom - mean * mean, min=0.0)
+        zero = torch.zeros_like(mean)
+        return {"total_craters": n, "mean_volume_um3": mean, "std_volume_um3": torch.sqrt(var),
+                "min_volume_um3": torch.where(none, zero, st[STAT.CRATER_MIN]),
+                "max_volume_um3": torch.where(none, zero, st[STAT.CRATER_MAX])}
+
     def get_crater_count(self) -> torch.Tensor:
         """`len(MaterialRemovalModule.crater_volumes_um3)` (material.py:133), per environment."""
         return self.state.spark_count

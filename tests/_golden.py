@@ -61,6 +61,7 @@ class Fixture:
         self.T_snaps = z["T_snaps"]
         self.T_snap_steps = z["T_snap_steps"]
         self.forced = z["forced"] if "forced" in z.files else None
+        self.data = {k: z[k] for k in ("crater_stats", "crater_volumes_um3") if k in z.files}
         self.float_fields = list(self.meta["float_fields"])
         self.int_fields = list(self.meta["int_fields"])
         self.n_steps = int(self.meta["n_steps_run"])

@@ -658,3 +658,25 @@ def test_voltage_controller_driver_on_gpu_matches_reference_fixture(golden_dir):
         if latch:
             action = ctl(env)
             assert float(action.servo[2]) == fx.actions[fx.action_idx[step + 1], 0], step
+
+
+def test_crater_statistics_on_gpu_match_reference_fixture(golden_dir):
+    """§8f-4: the running crater statistics kept by the kernels against the reference's
+    `get_crater_statistics()` (fixture F10, 140 craters), fused launches, three kernel variants."""
+    from tests._golden import Fixture
+
+    fx = Fixture(golden_dir / "f10_crater_statistics_philox_env1.npz")
+    total, mean, std, vmin, vmax = fx.data["crater_stats"].tolist()
+    for variant, lanes in ((0, 0), (3, 16), (1, 0)):
+        env = WireEDMEnv(num_envs=64, device="cuda:0")
+        env.set_kernel(variant, lanes)
+        env.reset(seed=81)
+        close_gap(env, 22.0, 10.0, 5000.0)
+        act = env.make_action(0.05, 80.0, 13, 2.0, 20.0)
+        for _ in range(12):
+            env.step_many(act, 1000)
+        got = {k: v[1].item() for k, v in env.get_crater_statistics().items()}
+        assert got["total_craters"] == total, (variant, got)
+        assert got["min_volume_um3"] == vmin and got["max_volume_um3"] == vmax
+        assert abs(got["mean_volume_um3"] - mean) <= 1e-12 * mean and abs(got["std_volume_um3"] - std) <= 1e-12 * std
+        assert float(env.state.workpiece_position[1]) == float(fx.float_row("workpiece_position")[-1])

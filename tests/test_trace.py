@@ -213,3 +213,48 @@ def test_logger_and_voltage_controller_share_one_trace():
     assert float(ctl.average_voltage()[0]) == float(d["voltage"][-1001:, 0].sum() / 1001)
     with pytest.raises(ValueError):
         VoltageController().bind(env, env.bind_trace(["voltage"], every=2, capacity=2000))
+
+
+# ------------------------------------------------------------------ running statistics (§8f-4)
+def crater_env(n, backend, device="cpu"):
+    env = WireEDMEnv(num_envs=n, device=device, backend=backend)
+    env.reset(seed=81)
+    env.state.workpiece_position = 22.0
+    env.state.wire_position = 10.0
+    env.state.target_position = 5000.0
+    return env
+
+
+def test_crater_statistics_match_the_reference(golden_dir):
+    """`MaterialRemovalModule.get_crater_statistics()` of the reference after 12 000 us of dense
+    sparking (fixture F10, 140 craters) against the running statistics kept at every fresh spark:
+    count / min / max exact, mean and std to 1e-12 (np.mean / np.std sum pairwise, the kernel
+    updates Welford's recurrence; both are float64)."""
+    fx = Fixture(golden_dir / "f10_crater_statistics_philox_env1.npz")
+    env = crater_env(3, LibmOracleBackend)
+    act = env.make_action(0.05, 80.0, 13, 2.0, 20.0)
+    assert (env.get_crater_statistics()["total_craters"] == 0).all()
+    trace = env.bind_trace(["last_crater_volume", "spark_state", "spark_duration"], capacity=fx.n_steps, envs=(1, 1))
+    for _ in range(12):
+        env.step_many(act, 1000)
+    check_step(env, fx, 1, fx.n_steps - 1, exact_floats=True)
+    total, mean, std, vmin, vmax = fx.data["crater_stats"].tolist()
+    got = {k: v[1].item() for k, v in env.get_crater_statistics().items()}
+    assert got["total_craters"] == total == 140
+    assert got["min_volume_um3"] == vmin and got["max_volume_um3"] == vmax
+    assert abs(got["mean_volume_um3"] - mean) <= 1e-12 * mean
+    assert abs(got["std_volume_um3"] - std) <= 1e-12 * std
+    # the full list of the reference (`volumes_um3`) is recoverable from the per-microsecond trace
+    t = trace.read()
+    fresh = (t["spark_state"][:, 0] == 1) & (t["spark_duration"][:, 0] == 0)
+    vols_mm3 = t["last_crater_volume"][:, 0][fresh].numpy()
+    assert np.array_equal(vols_mm3, fx.data["crater_volumes_um3"] / 1e9)
+    # environments without craters report zeros, like the reference's empty case
+    idle = WireEDMEnv(num_envs=2, device="cpu", backend=OracleBackend)
+    idle.reset(seed=1)
+    idle.step_many(idle.make_action(), 100)
+    assert all(float(v.abs().sum()) == 0 for v in idle.get_crater_statistics().values())
+    # a partial reset clears the statistics of the selected environments only
+    env.reset(options={"mask": torch.tensor([False, True, False])})
+    st = env.get_crater_statistics()
+    assert st["total_craters"].tolist()[1] == 0 and st["mean_volume_um3"][1] == 0 and st["total_craters"][0] > 0

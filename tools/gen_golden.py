@@ -277,6 +277,11 @@ def run_scenario(name, *, n_steps, seed=0, config=None, control_mode="position",
         "T_snaps": np.array(t_snaps, dtype=np.float32),
         "T_snap_steps": np.array(t_snap_steps, dtype=np.int32),
     }
+    # MaterialRemovalModule.get_crater_statistics() (material.py:207-227) at the end of the run
+    cs = env.material.get_crater_statistics()
+    arrays["crater_volumes_um3"] = np.asarray(cs["volumes_um3"], dtype=np.float64)
+    arrays["crater_stats"] = np.array([cs["total_craters"], cs["mean_volume_um3"], cs["std_volume_um3"],
+                                       cs["min_volume_um3"], cs["max_volume_um3"]], dtype=np.float64)
     if forced_rows:
         arrays["forced"] = np.array(forced_rows, dtype=np.float64)
     OUT.mkdir(parents=True, exist_ok=True)
@@ -465,6 +470,12 @@ def main():
                  control_mode="velocity", controller=VoltageDriver(30.0),
                  state_init={"workpiece_position": 70.0, "wire_position": 10.0, "target_position": 5000.0},
                  t_snap_every=3000, float_stride=9, note="run_simulation.py voltage controller, velocity mode")
+
+    # F10 — many craters: get_crater_statistics() (material.py:207-227) over a busy run
+    run_scenario("f10_crater_statistics_philox_env1", n_steps=12000, seed=81, rng="philox", env_id=1,
+                 state_init={"workpiece_position": 22.0, "wire_position": 10.0, "target_position": 5000.0},
+                 action=make_action(0.05, 80.0, 13, 2.0, 20.0), t_snap_every=12000, float_stride=97,
+                 note="dense sparking, mode I13: crater statistics")
 
     # geometry variants (BASELINE config 5 shapes), short Philox runs
     for i, (h, d) in enumerate(((10.0, 0.10), (15.0, 0.25), (30.0, 0.30), (12.3, 0.15))):
