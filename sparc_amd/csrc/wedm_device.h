@@ -188,6 +188,36 @@ struct Hot {
     int32_t n_seg;  // uniform geometry only
 };
 
+// Pin the float64 every-step constants in VGPRs (same value in every lane).  gfx9 VALU
+// instructions read at most ONE scalar operand, so an f64 op on two kernel constants needs a
+// v_mov of one of them anyway, and the ~45 SGPRs they occupy are what pushes the substep loop
+// into v_readlane / v_writelane SGPR spills.  Only for kernels with VGPRs to spare.
+__device__ __forceinline__ void pin_hot_in_vgprs(Hot& h) {
+#define WEDM_PIN(x) asm volatile("" : "+v"(h.x))
+    WEDM_PIN(hard_short_gap); WEDM_PIN(base_critical_density); WEDM_PIN(gap_coefficient);
+    WEDM_PIN(max_critical_density); WEDM_PIN(sigmoid_steepness);
+    WEDM_PIN(ignition_a); WEDM_PIN(ignition_b); WEDM_PIN(ignition_c); WEDM_PIN(ln2);
+    WEDM_PIN(default_target_voltage); WEDM_PIN(default_on_time); WEDM_PIN(default_off_time);
+    WEDM_PIN(spark_voltage_factor); WEDM_PIN(debris_removal_per_us);
+    WEDM_PIN(dt_s); WEDM_PIN(damping_coeff); WEDM_PIN(stiffness_coeff); WEDM_PIN(omega_n);
+    WEDM_PIN(max_acceleration); WEDM_PIN(max_jerk_dt); WEDM_PIN(max_speed);
+#undef WEDM_PIN
+}
+
+__device__ __forceinline__ void pin_mechanics_in_vgprs(Hot& h) {  // the epilogue's constants only
+#define WEDM_PIN(x) asm volatile("" : "+v"(h.x))
+    WEDM_PIN(dt_s); WEDM_PIN(damping_coeff); WEDM_PIN(stiffness_coeff); WEDM_PIN(omega_n);
+    WEDM_PIN(max_acceleration); WEDM_PIN(max_jerk_dt); WEDM_PIN(max_speed);
+#undef WEDM_PIN
+}
+
+__device__ __forceinline__ void pin_quiet_in_vgprs(Hot& h) {  // the quiet prelude's constants
+#define WEDM_PIN(x) asm volatile("" : "+v"(h.x))
+    WEDM_PIN(base_critical_density); WEDM_PIN(gap_coefficient); WEDM_PIN(max_critical_density);
+    WEDM_PIN(sigmoid_steepness); WEDM_PIN(ignition_a); WEDM_PIN(ignition_b); WEDM_PIN(ignition_c); WEDM_PIN(ln2);
+#undef WEDM_PIN
+}
+
 // per-lane geometry the every-step path needs (uniform values or the env's rows)
 struct Geom {
     double cavity_coeff;
@@ -733,14 +763,23 @@ __device__ __forceinline__ bool quiet_prelude(const Hot& p, const Geom& g, uint3
     return true;
 }
 
+// a - 2*b exactly as the reference rounds it: 2*b is exact in binary floating point, so
+// `a - (2*b)` rounds once, which is what one fused multiply-add fma(-2, b, a) computes.  The only
+// FMA in the stencil: everywhere else a product is rounded before it is added (wire.py:91-120).
+__device__ __forceinline__ float sub_twice(float a, float b) { return __builtin_fmaf(-2.0f, b, a); }
+typedef float f2v __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ f2v sub_twice(f2v a, f2v b) {
+    const f2v m2 = {-2.0f, -2.0f};
+    return __builtin_elementwise_fma(m2, b, a);
+}
+
 // one cell of wire.py:58-123, float32 op for op; tm1/tc/tp1 are OLD temperatures
 __device__ __forceinline__ float stencil_cell(int i, int n_seg, float tm1, float tc, float tp1, const Geom& g,
                                               const Coef& c, const Persist& ps, float tref, float alpha,
                                               float tdiel) {
     float d;
     if (i < n_seg - 1) {
-        float t2 = 2.0f * tc;
-        float a = tm1 - t2;
+        float a = sub_twice(tm1, tc);  // T[i-1] - 2*T[i]
         d = g.k * (a + tp1);
     } else {
         d = g.k * (tm1 - tc);

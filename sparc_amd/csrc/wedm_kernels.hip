@@ -198,6 +198,12 @@ __device__ __forceinline__ float fmax_gt(float a, float b) { return __builtin_fm
 template <int L, bool TRACE>
 __global__ void __launch_bounds__(256, 2) wedm_step_lanes(const KArgs k) {
     const ColdRef cold = kernarg_cold();
+#ifndef WEDM_NO_PIN_LANES
+    Hot hv = k.hot;
+    pin_hot_in_vgprs(hv);
+#else
+    const Hot& hv = k.hot;
+#endif
     extern __shared__ __attribute__((aligned(16))) float lds[];
     constexpr int EPB = 256 / L;
     const int tid = threadIdx.x;
@@ -246,7 +252,7 @@ __global__ void __launch_bounds__(256, 2) wedm_step_lanes(const KArgs k) {
     for (int it = 0; it < k.n_substeps; ++it) {
         if (__all(s.done) && !tracing) break;
         Coef cf{0.0f, 0.0f, 0, -1};
-        if (!quiet_prelude(k.hot, g, gid, s) && !s.done) cf = scalar_prelude(k.hot, cold, g, e, gid, s, ps, c == 0);
+        if (!quiet_prelude(hv, g, gid, s) && !s.done) cf = scalar_prelude(hv, cold, g, e, gid, s, ps, c == 0);
         const float halo_l = (c > 0) ? col[(C - 1) * 256 - 1] : spool;
         const float halo_r = (c < L - 1) ? col[1] : 0.0f;
         float tmax = spool, tm1 = halo_l, tc = col[0];
@@ -276,7 +282,7 @@ __global__ void __launch_bounds__(256, 2) wedm_step_lanes(const KArgs k) {
 #pragma unroll
         for (int m = 1; m < L; m <<= 1) tmax = fmax_gt(tmax, __shfl_xor(tmax, m));
         if (!s.done) {
-            scalar_epilogue(k.hot, s, tmax);
+            scalar_epilogue(hv, s, tmax);
             if (s.ctrl && c == 0) write_obs(cold, e, s);
         }
         WEDM_TRACE_POINT(k, it, e, s, c == 0,
@@ -334,7 +340,7 @@ __global__ void __launch_bounds__(256, 2) wedm_step_lanes(const KArgs k) {
 template <bool JOULE>
 __device__ __forceinline__ float interior_cell(float tm1, float tc, float tp1, float k, float tuf, float conv,
                                                float tdiel, float adv, float jfe, float alpha, float tref) {
-    float a = tm1 - (tc + tc);  // 2*T[i] is exact
+    float a = sub_twice(tm1, tc);  // T[i-1] - 2*T[i], one rounding
     float d = k * (a + tp1);
     if (JOULE) {
         float rho_T = 1.0f + alpha * (tc - tref);
@@ -364,7 +370,7 @@ __device__ __forceinline__ void tile_staged(const V (&old)[10], V (&tn)[8], cons
     V a[W], e[W], f[W], r[W];
 #pragma unroll
     for (int u = 0; u < W; ++u) {
-        a[u] = old[o + u + 1] + old[o + u + 1];  // 2*T[i]
+        a[u] = sub_twice(old[o + u], old[o + u + 1]);  // T[i-1] - 2*T[i] (exact product, one rounding)
         e[u] = old[o + u + 1] - tdiel;           // T[i] - T_dielectric
         f[u] = old[o + u] - old[o + u + 1];      // T[i-1] - T[i]
         if (JOULE) r[u] = old[o + u + 1] - tref;
@@ -372,7 +378,6 @@ __device__ __forceinline__ void tile_staged(const V (&old)[10], V (&tn)[8], cons
     WEDM_STAGE_FENCE();
 #pragma unroll
     for (int u = 0; u < W; ++u) {
-        a[u] = old[o + u] - a[u];
         e[u] = (PERCELL ? conv[o + u] : conv[0]) * e[u];
         f[u] = adv * f[u];
         if (JOULE) r[u] = alpha * r[u];
@@ -412,17 +417,23 @@ __device__ __forceinline__ void tile_staged(const V (&old)[10], V (&tn)[8], cons
 #ifndef WEDM_STAGE_W
 #define WEDM_STAGE_W 4
 #endif
+#ifndef WEDM_STAGE_W_PACKED
+#define WEDM_STAGE_W_PACKED 2  // as fast as 4 (the other wave of the SIMD fills the gaps) and 16 VGPRs cheaper
+#endif
 template <class V, bool JOULE, bool PERCELL>
 __device__ __forceinline__ void tile8_staged(const V (&old)[10], V (&tn)[8], float k, float tuf, const V (&conv)[8],
                                              float tdiel, float adv, const V (&jfe)[8], float alpha, float tref) {
+    constexpr int W = sizeof(V) == 8 ? WEDM_STAGE_W_PACKED : WEDM_STAGE_W;
 #pragma unroll
-    for (int o = 0; o < 8; o += WEDM_STAGE_W)
-        tile_staged<V, JOULE, PERCELL, WEDM_STAGE_W>(old, tn, o, k, tuf, conv, tdiel, adv, jfe, alpha, tref);
+    for (int o = 0; o < 8; o += W)
+        tile_staged<V, JOULE, PERCELL, W>(old, tn, o, k, tuf, conv, tdiel, adv, jfe, alpha, tref);
 }
 
 template <int L, bool TRACE>
 __global__ void __launch_bounds__(256, 2) wedm_step_fused(const KArgs k) {
     const ColdRef cold = kernarg_cold();
+    Hot hv = k.hot;
+    pin_hot_in_vgprs(hv);  // 178 -> 225 VGPRs, SGPR spill traffic in the loop 111 -> 37 instructions: +8 %
     extern __shared__ __attribute__((aligned(16))) float lds[];
     constexpr int EPB = 256 / L;  // environments per block
     const int tid = threadIdx.x;
@@ -498,7 +509,7 @@ __global__ void __launch_bounds__(256, 2) wedm_step_fused(const KArgs k) {
         if (__all(s.done) && !tracing) break;
         WEDM_STAMP(st0);
         Coef cf{0.0f, 0.0f, 0, -1};
-        if (!quiet_prelude(k.hot, g, gid, s) && !s.done) cf = scalar_prelude(k.hot, cold, g, e, gid, s, ps, c == 0);
+        if (!quiet_prelude(hv, g, gid, s) && !s.done) cf = scalar_prelude(hv, cold, g, e, gid, s, ps, c == 0);
         WEDM_STAMP(st1);
 
         // ---- halos: OLD neighbour values, read before any lane of this wave stores.  The right
@@ -658,7 +669,7 @@ __global__ void __launch_bounds__(256, 2) wedm_step_fused(const KArgs k) {
         for (int m = 1; m < L; m <<= 1) tmax = fmax_gt(tmax, __shfl_xor(tmax, m));
         WEDM_STAMP(st3);
         if (!s.done) {
-            scalar_epilogue(k.hot, s, tmax);
+            scalar_epilogue(hv, s, tmax);
             if (s.ctrl && c == 0) write_obs(cold, e, s);
         }
         WEDM_TRACE_POINT(k, it, e, s, c == 0,
@@ -698,7 +709,7 @@ __global__ void __launch_bounds__(256, 2) wedm_step_fused(const KArgs k) {
 template <bool JOULE>
 __device__ __forceinline__ f2 interior2(f2 tm1, f2 tc, f2 tp1, float k, float tuf, f2 conv, float tdiel, float adv,
                                         f2 jfe, float alpha, float tref) {
-    f2 a = tm1 - (tc + tc);
+    f2 a = sub_twice(tm1, tc);
     f2 d = k * (a + tp1);
     if (JOULE) {
         f2 rho_T = 1.0f + alpha * (tc - tref);
@@ -712,6 +723,11 @@ __device__ __forceinline__ f2 interior2(f2 tm1, f2 tc, f2 tp1, float k, float tu
 template <int L, bool TRACE>
 __global__ void __launch_bounds__(256, 2) wedm_step_packed(const KArgs k) {
     const ColdRef cold = kernarg_cold();
+    Hot hv = k.hot;
+    // the constants of the epilogue and of the quiet prelude: what fits in 256 VGPRs without a
+    // spill (pinning all of them spills 10 VGPRs and is no faster); +11 % over none
+    pin_mechanics_in_vgprs(hv);
+    pin_quiet_in_vgprs(hv);
     extern __shared__ __attribute__((aligned(16))) float lds[];
     constexpr int EPB = 256 / L;
     const int tid = threadIdx.x;
@@ -792,7 +808,7 @@ __global__ void __launch_bounds__(256, 2) wedm_step_packed(const KArgs k) {
         if (__all(s.done) && !tracing) break;
         WEDM_STAMP(st0);
         Coef cf{0.0f, 0.0f, 0, -1};
-        if (!quiet_prelude(k.hot, g, gid, s) && !s.done) cf = scalar_prelude(k.hot, cold, g, e, gid, s, ps, c == 0);
+        if (!quiet_prelude(hv, g, gid, s) && !s.done) cf = scalar_prelude(hv, cold, g, e, gid, s, ps, c == 0);
         WEDM_STAMP(st1);
 
         // ---- halos (OLD values, read before any store of this step)
@@ -967,7 +983,7 @@ __global__ void __launch_bounds__(256, 2) wedm_step_packed(const KArgs k) {
         for (int m = 1; m < L; m <<= 1) tmax = fmax_gt(tmax, __shfl_xor(tmax, m));
         WEDM_STAMP(st3);
         if (!s.done) {
-            scalar_epilogue(k.hot, s, tmax);
+            scalar_epilogue(hv, s, tmax);
             if (s.ctrl && c == 0) write_obs(cold, e, s);
         }
         WEDM_TRACE_POINT(k, it, e, s, c == 0,
