@@ -48,6 +48,10 @@ def parse_args():
     ap.add_argument("--lanes", type=int, default=0, help="lanes per environment in kernel 3 (0 auto)")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="target wall time of the cpu_baseline leg")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--trace", choices=["off", "voltage", "signals"], default="off",
+                    help="side measurement: cost of the in-kernel signal trace (every microsecond, all environments): "
+                         "'voltage' = the 1 ms ring the voltage controller needs, 'signals' = the 11 scalar signals "
+                         "of the reference's logger")
     ap.add_argument("--traffic", type=float, default=None,
                     help="measured HBM bytes per launch from a separate rocprofv3 --pmc pass (else null)")
     return ap.parse_args()
@@ -156,6 +160,11 @@ def main():
         mode = 5
         env = WireEDMEnv(num_envs=n_local, device=device, wire_params=wire, env_id_offset=rank * n_local)
     env.set_kernel(args.kernel, args.lanes)
+    if args.trace == "voltage":
+        env.bind_trace(["voltage"], every=1, capacity=1001)
+    elif args.trace == "signals":  # experiments/run_simulation.py:127-139 (scalar signals)
+        env.bind_trace(["time", "voltage", "current", "wire_position", "wire_velocity", "workpiece_position",
+                        "target_delta", "debris_concentration", "flow_rate", "is_short_circuit"], every=1, capacity=1000)
     env.reset(seed=1234)
     act = env.make_action(0.1, 80.0, mode, 3.0, 80.0)
     S = env.n_segments
@@ -212,6 +221,7 @@ def main():
                 "substeps_per_step": n_sub, "global_num_envs": world * n_local,
                 "parallelism": f"env-sharded x{world}, obs all-gather per control step" if world > 1 else "single GPU",
                 "kernel": env._backend.last_kernel(),
+                **({"trace": args.trace} if args.trace != "off" else {}),
             },
             "roofline": {
                 "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",

@@ -29,6 +29,7 @@
 #include <algorithm>
 #include <climits>
 #include <cstddef>
+#include <type_traits>
 #include <cstdint>
 #include <cstdio>
 #include <cstring>
@@ -557,18 +558,19 @@ __global__ void __launch_bounds__(256, 2) wedm_step_fused(const KArgs k) {
             const bool joule_wave = __any(jf_lane != 0.0f);
 
             // tile t covers cells j = 8t..8t+7; cur[u] = OLD T[j+1+u]; `nxt` is loaded one tile ahead
-            auto load8 = [&](float (&dst)[8], int j) {
+            // CLAMP = false: all eight rows exist (j + 8 <= C), one base address + immediate offsets
+            auto load8 = [&](auto clamp, float (&dst)[8], int j) {
 #pragma unroll
                 for (int u = 0; u < 8; ++u) {
                     int row = j + 1 + u;
-                    row = row < C ? row : C;  // rows past the chunk are never used; row C is the halo
+                    if (decltype(clamp)::value) row = row < C ? row : C;  // rows past the chunk are never used; row C is the halo
                     dst[u] = col[row * 256];
                 }
             };
             auto tile = [&](int t, float (&cur)[8], float (&nxt)[8]) {
                 const int j = 8 * t;
                 (void)nxt;
-                load8(cur, j);
+                load8(std::true_type{}, cur, j);  // (an unclamped variant for full tiles pays in the packed kernel only)
                 const float conv_lo = ((zone_lo >> t) & 1u) ? ps.conv_zone : ps.conv_base;
                 const float jfe_lo = ((joule_lo >> t) & 1u) ? jf_lane : 0.0f;
 #ifdef WEDM_STAMPS_TILES
@@ -850,11 +852,13 @@ __global__ void __launch_bounds__(256, 2) wedm_step_packed(const KArgs k) {
             const bool joule_wave = __any(jf_lane != 0.0f);
             const float cz = ps.conv_zone, cb = ps.conv_base;
 
-            auto load8 = [&](f2 (&dst)[8], int r0) {  // dst[u] = OLD (A[r0+1+u], B[r0+1+u])
+            // dst[u] = OLD (A[r0+1+u], B[r0+1+u]); CLAMP = false: all eight pairs exist (r0 + 8 <= Cv),
+            // one base address + immediate ds_read2st64 offsets
+            auto load8 = [&](auto clamp, f2 (&dst)[8], int r0) {
 #pragma unroll
                 for (int u = 0; u < 8; ++u) {
                     int p = r0 + 1 + u;
-                    p = p < Cv ? p : Cv;  // pair Cv is the halo pair; later pairs are never used
+                    if (decltype(clamp)::value) p = p < Cv ? p : Cv;  // pair Cv is the halo pair; later pairs are never used
                     dst[u].x = col[(2 * p) * 256];
                     dst[u].y = col[(2 * p + 1) * 256];
                 }
@@ -870,7 +874,8 @@ __global__ void __launch_bounds__(256, 2) wedm_step_packed(const KArgs k) {
                 // (236 B/lane, ~30 GB of L2 traffic per launch) and was 7 % slower; the other wave of
                 // the SIMD covers the LDS latency instead.
                 (void)nxt;
-                load8(cur, r0);
+                if (r0 + 8 <= Cv) load8(std::false_type{}, cur, r0);
+                else load8(std::true_type{}, cur, r0);
                 const f2 conv_lo = {((zlA >> t) & 1u) ? cz : cb, ((zlB >> t) & 1u) ? cz : cb};
                 const f2 jfe_lo = {((jlA >> t) & 1u) ? jf_lane : 0.0f, ((jlB >> t) & 1u) ? jf_lane : 0.0f};
                 if (((kind_n & ~slow_now) >> t) & 1u) {
