@@ -296,8 +296,9 @@ int64_t wedm_trace_samples(wedm_ctx* ctx);
 /* selects the kernel used by wedm_step: 0 = auto, 1 = global-memory stencil (one pass
  * over T in HBM per substep), 2 = LDS-staged predicated stencil (any geometry),
  * 3 = LDS-staged fused stencil walking a wave-uniform tile table (uniform geometry),
- * 4 = the same with two chunks per lane advanced by packed float32 math.
- * All variants produce bit-identical results.                                        */
+ * 4 = the same with two chunks per lane advanced by packed float32 math,
+ * 5 = global-memory stencil with the wire split over the four waves of a block (the
+ * automatic choice for n_substeps == 1).  All variants produce bit-identical results. */
 int32_t wedm_set_kernel(wedm_ctx* ctx, int32_t variant);
 
 /* lanes that share one environment in kernels 3 and 4: 0 = auto, or 1, 2, 4, 8 (16: kernel 3 only) */

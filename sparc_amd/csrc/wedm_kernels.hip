@@ -192,6 +192,149 @@ __global__ void __launch_bounds__(256) wedm_step_global(const KArgs k) {
 // np.max over finite temperatures; maps to v_max_f32 / v_max3_f32
 __device__ __forceinline__ float fmax_gt(float a, float b) { return __builtin_fmaxf(a, b); }
 
+// phase stamps of the split kernel (diagnostic build -DWEDM_STAMPS only): raw s_memtime at
+// [kernel entry, loop top, prelude done, barrier 1, walk done, barrier 2, loop exit, stored]
+#ifdef WEDM_STAMPS
+#define WEDM_SPLIT_STAMP_DECL unsigned long long sst[8] = {0, 0, 0, 0, 0, 0, 0, 0}; \
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(sst[7])::"memory")
+#define WEDM_SPLIT_STAMP(i) do { __builtin_amdgcn_sched_barrier(0); \
+    asm volatile("s_waitcnt vmcnt(0)\n\ts_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(sst[i])::"memory"); \
+    __builtin_amdgcn_sched_barrier(0); } while (0)
+#define WEDM_SPLIT_STAMP_OUT() do { if (k.dbg && (threadIdx.x & 63) == 0) { \
+    unsigned long long* o = k.dbg + ((size_t)blockIdx.x * 4 + (threadIdx.x >> 6)) * 8; \
+    for (int q = 0; q < 8; ++q) o[q] = sst[q]; } } while (0)
+#else
+#define WEDM_SPLIT_STAMP_DECL do { } while (0)
+#define WEDM_SPLIT_STAMP(i) do { } while (0)
+#define WEDM_SPLIT_STAMP_OUT() do { } while (0)
+#endif
+
+// ===================================================== split global-memory kernel (1 us / launch)
+// The reference's step() is ONE microsecond: every byte of T has to cross HBM once per launch.
+// With one lane per environment (wedm_step_global) a lane walks the whole wire through a chain
+// of dependent memory round trips (25 us even for a single block).  Here the wire is cut into
+// QL = 4 chunks walked by four WAVES of a block (chunk-major thread layout: a wave = one chunk of
+// 64 consecutive environments, every row access still a 256-B coalesced transaction).  Wave 0
+// runs the scalar physics once per environment and publishes the stencil coefficients through
+// LDS; the chunk maxima come back the same way.  T is updated in place: halos (OLD neighbour
+// values) are read before the barrier that precedes the first store.  Any geometry (predicated
+// cell).  Three barriers per microsecond.
+#define WEDM_QL 4
+template <bool TRACE>
+__global__ void __launch_bounds__(256) wedm_step_split(const KArgs k) {
+    const ColdRef cold = kernarg_cold();
+    __shared__ float sh_f[5][64];    // jf, q, conv_base, conv_zone, adv
+    __shared__ int32_t sh_i[4][64];  // joule_on, pidx, adv_on, skip (environment frozen)
+    __shared__ float sh_max[WEDM_QL][64];
+    const int tid = threadIdx.x;
+    const int c = tid >> 6, el = tid & 63;
+    const int64_t e = (int64_t)blockIdx.x * 64 + el;
+    const bool live = e < k.num_envs;
+    const int64_t stride = cold->s.stride;
+    const float spool = k.hot.spool, tref = k.hot.tref, alpha = k.hot.alpha, tdiel = k.hot.tdiel;
+    const uint32_t gid = k.hot.env_id_offset + (uint32_t)e;
+
+    Geom g;
+    load_geom(k.hot, cold, live ? e : 0, g);
+    const int n = g.n_seg;
+    const int C = (k.n_seg_max + WEDM_QL - 1) / WEDM_QL;
+    const int i0 = c * C, i1 = (i0 + C < n) ? i0 + C : n;  // this lane's cells [i0, i1) (may be empty)
+    GlobalT T{cold->s.T + (live ? e : 0), stride};
+
+    Env s;
+    Persist ps{0.0f, 0.0f, 0.0f, 0};
+    if (c == 0) {
+        if (live) load_env(cold, e, s);
+        else s.done = 1;
+        if (!s.done) {
+            s.ipk = peak_current(cold, s.mode);
+            init_persist(k.hot, cold, e, s, ps);
+        }
+    }
+    int trace_next = k.trace_next, trace_slot = k.trace_slot;
+    (void)trace_next; (void)trace_slot;
+    WEDM_SPLIT_STAMP_DECL;
+
+    for (int it = 0; it < k.n_substeps; ++it) {
+        WEDM_SPLIT_STAMP(0);
+        if (c == 0) {
+            Coef cf{0.0f, 0.0f, 0, -1};
+            if (!s.done) cf = scalar_prelude(k.hot, cold, g, e, gid, s, ps, true);
+            sh_f[0][el] = cf.jf; sh_f[1][el] = cf.q; sh_f[2][el] = ps.conv_base; sh_f[3][el] = ps.conv_zone;
+            sh_f[4][el] = ps.adv;
+            sh_i[0][el] = cf.joule_on; sh_i[1][el] = cf.pidx; sh_i[2][el] = ps.adv_on; sh_i[3][el] = s.done;
+        }
+        WEDM_SPLIT_STAMP(1);
+        // OLD neighbour values, read before the barrier that precedes every store of this step
+        float halo_l = spool, halo_r = 0.0f, first = 0.0f;
+        if (live && i0 < i1) {
+            if (i0 > 0) halo_l = T.ld(i0 - 1);
+            if (i1 < n) halo_r = T.ld(i1);
+            first = T.ld(i0);
+        }
+        __syncthreads();
+        WEDM_SPLIT_STAMP(2);
+        const Coef cf{sh_f[0][el], sh_f[1][el], sh_i[0][el], sh_i[1][el]};
+        const Persist pw{sh_f[4][el], sh_f[2][el], sh_f[3][el], sh_i[2][el]};
+        const bool skip = sh_i[3][el] != 0;
+        float tmax = spool;
+        if (live && !skip && i0 < i1) {
+            float tm1 = halo_l, tc = first;
+            for (int ib = i0; ib < i1; ib += 8) {
+                float nx[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    const int idx = ib + 1 + u;
+                    nx[u] = idx < i1 ? T.ld(idx) : halo_r;
+                }
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    const int i = ib + u;
+                    if (i < i1) {
+                        const float tn = (i >= 1) ? stencil_cell(i, n, (i == 1) ? spool : tm1, tc, nx[u], g, cf, pw, tref, alpha, tdiel)
+                                                  : spool;
+                        T.st(i, tn);
+                        tmax = tn > tmax ? tn : tmax;
+                        tm1 = tc;
+                        tc = nx[u];
+                    }
+                }
+            }
+        }
+        WEDM_SPLIT_STAMP(3);
+        sh_max[c][el] = tmax;
+        __syncthreads();
+        WEDM_SPLIT_STAMP(4);
+        if (c == 0 && !s.done) {
+            float m = sh_max[0][el];
+#pragma unroll
+            for (int q = 1; q < WEDM_QL; ++q) m = fmax_gt(m, sh_max[q][el]);
+            scalar_epilogue(k.hot, s, m);
+            if (s.ctrl) write_obs(cold, e, s);
+        }
+        if (TRACE && it == trace_next) {  // wave-uniform schedule; T rows of the step just finished
+            const wedm_trace_desc* tr = opaque(cold->tr);
+            const int64_t tcol = live ? trace_column(tr, e) : -1;
+            if (tcol >= 0) {
+                if (c == 0) trace_scalars(tr, tcol, s, trace_slot);
+                if (tr->T) {
+                    const int64_t tcnt = tr->env_count;
+                    float* tT = tr->T + (int64_t)trace_slot * k.n_seg_max * tcnt + tcol;
+                    for (int i = i0; i < i1; ++i) tT[(int64_t)i * tcnt] = T.ld(i);
+                }
+            }
+            trace_next += tr->every;
+            trace_slot = (trace_slot + 1 == tr->capacity) ? 0 : trace_slot + 1;
+        }
+        if (it + 1 < k.n_substeps) __syncthreads();  // the next step's halo reads follow this step's stores
+    }
+    WEDM_SPLIT_STAMP(5);
+    if (c == 0 && live) store_env(cold, e, s);
+    WEDM_SPLIT_STAMP(6);
+    WEDM_SPLIT_STAMP_OUT();
+}
+
+
 // Any geometry (uniform or one row per environment), L lanes per environment, every cell on the
 // predicated formula with the lane's own n_seg / zone / contact indices.  LDS layout and halo
 // exchange as in the fused kernels; the chunk length is uniform, C = ceil(n_seg_max / L), so an
@@ -1361,7 +1504,7 @@ int64_t wedm_trace_samples(wedm_ctx* ctx) { return ctx ? ctx->trace_count : 0; }
 
 int32_t wedm_set_kernel(wedm_ctx* ctx, int32_t variant) {
     if (!ctx) return WEDM_ERR_BAD_ARG;
-    if (variant < 0 || variant > 4) return fail(ctx, WEDM_ERR_BAD_ARG, "wedm_set_kernel: variant must be 0..4");
+    if (variant < 0 || variant > 5) return fail(ctx, WEDM_ERR_BAD_ARG, "wedm_set_kernel: variant must be 0..5");
     ctx->variant = variant;
     return WEDM_OK;
 }
@@ -1505,8 +1648,8 @@ int32_t wedm_step(wedm_ctx* ctx, int32_t n_substeps, const wedm_action_ptrs* act
     const bool lanes_ok = glanes > 0;
     int variant = ctx->variant;
     if (variant == 0) {
-        // single-microsecond launches: the global-memory kernel (measured 37 us vs 50+ us staged)
-        if (n_substeps <= 1) variant = 1;
+        // single-microsecond launches: the split global-memory kernel
+        if (n_substeps <= 1) variant = 5;
         else if (packed_ok && (ctx->auto_prefers_packed || !fused_ok)) variant = 4;
         else if (fused_ok) variant = 3;
         else variant = lanes_ok ? 2 : 1;
@@ -1527,6 +1670,10 @@ int32_t wedm_step(wedm_ctx* ctx, int32_t n_substeps, const wedm_action_ptrs* act
         grid = (ctx->num_envs + 255) / 256;
         fn = tr ? (const void*)wedm_step_global<true> : (const void*)wedm_step_global<false>;
         std::snprintf(name, sizeof(name), "wedm_step_global<<<%d,256>>> n_sub=%d", grid, n_substeps);
+    } else if (variant == 5) {
+        grid = (ctx->num_envs + 63) / 64;
+        fn = tr ? (const void*)wedm_step_split<true> : (const void*)wedm_step_split<false>;
+        std::snprintf(name, sizeof(name), "wedm_step_split<<<%d,256>>> n_sub=%d", grid, n_substeps);
     } else if (variant == 2) {
         grid = (ctx->num_envs + 256 / glanes - 1) / (256 / glanes);
         fl = (size_t)((ctx->n_seg_max + glanes - 1) / glanes) * 1024;

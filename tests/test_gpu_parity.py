@@ -48,7 +48,7 @@ def test_native_library_is_the_one_running():
     assert env._backend.name == "hip"
     env.reset(seed=1)
     env.step(env.make_action())
-    assert "wedm_step_global" in env._backend.last_kernel()
+    assert "wedm_step_split" in env._backend.last_kernel()
     env.step_many(env.make_action(), 10)
     assert "wedm_step_packed" in env._backend.last_kernel() or "wedm_step_fused" in env._backend.last_kernel()
     env.set_kernel(2)
@@ -111,7 +111,7 @@ def test_device_math_primitives_match_cpu_bit_for_bit(orc, kind):
         f"kind {kind}: {np.count_nonzero(got.view(np.uint64) != want.view(np.uint64))} of {len(want)} differ"
 
 
-KERNELS = [(1, 0), (2, 0), (3, 1), (3, 2), (3, 4), (3, 8), (3, 16), (4, 1), (4, 2), (4, 4), (4, 8)]
+KERNELS = [(1, 0), (5, 0), (2, 0), (3, 1), (3, 2), (3, 4), (3, 8), (3, 16), (4, 1), (4, 2), (4, 4), (4, 8)]
 
 
 @pytest.mark.parametrize("variant,lanes", KERNELS)
@@ -207,7 +207,7 @@ def test_per_environment_geometry_config5():
     gpu, cpu = make_pair(n, **kw)
     assert gpu.n_segments == cpu.n_segments and 350 <= gpu.n_segments <= 450
     both((gpu, cpu), lambda e: (e.reset(seed=2024), close_gap(e, 24.0, 10.0)))
-    for variant, lanes in ((1, 0), (2, 4), (2, 8), (2, 16), (2, 0)):
+    for variant, lanes in ((1, 0), (5, 0), (2, 4), (2, 8), (2, 16), (2, 0)):
         gpu.set_kernel(variant, lanes)
         for env in (gpu, cpu):
             a = env.make_action(0.1, 80.0, mode, 3.0, 40.0)
@@ -565,7 +565,7 @@ def test_device_trace_per_environment_geometry():
     gpu, cpu = make_pair(n, **kw)
     both((gpu, cpu), lambda e: (e.reset(seed=4), close_gap(e, 24.0, 10.0)))
     n_seg = gpu._geom_i32[0, :n].cpu()   # WEDM_GI_N_SEG
-    for variant in (2, 1):
+    for variant in (2, 1, 5):
         gpu.set_kernel(variant, 0)
         traces = [e.bind_trace(["voltage", "time", "spark_state"], every=10, capacity=64, envs=(5, 80),
                                wire_temperature=True) for e in (gpu, cpu)]
@@ -584,7 +584,7 @@ def test_single_microsecond_launches_feed_the_trace():
         a = env.make_action()
         for _ in range(41):
             env.step(a)
-    assert "wedm_step_global" in gpu._backend.last_kernel() and traces[0].count == 20
+    assert "wedm_step_split" in gpu._backend.last_kernel() and traces[0].count == 20
     assert_rings_equal(*traces)
     check(gpu, cpu, n)
 
@@ -667,7 +667,7 @@ def test_crater_statistics_on_gpu_match_reference_fixture(golden_dir):
 
     fx = Fixture(golden_dir / "f10_crater_statistics_philox_env1.npz")
     total, mean, std, vmin, vmax = fx.data["crater_stats"].tolist()
-    for variant, lanes in ((0, 0), (3, 16), (1, 0)):
+    for variant, lanes in ((0, 0), (3, 16), (1, 0), (5, 0)):
         env = WireEDMEnv(num_envs=64, device="cuda:0")
         env.set_kernel(variant, lanes)
         env.reset(seed=81)
