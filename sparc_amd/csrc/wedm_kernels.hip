@@ -220,6 +220,9 @@ __device__ __forceinline__ float fmax_gt(float a, float b) { return __builtin_fm
 // values) are read before the barrier that precedes the first store.  Any geometry (predicated
 // cell).  Three barriers per microsecond.
 #define WEDM_QL 4
+#ifndef WEDM_SPLIT_RB
+#define WEDM_SPLIT_RB 16
+#endif
 template <bool TRACE>
 __global__ void __launch_bounds__(256) wedm_step_split(const KArgs k) {
     const ColdRef cold = kernarg_cold();
@@ -266,11 +269,10 @@ __global__ void __launch_bounds__(256) wedm_step_split(const KArgs k) {
         }
         WEDM_SPLIT_STAMP(1);
         // OLD neighbour values, read before the barrier that precedes every store of this step
-        float halo_l = spool, halo_r = 0.0f, first = 0.0f;
+        float halo_l = spool, halo_r = 0.0f;
         if (live && i0 < i1) {
             if (i0 > 0) halo_l = T.ld(i0 - 1);
             if (i1 < n) halo_r = T.ld(i1);
-            first = T.ld(i0);
         }
         __syncthreads();
         WEDM_SPLIT_STAMP(2);
@@ -279,24 +281,29 @@ __global__ void __launch_bounds__(256) wedm_step_split(const KArgs k) {
         const bool skip = sh_i[3][el] != 0;
         float tmax = spool;
         if (live && !skip && i0 < i1) {
-            float tm1 = halo_l, tc = first;
-            for (int ib = i0; ib < i1; ib += 8) {
-                float nx[8];
+            // RB rows per batch of loads, unconditional from a clamped index (no branch between them,
+            // all in flight together).  Stamps show the walk phase itself moving ~7.7 TB/s chip-wide:
+            // what is left is the lock-step of the blocks (all in the scalar phase, then all walking).
+            constexpr int RB = WEDM_SPLIT_RB;
+            float tm1 = halo_l;
+            for (int ib = i0; ib < i1; ib += RB) {
+                float buf[RB + 1];
 #pragma unroll
-                for (int u = 0; u < 8; ++u) {
-                    const int idx = ib + 1 + u;
-                    nx[u] = idx < i1 ? T.ld(idx) : halo_r;
+                for (int u = 0; u <= RB; ++u) {
+                    int idx = ib + u;
+                    idx = idx < i1 ? idx : i1 - 1;  // past the chunk: any valid row, the value is not used
+                    buf[u] = T.ld(idx);
                 }
 #pragma unroll
-                for (int u = 0; u < 8; ++u) {
+                for (int u = 0; u < RB; ++u) {
                     const int i = ib + u;
                     if (i < i1) {
-                        const float tn = (i >= 1) ? stencil_cell(i, n, (i == 1) ? spool : tm1, tc, nx[u], g, cf, pw, tref, alpha, tdiel)
+                        const float tp1 = (i + 1 < i1) ? buf[u + 1] : halo_r;
+                        const float tn = (i >= 1) ? stencil_cell(i, n, (i == 1) ? spool : tm1, buf[u], tp1, g, cf, pw, tref, alpha, tdiel)
                                                   : spool;
                         T.st(i, tn);
                         tmax = tn > tmax ? tn : tmax;
-                        tm1 = tc;
-                        tc = nx[u];
+                        tm1 = buf[u];
                     }
                 }
             }

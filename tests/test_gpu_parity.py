@@ -371,7 +371,7 @@ def test_reference_fixtures_with_injected_philox_on_gpu(golden_dir):
 
 def test_full_size_fusion_and_sharding_invariance():
     """BASELINE batch (65 536 envs, 128 segments): properties that hold at any size.
-      * fusion: step_many(1000) == 1000 x step() bit for bit (LDS kernel vs global kernel);
+      * fusion: step_many(1000) == 1000 x step() bit for bit (LDS kernel vs split global-memory kernel);
       * sharding: the upper half computed alone with env_id_offset reproduces itself."""
     n = 65536
     kw = dict(wire_params=WireModuleParameters(segment_len=0.625))
@@ -387,7 +387,7 @@ def test_full_size_fusion_and_sharding_invariance():
     assert "wedm_step_packed" in a_env._backend.last_kernel()
     for _ in range(1300):
         b_env.step(act)
-    assert "wedm_step_global" in b_env._backend.last_kernel()
+    assert "wedm_step_split" in b_env._backend.last_kernel()
     half.step_many(half.make_action(0.1, 80.0, 5, 3.0, 80.0), 1300)
     torch.cuda.synchronize()
     A, B, H = a_env.state.clone_blocks(), b_env.state.clone_blocks(), half.state.clone_blocks()
