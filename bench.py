@@ -181,18 +181,29 @@ def main():
         one_step()
 
     # ---- timed region: exactly K steps between barrier + synchronize
-    starts = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps)]
-    ends = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps)]
+    # HIP events on torch's current stream == the stream wedm_step launches on.  One pair per step;
+    # with many short steps (single-microsecond launches) one pair around the whole region, because
+    # two event records per 30-us launch would themselves slow the stream down.
+    per_step_events = args.steps <= 200
+    n_ev = args.steps if per_step_events else 1
+    starts = [torch.cuda.Event(enable_timing=True) for _ in range(n_ev)]
+    ends = [torch.cuda.Event(enable_timing=True) for _ in range(n_ev)]
     if use_dist:
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
+    if not per_step_events:
+        starts[0].record()
     for i in range(args.steps):
-        starts[i].record()          # torch's current stream == the stream wedm_step launches on
+        if per_step_events:
+            starts[i].record()
         env.step_many(act, n_sub)
-        ends[i].record()
+        if per_step_events:
+            ends[i].record()
         if use_dist:
             dist.all_gather_into_tensor(gathered, obs_local.contiguous())
+    if not per_step_events:
+        ends[0].record()
     torch.cuda.synchronize()
     if use_dist:
         dist.barrier()

@@ -97,6 +97,7 @@ class HipBackend:
         self._L = load()
         self._torch = torch
         self.device = device
+        self._raw_stream = getattr(torch._C, "_cuda_getCurrentRawStream", None)
         self._ctx = C.c_void_p()
         with torch.cuda.device(device):
             rc = self._L.wedm_create(C.byref(params), num_envs, n_seg_max, C.byref(self._ctx))
@@ -108,6 +109,11 @@ class HipBackend:
             raise WedmError(rc, (self._L.wedm_last_error(self._ctx) or b"").decode())
 
     def _stream(self):
+        # raw handle of torch's current stream on this device (the public accessor builds a
+        # Stream object per call: several microseconds on the per-microsecond stepping path)
+        raw = self._raw_stream
+        if raw is not None:
+            return C.c_void_p(raw(self.device.index))
         return C.c_void_p(self._torch.cuda.current_stream(self.device).cuda_stream)
 
     def bind_state(self, ptrs: _abi.StatePtrs) -> None:

@@ -66,11 +66,18 @@ class BatchedEDMState:
         # read-only attributes computed on access (registered by the environment):
         # dielectric_flow_rate (dielectric.py:160-162), wire_average_temperature (wire.py:339-347)
         object.__setattr__(self, "derived", {})
+        object.__setattr__(self, "_views", {})
 
     # ------------------------------------------------------------------ views
     def _view(self, name: str) -> torch.Tensor:
-        block, row = _FIELDS[name]
-        return getattr(self, block)[int(row), : self.num_envs]
+        # the blocks are never reallocated, so a field's view is built once (a per-microsecond
+        # caller would otherwise pay ~2 us of tensor indexing per field and step)
+        cache = self.__dict__["_views"]
+        v = cache.get(name)
+        if v is None:
+            block, row = _FIELDS[name]
+            v = cache[name] = getattr(self, block)[int(row), : self.num_envs]
+        return v
 
     def __getattr__(self, name: str):
         if name in _FIELDS:

@@ -200,6 +200,7 @@ class WireEDMEnv:
         self._reward = torch.zeros(self.num_envs, dtype=torch.float32, device=self.device)
         self._truncated = torch.zeros(self.num_envs, dtype=torch.bool, device=self.device)
         self._mask_buf = None
+        self._step_out = None
         self._trace = None
         self._seed = int.from_bytes(os.urandom(8), "little")
         self._backend.reset(None, self._seed, True)
@@ -232,15 +233,19 @@ class WireEDMEnv:
         act = self._prepare_action(action)
         self._last_action = act  # keep the tensors alive while the launch is in flight
         self._backend.step(int(n_substeps), act.ptrs)
-        st = self.state
-        info = {
-            "wire_broken": st.is_wire_broken,
-            "target_reached": st.is_target_distance_reached,
-            "spark_state": st.spark_state,
-            "time": st.time,
-            "control_step": st.control_step,
-        }
-        return self._get_obs(), self._reward, st.done, self._truncated, info
+        # obs / done / info are views of caller-owned memory the kernel has just (asynchronously)
+        # updated: built once, handed out every step (`info` is a fresh dict of the same tensors)
+        out = self._step_out
+        if out is None:
+            st = self.state
+            out = self._step_out = (self._get_obs(), st.done, {
+                "wire_broken": st.is_wire_broken,
+                "target_reached": st.is_target_distance_reached,
+                "spark_state": st.spark_state,
+                "time": st.time,
+                "control_step": st.control_step,
+            })
+        return out[0], self._reward, out[1], self._truncated, dict(out[2])
 
     def step_control(self, action):
         """One control interval (``servo_interval`` physics steps, default 1000)."""
