@@ -1516,13 +1516,15 @@ int32_t wedm_set_kernel(wedm_ctx* ctx, int32_t variant) {
     return WEDM_OK;
 }
 
-// diagnostic builds (-DWEDM_STAMPS): device buffer of 4 uint64 per wave receiving the cycles
-// spent in {prelude, walk, patches+reduce, epilogue}; ignored by the shipped library
+#ifdef WEDM_STAMPS
+// diagnostic builds only (-DWEDM_STAMPS, tools/stamps*.py): device buffer receiving the phase
+// cycle stamps of every wave.  Not part of the shipped library, not declared in the header.
 int32_t wedm_debug_set_stamp_buffer(wedm_ctx* ctx, void* buf) {
     if (!ctx) return WEDM_ERR_BAD_ARG;
     ctx->dbg = (unsigned long long*)buf;
     return WEDM_OK;
 }
+#endif
 
 int32_t wedm_set_lanes(wedm_ctx* ctx, int32_t lanes) {
     if (!ctx) return WEDM_ERR_BAD_ARG;

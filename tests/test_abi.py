@@ -57,3 +57,36 @@ def test_enum_mirror_matches_header():
                   "wedm_geom_f64_field": "WEDM_G_", "wedm_geom_i32_field": "WEDM_GI_"}[enum_name]
         for idx, n in enumerate(names[:-1]):
             assert py_enum[n[len(prefix):]].value == idx, (enum_name, n)
+
+
+def test_header_is_plain_c_and_struct_layouts_match_the_ctypes_mirrors(tmp_path):
+    """include/wedm_hip.h compiles as strict C99 (what a cgo / JNI / ctypes binder consumes) and
+    every structure crossing the boundary has the size and field offsets of its Python mirror."""
+    import subprocess
+
+    mirrors = {"wedm_params": _abi.Params, "wedm_state_ptrs": _abi.StatePtrs, "wedm_geom_ptrs": _abi.GeomPtrs,
+               "wedm_action_ptrs": _abi.ActionPtrs, "wedm_trace_desc": _abi.TraceDesc}
+    lines = ['#include <stdio.h>', '#include <stddef.h>', '#include "wedm_hip.h"', "int main(void) {"]
+    for cname, mirror in mirrors.items():
+        lines.append(f'  printf("{cname} size %zu\\n", sizeof({cname}));')
+        for field, _ in mirror._fields_:
+            lines.append(f'  printf("{cname} {field} %zu\\n", offsetof({cname}, {field}));')
+    lines += ['  printf("abi %d stat_count %d\\n", WEDM_ABI_VERSION, (int)WEDM_STAT_COUNT);', "  return 0;", "}"]
+    src = tmp_path / "layout.c"
+    src.write_text("\n".join(lines))
+    exe = tmp_path / "layout"
+    subprocess.run(["gcc", "-std=c99", "-pedantic", "-Wall", "-Werror", f"-I{ROOT / 'include'}", str(src), "-o", str(exe)],
+                   check=True)
+    out = subprocess.run([str(exe)], check=True, capture_output=True, text=True).stdout.split("\n")
+    seen = 0
+    for row in out:
+        parts = row.split()
+        if len(parts) == 3 and parts[0] in mirrors:
+            mirror = mirrors[parts[0]]
+            if parts[1] == "size":
+                assert C.sizeof(mirror) == int(parts[2]), row
+            else:
+                assert getattr(mirror, parts[1]).offset == int(parts[2]), row
+            seen += 1
+    assert seen > 100
+    assert f"abi {_abi.ABI_VERSION} stat_count {_abi.STAT_COUNT}" in out
