@@ -337,6 +337,25 @@ class WireEDMEnv:
         self._backend.bind_trace(None)
         self._trace = None
 
+    # ---- checkpoint / resume (the reference has none for simulation state) ---------
+    def state_dict(self) -> Dict[str, Any]:
+        """Everything a bit-identical continuation needs: the raw state blocks (Philox key, episode
+        and clocks live in them, so the random streams resume exactly) and the reset seed."""
+        return {"blocks": self.state.clone_blocks(), "seed": self._seed, "num_envs": self.num_envs,
+                "n_segments": self.n_segments, "env_id_offset": self.env_id_offset}
+
+    def load_state_dict(self, sd: Dict[str, Any]) -> None:
+        if (sd["num_envs"], sd["n_segments"], sd["env_id_offset"]) != (self.num_envs, self.n_segments, self.env_id_offset):
+            raise ValueError("checkpoint was taken from an environment of a different shape / shard")
+        self.state.load_blocks(sd["blocks"])
+        self._seed = int(sd["seed"])
+
+    def save_checkpoint(self, path) -> None:
+        torch.save(self.state_dict(), path)
+
+    def load_checkpoint(self, path) -> None:
+        self.load_state_dict(torch.load(path, map_location="cpu", weights_only=False))
+
     def zone_mean_temperature(self) -> torch.Tensor:
         """Mean wire temperature over the workpiece zone (wire.py:390-398), per environment."""
         if self.geometry is None:

@@ -680,3 +680,19 @@ def test_crater_statistics_on_gpu_match_reference_fixture(golden_dir):
         assert got["min_volume_um3"] == vmin and got["max_volume_um3"] == vmax
         assert abs(got["mean_volume_um3"] - mean) <= 1e-12 * mean and abs(got["std_volume_um3"] - std) <= 1e-12 * std
         assert float(env.state.workpiece_position[1]) == float(fx.float_row("workpiece_position")[-1])
+
+
+def test_checkpoint_resume_on_gpu(tmp_path):
+    n = 512
+    a = WireEDMEnv(num_envs=n, device="cuda:0")
+    a.reset(seed=12)
+    close_gap(a)
+    act = a.make_action(0.1, 80.0, 9, 3.0, 40.0)
+    a.step_many(act, 1300)
+    a.save_checkpoint(tmp_path / "ck.pt")
+    a.step_many(act, 1200)
+    b = WireEDMEnv(num_envs=n, device="cuda:0")
+    b.load_checkpoint(tmp_path / "ck.pt")
+    b.step_many(b.make_action(0.1, 80.0, 9, 3.0, 40.0), 1200)
+    torch.cuda.synchronize()
+    assert_blocks_equal(a.state.clone_blocks(), b.state.clone_blocks(), n)

@@ -134,3 +134,23 @@ def test_module_statistics_helpers():
     assert set(deb) == {"debris_volume_mm3", "debris_density", "cavity_volume_mm3", "flow_condition", "debris_fill_percentage"}
     assert (env.get_crater_count() == 0).all()
     assert env.zone_mean_temperature().shape == (4,)
+
+
+def test_checkpoint_resume_is_bit_identical(tmp_path):
+    a = driver_env(6, 21, backend=OracleBackend)
+    a.state.workpiece_position = 24.0
+    act = a.make_action(0.1, 80.0, 9, 3.0, 40.0)
+    a.step_many(act, 1700)
+    a.save_checkpoint(tmp_path / "ck.pt")
+    a.step_many(act, 1500)
+    b = WireEDMEnv(num_envs=6, device="cpu", backend=OracleBackend)
+    b.reset(seed=999)                         # different key: everything must come from the checkpoint
+    b.load_checkpoint(tmp_path / "ck.pt")
+    b.step_many(b.make_action(0.1, 80.0, 9, 3.0, 40.0), 1500)
+    A, B = a.state.clone_blocks(), b.state.clone_blocks()
+    for k in A:
+        same = (A[k] == B[k]) | ((A[k] != A[k]) & (B[k] != B[k])) if A[k].is_floating_point() else (A[k] == B[k])
+        assert bool(same.all()), k
+    assert int(a.state.spark_count.sum()) > 20
+    with pytest.raises(ValueError):
+        WireEDMEnv(num_envs=5, device="cpu", backend=OracleBackend).load_checkpoint(tmp_path / "ck.pt")
