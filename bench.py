@@ -52,6 +52,7 @@ def parse_args():
                     help="side measurement: cost of the in-kernel signal trace (every microsecond, all environments): "
                          "'voltage' = the 1 ms ring the voltage controller needs, 'signals' = the 11 scalar signals "
                          "of the reference's logger")
+    ap.add_argument("--trace-every", type=int, default=1, help="sample period of --trace in microseconds")
     ap.add_argument("--traffic", type=float, default=None,
                     help="measured HBM bytes per launch from a separate rocprofv3 --pmc pass (else null)")
     return ap.parse_args()
@@ -161,10 +162,10 @@ def main():
         env = WireEDMEnv(num_envs=n_local, device=device, wire_params=wire, env_id_offset=rank * n_local)
     env.set_kernel(args.kernel, args.lanes)
     if args.trace == "voltage":
-        env.bind_trace(["voltage"], every=1, capacity=1001)
+        env.bind_trace(["voltage"], every=args.trace_every, capacity=1001)
     elif args.trace == "signals":  # experiments/run_simulation.py:127-139 (scalar signals)
         env.bind_trace(["time", "voltage", "current", "wire_position", "wire_velocity", "workpiece_position",
-                        "target_delta", "debris_concentration", "flow_rate", "is_short_circuit"], every=1, capacity=1000)
+                        "target_delta", "debris_concentration", "flow_rate", "is_short_circuit"], every=args.trace_every, capacity=1000)
     env.reset(seed=1234)
     act = env.make_action(0.1, 80.0, mode, 3.0, 80.0)
     S = env.n_segments

@@ -253,7 +253,6 @@ struct Cold {  // everything reachable only through rare branches
     wedm_action_ptrs a;
     wedm_state_ptrs s;
     Tables tb;
-    const wedm_trace_desc* tr;  // device copy of the bound trace descriptor (NULL: none)
 };
 
 // The kernels never touch their by-value `Cold` argument directly: they read it THROUGH the
@@ -417,32 +416,28 @@ __device__ __forceinline__ int32_t env_i8_row(const Env& v, int row) {
 }
 
 // Column of environment e in the trace buffers, or -1 when it is not traced.
-__device__ __forceinline__ int64_t trace_column(const wedm_trace_desc* tr, int64_t e) {
-    const int64_t col = e - tr->env_lo;
-    return (col >= 0 && col < tr->env_count) ? col : -1;
+__device__ __forceinline__ int64_t trace_column(const wedm_trace_desc& tr, int64_t e) {
+    const int64_t col = e - tr.env_lo;
+    return (col >= 0 && col < tr.env_count) ? col : -1;
 }
 
 // The selected scalar rows of one environment into ring slot `slot` (one lane per environment).
-__device__ __forceinline__ void trace_scalars(const wedm_trace_desc* tr, int64_t col, const Env& v, int slot) {
-    const int64_t cnt = tr->env_count;
-    const uint32_t mf = tr->f64_mask, mi = tr->i32_mask, mb = tr->i8_mask;
+__device__ __forceinline__ void trace_scalars(const wedm_trace_desc& tr, int64_t col, const Env& v, int slot) {
+    const int64_t cnt = tr.env_count;
+    const uint32_t mf = tr.f64_mask, mi = tr.i32_mask, mb = tr.i8_mask;
+    // loop over the SET bits (wave-uniform): the cost follows the number of traced rows, not the 45
+    // rows that exist (one scalar branch per row tested cost ~13 % with a single traced row)
     if (mf) {
-        double* dst = tr->f64 + (int64_t)slot * __builtin_popcount(mf) * cnt + col;
-#pragma unroll
-        for (int r = 0; r < WEDM_F64_COUNT; ++r)
-            if ((mf >> r) & 1u) { *dst = env_f64_row(v, r); dst += cnt; }
+        double* dst = tr.f64 + (int64_t)slot * __builtin_popcount(mf) * cnt + col;
+        for (uint32_t m = mf; m; m &= m - 1u) { *dst = env_f64_row(v, __builtin_ctz(m)); dst += cnt; }
     }
     if (mi) {
-        int32_t* dst = tr->i32 + (int64_t)slot * __builtin_popcount(mi) * cnt + col;
-#pragma unroll
-        for (int r = 0; r < WEDM_I32_COUNT; ++r)
-            if ((mi >> r) & 1u) { *dst = env_i32_row(v, r); dst += cnt; }
+        int32_t* dst = tr.i32 + (int64_t)slot * __builtin_popcount(mi) * cnt + col;
+        for (uint32_t m = mi; m; m &= m - 1u) { *dst = env_i32_row(v, __builtin_ctz(m)); dst += cnt; }
     }
     if (mb) {
-        int8_t* dst = tr->i8 + (int64_t)slot * __builtin_popcount(mb) * cnt + col;
-#pragma unroll
-        for (int r = 0; r < WEDM_I8_COUNT; ++r)
-            if ((mb >> r) & 1u) { *dst = (int8_t)env_i8_row(v, r); dst += cnt; }
+        int8_t* dst = tr.i8 + (int64_t)slot * __builtin_popcount(mb) * cnt + col;
+        for (uint32_t m = mb; m; m &= m - 1u) { *dst = (int8_t)env_i8_row(v, __builtin_ctz(m)); dst += cnt; }
     }
 }
 

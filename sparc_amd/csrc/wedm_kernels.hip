@@ -74,6 +74,7 @@ struct KArgs {
     const WalkTable* walk;  // device copy of the table for the L in use (fused kernel only)
     int32_t trace_next;     // substep index after which the next trace sample is due (INT32_MAX: no trace)
     int32_t trace_slot;     // ring slot of that sample
+    wedm_trace_desc trace;  // the bound trace (by value: one kernarg s_load, only in the TRACE instantiations)
     unsigned long long* dbg; // diagnostic builds only (WEDM_STAMPS): per-wave phase cycle sums
 };
 
@@ -84,7 +85,7 @@ __device__ __forceinline__ ColdRef kernarg_cold() {
 
 // ------------------------------------------------------------ signal trace
 // The sample schedule is host-made and identical for every wave: `it == trace_next` is a scalar
-// compare per microsecond; the descriptor is only touched inside the (rare) branch.  While a
+// compare per microsecond; the descriptor travels by value in the kernel arguments.  While a
 // trace is due in this launch the kernels keep iterating over terminated environments so that
 // every slot receives a sample (their frozen state).
 // Kernels are instantiated with and without the trace point (template parameter TRACE): the
@@ -95,18 +96,18 @@ __device__ __forceinline__ ColdRef kernarg_cold() {
 // CELLS: statement that copies this lane's wire cells, given `tT` (slot base + column) and `tcnt`
 #define WEDM_TRACE_POINT(k, it, e, s, SCALAR_LANE, CELLS)                                        \
     if (TRACE && (it) == trace_next) {                                                           \
-        const wedm_trace_desc* tr = opaque(cold->tr);                                         \
+        const wedm_trace_desc& tr = (k).trace;                                                   \
         const int64_t tcol = trace_column(tr, (e));                                              \
         if (tcol >= 0) {                                                                         \
             if (SCALAR_LANE) trace_scalars(tr, tcol, (s), trace_slot);                           \
-            if (tr->T) {                                                                         \
-                const int64_t tcnt = tr->env_count;                                              \
-                float* tT = tr->T + (int64_t)trace_slot * (k).n_seg_max * tcnt + tcol;           \
+            if (tr.T) {                                                                          \
+                const int64_t tcnt = tr.env_count;                                               \
+                float* tT = tr.T + (int64_t)trace_slot * (k).n_seg_max * tcnt + tcol;            \
                 CELLS;                                                                           \
             }                                                                                    \
         }                                                                                        \
-        trace_next += tr->every;                                                                 \
-        trace_slot = (trace_slot + 1 == tr->capacity) ? 0 : trace_slot + 1;                      \
+        trace_next += tr.every;                                                                  \
+        trace_slot = (trace_slot + 1 == tr.capacity) ? 0 : trace_slot + 1;                       \
     }
 
 // ------------------------------------------------------------ T accessors
@@ -320,18 +321,18 @@ __global__ void __launch_bounds__(256) wedm_step_split(const KArgs k) {
             if (s.ctrl) write_obs(cold, e, s);
         }
         if (TRACE && it == trace_next) {  // wave-uniform schedule; T rows of the step just finished
-            const wedm_trace_desc* tr = opaque(cold->tr);
+            const wedm_trace_desc& tr = k.trace;
             const int64_t tcol = live ? trace_column(tr, e) : -1;
             if (tcol >= 0) {
                 if (c == 0) trace_scalars(tr, tcol, s, trace_slot);
-                if (tr->T) {
-                    const int64_t tcnt = tr->env_count;
-                    float* tT = tr->T + (int64_t)trace_slot * k.n_seg_max * tcnt + tcol;
+                if (tr.T) {
+                    const int64_t tcnt = tr.env_count;
+                    float* tT = tr.T + (int64_t)trace_slot * k.n_seg_max * tcnt + tcol;
                     for (int i = i0; i < i1; ++i) tT[(int64_t)i * tcnt] = T.ld(i);
                 }
             }
-            trace_next += tr->every;
-            trace_slot = (trace_slot + 1 == tr->capacity) ? 0 : trace_slot + 1;
+            trace_next += tr.every;
+            trace_slot = (trace_slot + 1 == tr.capacity) ? 0 : trace_slot + 1;
         }
         if (it + 1 < k.n_substeps) __syncthreads();  // the next step's halo reads follow this step's stores
     }
@@ -1250,11 +1251,9 @@ struct wedm_ctx {
     WalkTable* walk_dev = nullptr;     // [5] tables for L = 1, 2, 4, 8, 16
     bool walk_ok[5] = {false, false, false, false, false};
     int32_t walk_C[5] = {0, 0, 0, 0, 0};
-    // signal trace (wedm_bind_trace): descriptor, its device copy, microseconds stepped and samples
-    // written since the bind
+    // signal trace (wedm_bind_trace): descriptor, microseconds stepped and samples written since the bind
     bool trace_on = false;
     wedm_trace_desc trace{};
-    wedm_trace_desc* trace_dev = nullptr;
     int64_t trace_us = 0, trace_count = 0;
     std::string err;
     std::string last_kernel;
@@ -1453,7 +1452,6 @@ int32_t wedm_destroy(wedm_ctx* ctx) {
     if (ctx->tables_dev) (void)hipFree(ctx->tables_dev);
     if (ctx->walk_dev) (void)hipFree(ctx->walk_dev);
     if (ctx->params_dev) (void)hipFree(ctx->params_dev);
-    if (ctx->trace_dev) (void)hipFree(ctx->trace_dev);
     delete ctx;
     return WEDM_OK;
 }
@@ -1495,14 +1493,7 @@ int32_t wedm_bind_trace(wedm_ctx* ctx, const wedm_trace_desc* desc) {
         return fail(ctx, WEDM_ERR_BAD_ARG, "wedm_bind_trace: every and capacity must be >= 1");
     if (desc->env_lo < 0 || desc->env_count < 1 || (int64_t)desc->env_lo + desc->env_count > ctx->num_envs)
         return fail(ctx, WEDM_ERR_BAD_ARG, "wedm_bind_trace: environment range outside [0, num_envs)");
-    hipError_t e;
-    if (!ctx->trace_dev && (e = hipMalloc((void**)&ctx->trace_dev, sizeof(wedm_trace_desc))) != hipSuccess)
-        return hip_fail(ctx, e, "hipMalloc(trace descriptor)");
-    // synchronous copy: a launch of an earlier wedm_step may still be reading the old descriptor
-    if ((e = hipDeviceSynchronize()) != hipSuccess) return hip_fail(ctx, e, "hipDeviceSynchronize");
-    if ((e = hipMemcpy(ctx->trace_dev, desc, sizeof(wedm_trace_desc), hipMemcpyHostToDevice)) != hipSuccess)
-        return hip_fail(ctx, e, "hipMemcpy(trace descriptor)");
-    ctx->trace = *desc;
+    ctx->trace = *desc;  // travels by value with every launch: nothing to copy to the device here
     ctx->trace_on = true;
     return WEDM_OK;
 }
@@ -1587,7 +1578,7 @@ int32_t wedm_step(wedm_ctx* ctx, int32_t n_substeps, const wedm_action_ptrs* act
     k.n_seg_max = ctx->n_seg_max;
     k.walk = nullptr;
     k.dbg = ctx->dbg;
-    k.cold.tr = ctx->trace_dev;
+    k.trace = ctx->trace;
     k.trace_next = INT32_MAX;
     k.trace_slot = 0;
     if (ctx->trace_on) {
