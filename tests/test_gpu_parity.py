@@ -696,3 +696,19 @@ def test_checkpoint_resume_on_gpu(tmp_path):
     b.step_many(b.make_action(0.1, 80.0, 9, 3.0, 40.0), 1200)
     torch.cuda.synchronize()
     assert_blocks_equal(a.state.clone_blocks(), b.state.clone_blocks(), n)
+
+
+def test_full_headline_batch_matches_oracle_bit_for_bit():
+    """The bench workload itself (BASELINE configs[2]: 65 536 environments x 128 segments, the
+    kernel the bench runs) against the CPU oracle on every byte of state, 2 control intervals."""
+    n = 65536
+    kw = dict(wire_params=WireModuleParameters(segment_len=0.625))
+    gpu, cpu = make_pair(n, **kw)
+    both((gpu, cpu), lambda e: e.reset(seed=1234))
+    for env in (gpu, cpu):
+        act = env.make_action(0.1, 80.0, 5, 3.0, 80.0)
+        env.step_many(act, 1000)
+        env.step_many(act, 1000)
+    assert "wedm_step_packed<2>" in gpu._backend.last_kernel()
+    check(gpu, cpu, n)
+    assert int(gpu.state.spark_count.sum()) > 50000
