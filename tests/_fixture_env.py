@@ -45,3 +45,92 @@ def check_step(env, fx, env_index, step, *, exact_floats, float_rtol=1e-12, tmax
             else:
                 assert same or abs(want - got) <= float_rtol * max(abs(want), abs(got)), \
                     f"step {step} env {env_index} {name}: reference {want!r} got {got!r}"
+
+
+# ------------------------------------------------------------------ whole-trajectory comparison
+# A Philox fixture replayed on the BATCHED environment: the environment whose global id equals the
+# fixture's env_id must follow the reference microsecond by microsecond.  The trajectory is read
+# from the device trace, so the run itself uses fused launches (one per control interval).
+TRACE_INT = {"time": "time", "spark_state": "spark_state", "spark_dur": "spark_duration",
+             "is_short_circuit": "is_short_circuit", "random_short_remaining": "random_short_remaining",
+             "debris_short_remaining": "debris_short_remaining", "time_in_critical_temp": "time_in_critical_temp",
+             "is_wire_broken": "is_wire_broken", "is_target_reached": "is_target_distance_reached",
+             "time_since_servo": "time_since_servo"}
+TRACE_EXACT = {"workpiece_position": "workpiece_position", "wire_position": "wire_position",
+               "wire_velocity": "wire_velocity", "voltage": "voltage", "current": "current", "spark_y": "spark_location",
+               "prev_accel": "prev_accel"}
+TRACE_CLOSE = {"debris_volume": "debris_volume", "debris_density": "debris_density", "flow_rate": "flow_rate",
+               "cavity_volume": "cavity_volume", "last_crater_volume": "last_crater_volume"}
+
+
+def env_from_fixture(fx, n, *, device, backend=None):
+    """A batched environment configured like the fixture's reference run (constant-action scenarios)."""
+    from sparc_amd import (DielectricModuleParameters, EnvironmentConfig, IgnitionModuleParameters,
+                           MaterialModuleParameters, MechanicsModuleParameters, WireEDMEnv, WireModuleParameters)
+
+    m = fx.meta
+    mods = m["modules"]
+    kw = dict(backend=backend) if backend is not None else {}
+    env = WireEDMEnv(num_envs=n, device=device, mechanics_control_mode=m["control_mode"],
+                     config=EnvironmentConfig(**m["config"]),
+                     ignition_params=IgnitionModuleParameters(**mods["ignition"]),
+                     wire_params=WireModuleParameters(**mods["wire"]),
+                     material_params=MaterialModuleParameters(**mods["material"]),
+                     dielectric_params=DielectricModuleParameters(**mods["dielectric"]),
+                     mechanics_params=MechanicsModuleParameters(**mods["mechanics"]), **kw)
+    env.reset(seed=int(m["seed"]))
+    for k, v in m["state_init"].items():
+        setattr(env.state, k, v)
+    for k, v in m["module_init"].items():
+        assert k == "dielectric.debris_volume"
+        env.state.debris_volume = v
+    return env
+
+
+def run_fixture_through_trace(env, fx, *, exact_floats, float_rtol=1e-12, T_atol=1e-4):
+    """Run the fixture's constant action for its whole length in fused launches and compare the
+    traced trajectory of environment `env_id` with the reference's recording."""
+    import torch
+
+    e = int(fx.meta["env_id"])
+    assert len(fx.actions) == 1, "constant-action fixtures only"
+    servo, tv, on, off, mode = fx.actions[0]
+    act = env.make_action(servo, tv, int(mode), on, off)
+    names = sorted(set(TRACE_INT.values()) | set(TRACE_EXACT.values()) | set(TRACE_CLOSE.values()))
+    trace = env.bind_trace(names, every=1, capacity=fx.n_steps, envs=(e, 1))
+    interval = env.servo_interval // env.dt
+    left = fx.n_steps
+    while left > 0:
+        k = min(interval, left)
+        env.step_many(act, k)
+        left -= k
+    got = {k: v[:, 0].cpu().numpy() for k, v in trace.read().items()}
+    for ref, name in TRACE_INT.items():
+        want = fx.int_row(ref)
+        assert np.array_equal(got[name].astype(np.int64), want.astype(np.int64)), \
+            f"{ref}: first difference at step {int(np.nonzero(got[name].astype(np.int64) != want)[0][0])}"
+    fs = fx.float_steps
+    for ref, name in TRACE_EXACT.items():
+        want, have = fx.float_row(ref), got[name][fs]
+        same = (want == have) | (np.isnan(want) & np.isnan(have))
+        assert same.all(), f"{ref}: step {int(fs[np.nonzero(~same)[0][0]])}"
+    for ref, name in TRACE_CLOSE.items():
+        want, have = fx.float_row(ref), got[name][fs]
+        if exact_floats:
+            assert np.array_equal(want, have), ref
+        else:
+            assert np.all(np.abs(want - have) <= float_rtol * np.maximum(np.abs(want), np.abs(have))), ref
+    T = env.state.wire_temperature[e].cpu().numpy()[: fx.T_snaps.shape[1]]
+    if exact_floats:
+        assert np.array_equal(T, fx.T_snaps[-1])
+    else:
+        assert np.abs(T.astype(np.float64) - fx.T_snaps[-1]).max() <= T_atol
+    if "crater_stats" in fx.data:
+        stats = {k: v[e].item() for k, v in env.get_crater_statistics().items()}
+        total, mean, std, vmin, vmax = fx.data["crater_stats"].tolist()
+        assert stats["total_craters"] == total
+        if total:
+            assert (stats["min_volume_um3"], stats["max_volume_um3"]) == (vmin, vmax)
+            assert abs(stats["mean_volume_um3"] - mean) <= 1e-12 * mean
+    env.unbind_trace()
+    return got

@@ -712,3 +712,18 @@ def test_full_headline_batch_matches_oracle_bit_for_bit():
     assert "wedm_step_packed<2>" in gpu._backend.last_kernel()
     check(gpu, cpu, n)
     assert int(gpu.state.spark_count.sum()) > 50000
+
+
+@pytest.mark.parametrize("k", range(8))
+def test_randomized_parameter_reference_fixtures_on_gpu(golden_dir, k):
+    """F11 on the GPU: eight reference runs with randomized parameters in every module; the
+    per-microsecond trajectory comes back through the in-kernel trace of fused launches.
+    Discrete state, clocks, positions, voltage / current exact; debris / flow <= 1e-12; T <= 1e-4 K."""
+    from tests._fixture_env import env_from_fixture, run_fixture_through_trace
+    from tests._golden import Fixture
+
+    fx = Fixture(golden_dir / f"f11_random_params_{k}.npz")
+    env = env_from_fixture(fx, 64, device="cuda:0")
+    got = run_fixture_through_trace(env, fx, exact_floats=False)
+    assert (got["spark_state"] == 1).sum() > 30
+    assert "wedm_step_" in env._backend.last_kernel()

@@ -16,7 +16,9 @@ NATIVE = [
 ]
 PHILOX = [f"f3_philox_env{i}" for i in (0, 1, 2, 3, 777, 65535)] + ["f3_philox_config3_env5"] + [
     f"f8_geometry_{i}" for i in range(4)
-]
+] + ["f7_gap_controller_philox_env0", "f7_gap_controller_philox_env9", "f7_gap_controller_velocity_philox_env3",
+     "f9_voltage_controller_philox_env2", "f9_voltage_controller_velocity_philox_env5",
+     "f10_crater_statistics_philox_env1"] + [f"f11_random_params_{k}" for k in range(8)]
 
 
 @pytest.mark.parametrize("name", NATIVE)
@@ -33,8 +35,16 @@ def test_oracle_philox_matches_injected_reference(orc, golden_dir, name):
     """The reference consumed the build's Philox variates (injection shim); the oracle
     generates the same variates itself and must reproduce the reference exactly."""
     fx = Fixture(golden_dir / f"{name}.npz")
-    bad, _ = replay(fx, math_mode=orc.MATH_LIBM)
+    bad, env = replay(fx, math_mode=orc.MATH_LIBM)
     assert not bad, "\n".join(bad[:20])
+    if "crater_stats" in fx.data:  # MaterialRemovalModule.get_crater_statistics() of the reference run
+        total, mean, std, vmin, vmax = fx.data["crater_stats"].tolist()
+        assert env.spark_count == total
+        if total:
+            assert (env.crater_stat_min, env.crater_stat_max) == (vmin, vmax)
+            assert abs(env.crater_stat_sum / total - mean) <= 1e-12 * mean
+            var = max(env.crater_stat_sumsq / total - (env.crater_stat_sum / total) ** 2, 0.0)
+            assert abs(var ** 0.5 - std) <= 1e-9 * max(std, 1.0)
 
 
 def test_known_answers_from_survey(orc, golden_dir):

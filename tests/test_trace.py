@@ -258,3 +258,17 @@ def test_crater_statistics_match_the_reference(golden_dir):
     env.reset(options={"mask": torch.tensor([False, True, False])})
     st = env.get_crater_statistics()
     assert st["total_craters"].tolist()[1] == 0 and st["mean_volume_um3"][1] == 0 and st["total_craters"][0] > 0
+
+
+@pytest.mark.parametrize("k", range(8))
+def test_randomized_parameter_fixtures_on_the_batched_environment(golden_dir, k):
+    """F11: eight reference runs with randomized parameters in every module (random shorts on,
+    odd servo intervals, velocity mode, coarse wires ...).  The batched environment (host
+    derivation of all constants + SoA layout + fused launches) must reproduce the reference's
+    whole trajectory, read back through the device trace: bit for bit in LIBM math mode."""
+    from tests._fixture_env import env_from_fixture, run_fixture_through_trace
+
+    fx = Fixture(golden_dir / f"f11_random_params_{k}.npz")
+    env = env_from_fixture(fx, 64, device="cpu", backend=LibmOracleBackend)
+    got = run_fixture_through_trace(env, fx, exact_floats=True)
+    assert (got["spark_state"] == 1).sum() > 30

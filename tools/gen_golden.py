@@ -346,6 +346,12 @@ class VoltageDriver:
         return self.ctl(env, list(self.vh))
 
 
+def env_probe_modes():
+    """Current modes that have crater data in the reference (material.py:108-113)."""
+    env = ref_harness.quiet(wedm.WireEDMEnv)
+    return [m for m in env.material.crater_data.keys()]
+
+
 def single_spark_forced(spark_time=50, duration=2, loc=25.0, ocv=80.0):
     """experiments/single_spark_animation.py:209-251."""
 
@@ -476,6 +482,46 @@ def main():
                  state_init={"workpiece_position": 22.0, "wire_position": 10.0, "target_position": 5000.0},
                  action=make_action(0.05, 80.0, 13, 2.0, 20.0), t_snap_every=12000, float_stride=97,
                  note="dense sparking, mode I13: crater statistics")
+
+    # F11 — randomized parameter sets over every module (seeded), Philox variates: widens the part of
+    # the parameter space on which the oracle (and through it the GPU) is pinned to the reference
+    prng = np.random.default_rng(20261004)
+    valid_modes = sorted(int(k[1:]) for k in env_probe_modes())
+    for k in range(8):
+        u = prng.uniform
+        cfg = {"workpiece_height": float(u(8.0, 32.0)), "wire_diameter": float(prng.choice([0.1, 0.15, 0.2, 0.25, 0.3])),
+               "servo_interval": int(prng.choice([250, 500, 1000])), "initial_gap": float(u(15.0, 60.0))}
+        ign = {"base_critical_density": float(u(0.05, 0.4)), "gap_coefficient": float(u(0.005, 0.03)),
+               "max_critical_density": float(u(0.6, 0.99)), "hard_short_gap": float(u(1.0, 4.0)),
+               "sigmoid_steepness": float(prng.choice([50.0, 200.0, 500.0])),
+               "debris_short_duration": int(prng.integers(10, 80)), "random_short_duration": int(prng.integers(20, 120)),
+               "random_short_min_gap": float(u(1.0, 5.0)), "random_short_max_gap": float(u(30.0, 70.0)),
+               "random_short_max_probability": float(prng.choice([0.0, 0.002, 0.01])),
+               "ignition_a_coeff": float(0.48 * u(0.8, 1.2)), "ignition_b_coeff": float(-3.69 * u(0.8, 1.2)),
+               "ignition_c_coeff": float(14.05 * u(0.9, 1.3)), "default_target_voltage": float(u(60.0, 100.0)),
+               "default_on_time": float(u(1.0, 4.0)), "default_off_time": float(u(20.0, 90.0)),
+               "spark_voltage_factor": float(u(0.2, 0.5))}
+        wire = {"segment_len": float(prng.choice([0.2, 0.25, 0.4, 0.5])), "buffer_len_bottom": float(u(10.0, 40.0)),
+                "buffer_len_top": float(u(10.0, 40.0)), "contact_offset_bottom": float(u(5.0, 15.0)),
+                "contact_offset_top": float(u(5.0, 15.0)), "base_convection_coefficient": float(u(8000.0, 20000.0)),
+                "plasma_efficiency": float(u(0.05, 0.3)), "convection_velocity_factor": float(u(0.2, 0.8)),
+                "convection_flow_enhancement": float(u(0.5, 1.5)), "spool_T": float(prng.choice([288.15, 293.15, 300.0])),
+                "critical_temp_threshold": float(u(0.7, 0.95))}
+        mat = {"base_overcut": float(u(0.08, 0.2))}
+        diel = {"base_flow_rate": float(u(50.0, 200.0)), "debris_removal_efficiency": float(u(0.005, 0.05)),
+                "debris_obstruction_coeff": float(u(0.5, 3.0)), "reference_gap": float(u(15.0, 40.0)),
+                "dielectric_temperature": float(u(285.0, 300.0))}
+        mech = {"omega_n": float(u(150.0, 400.0)), "zeta": float(u(0.2, 0.9)), "max_acceleration": float(3.0e5 * u(0.3, 1.5)),
+                "max_jerk": float(1.0e8 * u(0.3, 1.5)), "max_speed": float(3.0e4 * u(0.3, 1.5))}
+        mode = "velocity" if k % 3 == 2 else "position"
+        servo = float(u(50.0, 400.0)) if mode == "velocity" else float(u(-0.05, 0.3))
+        act = make_action(servo, float(u(60.0, 120.0)), int(prng.choice(valid_modes)), float(u(1.0, 4.0)), float(u(10.0, 60.0)))
+        run_scenario(f"f11_random_params_{k}", n_steps=3000, seed=1000 + k, rng="philox", env_id=int(prng.integers(0, 64)),
+                     control_mode=mode, config=cfg, ignition=ign, wire=wire, material=mat, dielectric=diel, mechanics=mech,
+                     state_init={"workpiece_position": float(10.0 + u(6.0, 30.0)), "wire_position": 10.0,
+                                 "target_position": 5000.0},
+                     module_init={"dielectric.debris_volume": float(u(0.0, 0.02))} if k % 2 else None,
+                     action=act, t_snap_every=1500, float_stride=7, note="randomized parameters over all modules")
 
     # geometry variants (BASELINE config 5 shapes), short Philox runs
     for i, (h, d) in enumerate(((10.0, 0.10), (15.0, 0.25), (30.0, 0.30), (12.3, 0.15))):
