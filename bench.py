@@ -170,13 +170,16 @@ def main():
     act = env.make_action(0.1, 80.0, mode, 3.0, 80.0)
     S = env.n_segments
     obs_local = env.state.obs[:, :n_local]
-    gathered = (torch.empty((world * obs_local.shape[0], obs_local.shape[1]), dtype=obs_local.dtype, device=device)
-                if use_dist else None)
+    gather = None
+    if use_dist:  # observations of every shard, once per control step, over xGMI, overlapped with the next launch
+        from sparc_amd.parallel import PipelinedObsGather
+
+        gather = PipelinedObsGather(obs_local, world)
 
     def one_step():
         env.step_many(act, n_sub)
-        if use_dist:  # observations of every shard, once per control step, over xGMI
-            dist.all_gather_into_tensor(gathered, obs_local.contiguous())
+        if use_dist:
+            gather.post()
 
     for _ in range(args.warmup):
         one_step()
@@ -202,9 +205,10 @@ def main():
         if per_step_events:
             ends[i].record()
         if use_dist:
-            dist.all_gather_into_tensor(gathered, obs_local.contiguous())
+            gather.post()
     if not per_step_events:
         ends[0].record()
+    gathered = gather.result() if use_dist else None  # the last gather is inside the timed region
     torch.cuda.synchronize()
     if use_dist:
         dist.barrier()
@@ -231,7 +235,8 @@ def main():
                 "workload": f"{wl_name}: num_envs={n_local} per GPU, n_segments={S}, fresh reset(seed=1234), "
                             f"constant action servo 0.1 / 80 V / I5 / ON 3 / OFF 80",
                 "substeps_per_step": n_sub, "global_num_envs": world * n_local,
-                "parallelism": f"env-sharded x{world}, obs all-gather per control step" if world > 1 else "single GPU",
+                "parallelism": (f"env-sharded x{world}, obs all-gather per control step (async, overlapped with the next "
+                                "launch)") if world > 1 else "single GPU",
                 "kernel": env._backend.last_kernel(),
                 **({"trace": args.trace} if args.trace != "off" else {}),
             },
@@ -253,7 +258,8 @@ def main():
         print(json.dumps(out))
     if use_dist:
         if rank == 0 and gathered is not None:  # the gathered block really is the local observations
-            assert torch.equal(gathered[: obs_local.shape[0]], obs_local), "all-gather returned wrong data"
+            assert torch.equal(gathered[rank * obs_local.shape[0]: (rank + 1) * obs_local.shape[0]], obs_local), \
+                "all-gather returned wrong data"
         dist.destroy_process_group()
 
 

@@ -107,3 +107,35 @@ class ShardedWireEDMEnv:
 
     def close(self) -> None:
         self.env.close()
+
+
+class PipelinedObsGather:
+    """The observation all-gather taken off the critical path.
+
+    After control interval k the local observations are snapshotted into a staging buffer (a
+    2-MB device copy on the compute stream) and all-gathered ASYNCHRONOUSLY (the process group
+    runs the collective on its own stream), while the compute stream goes straight on to interval
+    k+1 — whose control step overwrites the live observation block, hence the snapshot.
+    `post()` after every `step_many`; `result()` waits for the newest gather.  Same bytes over
+    xGMI per control step as the blocking form, overlapped with the next launch."""
+
+    def __init__(self, obs_local: torch.Tensor, world_size: int, group: Optional[Any] = None):
+        self.obs_local = obs_local                        # [obs_dim, n_local] view of the live block
+        self.stage = torch.empty_like(obs_local, memory_format=torch.contiguous_format)
+        self.out = torch.empty((world_size * obs_local.shape[0], obs_local.shape[1]), dtype=obs_local.dtype,
+                               device=obs_local.device)
+        self.group = group
+        self._work = None
+
+    def post(self) -> None:
+        if self._work is not None:
+            self._work.wait()          # the previous gather has consumed the staging buffer
+        self.stage.copy_(self.obs_local)
+        self._work = dist.all_gather_into_tensor(self.out, self.stage, group=self.group, async_op=True)
+
+    def result(self) -> torch.Tensor:
+        """Rank-major ``[world * obs_dim, n_local]`` block of the newest posted gather."""
+        if self._work is not None:
+            self._work.wait()
+            self._work = None
+        return self.out

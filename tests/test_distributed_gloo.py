@@ -48,8 +48,14 @@ def _worker(rank, world, port, out):
         env.state.wire_position = 10.0
         env.state.target_position = 5000.0
         act = env.make_action(servo=torch.linspace(-0.2, 0.4, N_GLOBAL).double(), current_mode=[1, 3, 5, 7, 9, 11] * 4)
+        from sparc_amd.parallel import PipelinedObsGather
+
+        pipe = PipelinedObsGather(env.state.obs[:, : env.num_envs], world)
         for _ in range(2):
             obs_all, *_ = env.step_control(act)
+            pipe.post()                       # the bench's overlapped form of the same gather
+        piped = pipe.result().view(world, -1, env.num_envs).permute(0, 2, 1).reshape(N_GLOBAL, -1)
+        assert torch.equal(piped, obs_all)
         done_all = env.gather_done()
         blocks = env.state.clone_blocks()
         n = env.num_envs
