@@ -961,8 +961,15 @@ __global__ void __launch_bounds__(256, 2) wedm_step_packed(const KArgs k) {
         if (__all(s.done) && !tracing) break;
         WEDM_STAMP(st0);
         Coef cf{0.0f, 0.0f, 0, -1};
+#ifdef WEDM_STAMPS
+        const bool was_quiet = quiet_prelude(hv, g, gid, s);
+        if (!was_quiet && !s.done) cf = scalar_prelude(hv, cold, g, e, gid, s, ps, c == 0);
+        WEDM_STAMP(st1);
+        if (was_quiet) { accN += st1 - st0; ++cntN; } else { accB += st1 - st0; ++cntB; }  // quiet / general prelude
+#else
         if (!quiet_prelude(hv, g, gid, s) && !s.done) cf = scalar_prelude(hv, cold, g, e, gid, s, ps, c == 0);
         WEDM_STAMP(st1);
+#endif
 
         // ---- halos (OLD values, read before any store of this step)
         const float halo_l = (c > 0) ? col[(R - 1) * 256 - 1] : spool;  // left neighbour lane's B[Cv-1]

@@ -28,8 +28,12 @@ t = raw[nblk * 16: nblk * 16 + nblk * 24].reshape(-1, 6)
 t = t[t[:, 3:].sum(axis=1) > 0]
 if len(t):
     tm = t.mean(axis=0)
-    print("   tiles per step: N %.2f B %.2f S %.2f ; cycles per tile: N %.0f B %.0f S %.0f" % (
-        tm[3] / 1000, tm[4] / 1000, tm[5] / 1000, tm[0] / max(tm[3], 1), tm[1] / max(tm[4], 1), tm[2] / max(tm[5], 1)))
+    if kernel == 4:  # the packed kernel uses these slots for the prelude: quiet fast path vs general path
+        print("   prelude: quiet path on %.0f %% of the steps at %.0f cycles, general path %.0f %% at %.0f cycles" % (
+            tm[3] / 10, tm[0] / max(tm[3], 1), tm[4] / 10, tm[1] / max(tm[4], 1)))
+    else:
+        print("   tiles per step: N %.2f B %.2f S %.2f ; cycles per tile: N %.0f B %.0f S %.0f" % (
+            tm[3] / 1000, tm[4] / 1000, tm[5] / 1000, tm[0] / max(tm[3], 1), tm[1] / max(tm[4], 1), tm[2] / max(tm[5], 1)))
 b = b[b.sum(axis=1) > 0]
 m = b.mean(axis=0) / 1000.0
 print(f"kernel {kernel} lanes {lanes} {wl}: waves {len(b)}  cycles/step: prelude {m[0]:.0f}  walk {m[1]:.0f}  patches+reduce {m[2]:.0f}  epilogue {m[3]:.0f}  total {m.sum():.0f}  ({env._backend.last_kernel()})")
