@@ -48,6 +48,9 @@ def parse_args():
     ap.add_argument("--lanes", type=int, default=0, help="lanes per environment in kernel 3 (0 auto)")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="target wall time of the cpu_baseline leg")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--gap", type=float, default=None,
+                    help="side measurement: start from this gap [um] instead of the reset state's 50 um (a 15 um gap "
+                         "sparks about every 90 us per environment, so the general scalar path runs on most steps)")
     ap.add_argument("--trace", choices=["off", "voltage", "signals"], default="off",
                     help="side measurement: cost of the in-kernel signal trace (every microsecond, all environments): "
                          "'voltage' = the 1 ms ring the voltage controller needs, 'signals' = the 11 scalar signals "
@@ -167,6 +170,10 @@ def main():
         env.bind_trace(["time", "voltage", "current", "wire_position", "wire_velocity", "workpiece_position",
                         "target_delta", "debris_concentration", "flow_rate", "is_short_circuit"], every=args.trace_every, capacity=1000)
     env.reset(seed=1234)
+    if args.gap is not None:
+        env.state.wire_position = 10.0
+        env.state.workpiece_position = 10.0 + args.gap
+        env.state.target_position = 5000.0
     act = env.make_action(0.1, 80.0, mode, 3.0, 80.0)
     S = env.n_segments
     obs_local = env.state.obs[:, :n_local]
@@ -239,6 +246,7 @@ def main():
                                 "launch)") if world > 1 else "single GPU",
                 "kernel": env._backend.last_kernel(),
                 **({"trace": args.trace} if args.trace != "off" else {}),
+                **({"initial_gap_um": args.gap} if args.gap is not None else {}),
             },
             "roofline": {
                 "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
