@@ -727,3 +727,71 @@ def test_randomized_parameter_reference_fixtures_on_gpu(golden_dir, k):
     got = run_fixture_through_trace(env, fx, exact_floats=False)
     assert (got["spark_state"] == 1).sum() > 30
     assert "wedm_step_" in env._backend.last_kernel()
+
+
+@pytest.mark.parametrize("case", range(10))
+def test_randomized_configurations_all_kernels_bit_exact(case):
+    """Fuzz: random parameters in every module, random batch size / control mode / action / kernel
+    variant (and per-environment geometry in a third of the cases): GPU == oracle on every byte."""
+    from sparc_amd import DielectricModuleParameters, MaterialModuleParameters
+    from sparc_amd._lib import WedmError
+
+    rng = np.random.default_rng(9000 + case)
+    u = rng.uniform
+    n = int(rng.choice([65, 128, 200, 333]))
+    per_env = case % 3 == 2
+    kw = dict(
+        mechanics_control_mode="velocity" if case % 4 == 1 else "position",
+        config=EnvironmentConfig(workpiece_height=float(u(8, 32)), wire_diameter=float(rng.choice([0.1, 0.2, 0.3])),
+                                 servo_interval=int(rng.choice([200, 500, 1000])), initial_gap=float(u(15, 40)),
+                                 target_cutting_distance=5000.0),
+        ignition_params=IgnitionModuleParameters(
+            base_critical_density=float(u(0.05, 0.4)), gap_coefficient=float(u(0.005, 0.03)),
+            sigmoid_steepness=float(rng.choice([50.0, 500.0])), hard_short_gap=float(u(1, 4)),
+            debris_short_duration=int(rng.integers(10, 80)), random_short_duration=int(rng.integers(20, 120)),
+            random_short_max_probability=float(rng.choice([0.0, 0.003, 0.01])), spark_voltage_factor=float(u(0.2, 0.5)),
+            ignition_c_coeff=float(14.05 * u(0.9, 1.3))),
+        wire_params=WireModuleParameters(segment_len=float(rng.choice([0.2, 0.25, 0.5, 0.625])),
+                                         buffer_len_bottom=float(u(10, 40)), buffer_len_top=float(u(10, 40)),
+                                         base_convection_coefficient=float(u(8000, 20000)),
+                                         plasma_efficiency=float(u(0.05, 0.3)), critical_temp_threshold=float(u(0.7, 0.95))),
+        material_params=MaterialModuleParameters(base_overcut=float(u(0.08, 0.2))),
+        dielectric_params=DielectricModuleParameters(base_flow_rate=float(u(50, 200)), debris_obstruction_coeff=float(u(0.5, 3)),
+                                                     reference_gap=float(u(15, 40)), dielectric_temperature=float(u(285, 300))),
+        mechanics_params=MechanicsModuleParameters(omega_n=float(u(150, 400)), zeta=float(u(0.2, 0.9)),
+                                                   max_speed=float(3e4 * u(0.3, 1.5))),
+    )
+    if per_env:
+        kw["workpiece_height"] = rng.uniform(8, 32, n)
+        kw["wire_diameter"] = rng.choice([0.1, 0.15, 0.25], n)
+    gpu, cpu = make_pair(n, **kw)
+    seed = int(rng.integers(1, 1 << 40))
+    gaps, debris = rng.uniform(6, 30, n), rng.uniform(0, 0.01, n)
+    for env in (gpu, cpu):
+        env.reset(seed=seed)
+        env.state.wire_position = 10.0
+        env.state.workpiece_position = torch.as_tensor(10.0 + gaps)
+        env.state.target_position = 5000.0
+        env.state.debris_volume = torch.as_tensor(debris) if case % 2 else 0.0
+    variants = [(0, 0), (1, 0), (5, 0), (2, 4), (2, 8)] if per_env else KERNELS + [(0, 0)]
+    servo = rng.uniform(50, 300, n) if kw["mechanics_control_mode"] == "velocity" else rng.uniform(-0.05, 0.3, n)
+    modes = rng.choice([1, 3, 5, 7, 9, 11, 13, 15, 17], n).astype(np.int32)
+    ran = 0
+    for variant, lanes in [variants[i] for i in rng.permutation(len(variants))[:4]]:
+        gpu.set_kernel(variant, lanes)
+        k = int(rng.choice([1, 7, 400, 1300]))
+        if ran == 0:
+            volt, on, off = float(u(60, 120)), float(rng.choice([1.5, 2.0, 3.0])), float(u(10, 60))
+            acts = [env.make_action(servo, volt, modes, on, off) for env in (gpu, cpu)]
+        try:
+            gpu.step_many(acts[0], k)
+        except WedmError as exc:
+            assert "UNSUPPORTED" in str(exc)
+            continue
+        cpu.step_many(acts[1], k)
+        torch.cuda.synchronize()
+        diffs = block_diffs(gpu.state.clone_blocks(), cpu.state.clone_blocks(), n)
+        assert not diffs, f"case {case}: kernel {gpu._backend.last_kernel()} after {k} us (n={n}, S={gpu.n_segments}):\n" + \
+            "\n".join(diffs[:12])
+        ran += 1
+    assert ran >= 2
