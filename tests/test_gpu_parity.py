@@ -795,3 +795,27 @@ def test_randomized_configurations_all_kernels_bit_exact(case):
             "\n".join(diffs[:12])
         ran += 1
     assert ran >= 2
+
+
+@pytest.mark.parametrize("segment_len,expect", [(0.05, "wedm_step_fused<16>"), (0.02, "wedm_step_global")])
+def test_very_long_wires_fall_back_to_a_kernel_that_fits(segment_len, expect):
+    """1 600 segments (a chunk fits in LDS only at 16 lanes per environment) and 4 000 segments (no
+    LDS kernel fits: multi-microsecond launches run the global-memory kernel); single steps take
+    the split kernel.  All against the oracle."""
+    n = 70
+    kw = dict(wire_params=WireModuleParameters(segment_len=segment_len))
+    gpu, cpu = make_pair(n, **kw)
+    assert gpu.n_segments == round(80.0 / segment_len)
+    both((gpu, cpu), lambda e: (e.reset(seed=6), close_gap(e)))
+    for env in (gpu, cpu):
+        act = env.make_action(0.1, 80.0, 9, 3.0, 30.0)
+        env.step_many(act, 150)
+    assert expect in gpu._backend.last_kernel()
+    check(gpu, cpu, n)
+    for env in (gpu, cpu):
+        act = env.make_action(0.1, 80.0, 9, 3.0, 30.0)
+        for _ in range(3):
+            env.step(act)
+    assert "wedm_step_split" in gpu._backend.last_kernel()
+    check(gpu, cpu, n)
+    assert int(gpu.state.spark_count.sum()) > 0
