@@ -819,3 +819,15 @@ def test_very_long_wires_fall_back_to_a_kernel_that_fits(segment_len, expect):
     assert "wedm_step_split" in gpu._backend.last_kernel()
     check(gpu, cpu, n)
     assert int(gpu.state.spark_count.sum()) > 0
+
+
+def test_single_environment_batch_follows_the_reference(golden_dir):
+    """num_envs = 1 (the reference's own shape): fixture F3 env 0, whole trajectory through the
+    device trace, fused launches."""
+    from tests._fixture_env import env_from_fixture, run_fixture_through_trace
+    from tests._golden import Fixture
+
+    fx = Fixture(golden_dir / "f3_philox_env0.npz")
+    env = env_from_fixture(fx, 1, device="cuda:0")
+    got = run_fixture_through_trace(env, fx, exact_floats=False)
+    assert (got["spark_state"] == 1).sum() > 10
