@@ -17,8 +17,21 @@ from . import _abi
 from .envs.wire_edm import WireEDMEnv
 
 
+def progress_reward(env: WireEDMEnv, prev: Dict[str, torch.Tensor]) -> torch.Tensor:
+    """Default reward of the adapter (the reference's `_calculate_reward` is a TODO returning 0.0,
+    envs/wire_edm.py:185-187): micrometres cut during the control interval, minus 10 when the wire
+    broke or collided in it, float32 per environment."""
+    st = env.state
+    cut = (st.workpiece_position - prev["workpiece_position"]).to(torch.float32)
+    return cut - 10.0 * st.is_wire_broken.to(torch.float32)
+
+
 class WireEDMVectorEnv:
-    def __init__(self, env: WireEDMEnv, *, max_episode_steps: Optional[int] = None, autoreset: bool = True):
+    def __init__(self, env: WireEDMEnv, *, max_episode_steps: Optional[int] = None, autoreset: bool = True,
+                 reward=None):
+        """``reward``: None keeps the reference's constant 0.0; ``"progress"`` selects `progress_reward`;
+        a callable ``f(env, prev) -> float32[N]`` receives the environment after the control interval
+        and ``prev = {"workpiece_position": ...}`` snapshotted before it (all on the device)."""
         self.env = env
         self.num_envs = env.num_envs
         self.single_action_space = env.single_action_space
@@ -27,6 +40,9 @@ class WireEDMVectorEnv:
         self.observation_space = env.observation_space
         self.autoreset = bool(autoreset)
         self.max_episode_steps = max_episode_steps
+        self._reward_fn = progress_reward if reward == "progress" else reward
+        if self._reward_fn is not None and not callable(self._reward_fn):
+            raise ValueError("reward must be None, 'progress' or a callable")
         self._need_reset = torch.zeros(self.num_envs, dtype=torch.bool, device=env.device)
         self.episode_count = torch.zeros(self.num_envs, dtype=torch.int64, device=env.device)
 
@@ -41,7 +57,10 @@ class WireEDMVectorEnv:
             self.env.reset(options={"mask": self._need_reset})  # same key, next episode stream
             self.episode_count += self._need_reset.to(torch.int64)
             self._need_reset.zero_()
+        prev = {"workpiece_position": self.env.state.workpiece_position.clone()} if self._reward_fn is not None else None
         obs, reward, terminated, truncated, info = self.env.step_control(action)
+        if self._reward_fn is not None:
+            reward = self._reward_fn(self.env, prev)
         terminated = terminated.clone()
         if self.max_episode_steps is not None:
             truncated = (self.env.state.time >= self.max_episode_steps) & ~terminated

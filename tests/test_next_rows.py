@@ -99,6 +99,30 @@ def test_vector_env_autoreset():
     assert (vec2.env.state.time == 1000).all()           # reset happened before the third interval
 
 
+def test_vector_env_progress_reward():
+    env = WireEDMEnv(num_envs=5, device="cpu", backend=OracleBackend)
+    vec = WireEDMVectorEnv(env, reward="progress")
+    vec.reset(seed=4)
+    env.state.workpiece_position = 24.0
+    env.state.wire_position = 10.0
+    env.state.target_position = 5000.0
+    act = env.make_action(0.05, 80.0, 13, 2.0, 20.0)
+    total = torch.zeros(5)
+    for _ in range(3):
+        _, reward, *_ = vec.step(act)
+        assert reward.dtype == torch.float32 and reward.shape == (5,)
+        total += reward
+    cut = (env.state.workpiece_position - 24.0).to(torch.float32)
+    assert torch.allclose(total, cut, atol=1e-5) and bool((cut > 0).all())          # micrometres of material removed
+    plain = WireEDMVectorEnv(WireEDMEnv(num_envs=2, device="cpu", backend=OracleBackend))
+    plain.reset(seed=1)
+    assert float(plain.step(plain.env.make_action())[1].abs().sum()) == 0.0          # the reference's constant 0.0
+    custom = WireEDMVectorEnv(env, reward=lambda e, prev: e.state.voltage.to(torch.float32))
+    assert torch.equal(custom.step(act)[1], env.state.voltage.to(torch.float32))
+    with pytest.raises(ValueError):
+        WireEDMVectorEnv(env, reward="nope")
+
+
 def test_signal_logger_frequencies_and_npz(tmp_path):
     env = driver_env(4, 9, backend=OracleBackend)
     cfg = {"signals_to_log": ["time", "voltage", "wire_position", "spark_status", "wire_temperature"],
