@@ -22,7 +22,6 @@ Documented deviations from the single-environment reference:
 from __future__ import annotations
 
 import os
-from types import SimpleNamespace
 from typing import Any, Callable, Dict, Optional
 
 import numpy as np
@@ -173,13 +172,14 @@ class WireEDMEnv:
         if self.per_env_geometry:
             self._backend.bind_geometry(_abi.GeomPtrs(self._geom_f64.data_ptr(), self._geom_i32.data_ptr()))
 
-        # lightweight views where the reference exposes module objects
-        self.ignition = SimpleNamespace(params=self.ignition_params)
-        self.wire = SimpleNamespace(params=self.wire_params, n_segments=self.n_segments,
-                                    wire_material=self.wire_material, geometry=self.geometry)
-        self.material = SimpleNamespace(params=self.material_params, crater_data=CRATER, currents_data=MODE_CURRENT)
-        self.dielectric = SimpleNamespace(params=self.dielectric_params)
-        self.mechanics = SimpleNamespace(params=self.mechanics_params, control_mode=mechanics_control_mode)
+        # what remains of the reference's module objects: parameters + read-only helpers
+        from ..modules.views import DielectricView, IgnitionView, MaterialView, MechanicsView, WireView
+
+        self.ignition = IgnitionView(self, self.ignition_params)
+        self.wire = WireView(self, self.wire_params, self.n_segments, self.wire_material, self.geometry)
+        self.material = MaterialView(self, self.material_params)
+        self.dielectric = DielectricView(self, self.dielectric_params)
+        self.mechanics = MechanicsView(self, self.mechanics_params, mechanics_control_mode)
         self.modules = {"ignition": self.ignition, "material": self.material, "dielectric": self.dielectric,
                         "wire": self.wire, "mechanics": self.mechanics}
 

@@ -223,3 +223,36 @@ def test_product_refuses_to_run_without_the_gpu():
     """No CPU fallback: the default backend is the HIP library and needs a CUDA/HIP device."""
     with pytest.raises(RuntimeError, match="no CPU path"):
         WireEDMEnv(num_envs=2, device="cpu")
+
+
+def test_module_getters_match_the_reference(golden_dir):
+    """F12: `IgnitionModule.get_critical_density_for_gap / get_debris_short_probability / get_lambda`
+    and `MaterialRemovalModule.get_current_mapping_table` of the reference over a grid."""
+    import numpy as np
+
+    from tests._oracle_backend import OracleBackend
+
+    z = np.load(golden_dir / "f12_module_getters.npz")
+    gaps, dens = torch.from_numpy(z["gaps"]), torch.from_numpy(z["densities"])
+    env = WireEDMEnv(num_envs=len(gaps), device="cpu", backend=OracleBackend)
+    env.reset(seed=0)
+    assert np.array_equal(env.ignition.get_critical_density_for_gap(gaps).numpy(), z["critical_density"])
+    p = env.ignition.get_debris_short_probability(gaps[:, None], dens[None, :]).numpy()
+    assert np.allclose(p, z["debris_short_probability"], rtol=1e-14, atol=0)
+    env.state.wire_position = 10.0
+    env.state.workpiece_position = 10.0 + gaps
+    assert np.allclose(env.ignition.get_lambda().numpy(), z["ignition_lambda"], rtol=1e-15, atol=0)
+    env.state.is_short_circuit[3] = True
+    assert bool(torch.isnan(env.ignition.get_lambda()[3]))
+    table = env.material.get_current_mapping_table()
+    for row in z["mapping"]:
+        e = table[f"I{int(row[0])}"]
+        assert e["machine_current"] == row[1] and (e["crater_data"] is not None) == bool(row[2])
+        if row[2]:
+            cd = e["crater_data"]
+            assert (cd["ellipsoid_volume_half"], cd["ellipsoid_volume_std"], cd["depth"]) == tuple(row[3:6])
+        else:
+            assert "error" in e
+    assert env.material.get_crater_data_for_current_mode("I99")["current_mode"] == "I1"
+    assert env.wire.compute_zone_mean_temperature().shape == (len(gaps),)
+    assert set(env.dielectric.get_debris_statistics()) >= {"debris_volume_mm3", "flow_condition"}

@@ -531,6 +531,31 @@ def main():
                      action=make_action(0.1, 80.0, (1, 7, 15, 17)[i], 3.0, 40.0), t_snap_every=2500,
                      float_stride=5, note=f"h={h} d={d}")
 
+    # F12 — the modules' public getters over a grid (ignition.py:348-384, material.py:176-205)
+    if not only or only in "f12_module_getters":
+        env = ref_harness.quiet(wedm.WireEDMEnv)
+        env.reset(seed=0)
+        gaps = np.concatenate([np.linspace(0.25, 4.0, 16), np.linspace(5.0, 80.0, 31)])
+        dens = np.linspace(0.0, 1.0, 41)
+        crit = np.array([env.ignition.get_critical_density_for_gap(float(g)) for g in gaps])
+        pshort = np.array([[env.ignition.get_debris_short_probability(float(g), float(d)) for d in dens] for g in gaps])
+        lam = []
+        for g in gaps:
+            env.state.workpiece_position, env.state.wire_position, env.state.is_short_circuit = 10.0 + float(g), 10.0, False
+            lam.append(env.ignition.get_lambda(env.state))
+        table = env.material.get_current_mapping_table()
+        rows = []
+        for i in range(1, 20):
+            e = table[f"I{i}"]
+            cd = e["crater_data"]
+            rows.append([i, e["machine_current"], 1.0 if cd else 0.0,
+                         cd["ellipsoid_volume_half"] if cd else 0.0, cd["ellipsoid_volume_std"] if cd else 0.0,
+                         cd["depth"] if cd else 0.0])
+        np.savez_compressed(OUT / "f12_module_getters.npz", gaps=gaps, densities=dens, critical_density=crit,
+                            debris_short_probability=pshort, ignition_lambda=np.array(lam, dtype=np.float64),
+                            mapping=np.array(rows, dtype=np.float64))
+        print("f12_module_getters", len(gaps), "gaps x", len(dens), "densities")
+
     # F4 — geometry table straight from WireModule.__init__
     rows = []
     for h in (5.0, 10.0, 12.3, 15.0, 20.0, 25.0, 30.0, 47.7):
