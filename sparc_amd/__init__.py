@@ -23,6 +23,8 @@ from .modules.parameters import (
     WireModuleParameters,
 )
 
+from .core.state_utils import get_gap, is_short_circuited
+from .modules.views import DielectricModule, IgnitionModule, MaterialRemovalModule, MechanicsModule, WireModule
 from .controllers import GapController, VoltageController, run_controlled
 from .trace import DeviceTrace
 from .utils.logger import LoggerConfig, SimulationLogger
@@ -36,6 +38,8 @@ __all__ = [
     "EDMState", "BatchedEDMState", "EnvironmentConfig", "MaterialDatabase", "WireMaterial", "get_material_db",
     "WireEDMEnv", "DeviceAction", "WireEDMVectorEnv", "GapController", "VoltageController", "run_controlled", "DeviceTrace",
     "SimulationLogger", "LoggerConfig",
+    "IgnitionModule", "WireModule", "MaterialRemovalModule", "DielectricModule", "MechanicsModule",
+    "get_gap", "is_short_circuited",
     "IgnitionModuleParameters", "WireModuleParameters", "MaterialModuleParameters",
     "DielectricModuleParameters", "MechanicsModuleParameters",
 ]

@@ -175,11 +175,11 @@ class WireEDMEnv:
         # what remains of the reference's module objects: parameters + read-only helpers
         from ..modules.views import DielectricView, IgnitionView, MaterialView, MechanicsView, WireView
 
-        self.ignition = IgnitionView(self, self.ignition_params)
-        self.wire = WireView(self, self.wire_params, self.n_segments, self.wire_material, self.geometry)
-        self.material = MaterialView(self, self.material_params)
-        self.dielectric = DielectricView(self, self.dielectric_params)
-        self.mechanics = MechanicsView(self, self.mechanics_params, mechanics_control_mode)
+        self.ignition = IgnitionView(self)
+        self.wire = WireView(self)
+        self.material = MaterialView(self)
+        self.dielectric = DielectricView(self)
+        self.mechanics = MechanicsView(self)
         self.modules = {"ignition": self.ignition, "material": self.material, "dielectric": self.dielectric,
                         "wire": self.wire, "mechanics": self.mechanics}
 

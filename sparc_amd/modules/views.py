@@ -23,8 +23,9 @@ def _t(x, like=None) -> torch.Tensor:
 class IgnitionView:
     """`IgnitionModule`'s parameters and getters (modules/ignition.py:348-399)."""
 
-    def __init__(self, env, params):
-        self._env, self.params = env, params
+    def __init__(self, env, params=None):
+        self._env = self.env = env
+        self.params = params if params is not None else env.ignition_params
 
     def get_critical_density_for_gap(self, gap):
         """ignition.py:366-377: 0 below the hard-short gap, else min(base + k*gap, max)."""
@@ -59,8 +60,9 @@ class IgnitionView:
 class MaterialView:
     """`MaterialRemovalModule`'s tables and getters (modules/material.py:176-227)."""
 
-    def __init__(self, env, params):
-        self._env, self.params = env, params
+    def __init__(self, env, params=None):
+        self._env = self.env = env
+        self.params = params if params is not None else env.material_params
         self.currents_data = {f"I{m}": {"Current": a} for m, a in MODE_CURRENT.items()}
         self.crater_data = {f"I{m}": {"ellipsoid_volume_half": v, "ellipsoid_volume_std": s, "depth": d}
                             for m, (v, s, d) in CRATER.items()}
@@ -85,17 +87,21 @@ class MaterialView:
 class DielectricView:
     """`DielectricModule`'s parameters and statistics (modules/dielectric.py:164-182)."""
 
-    def __init__(self, env, params):
-        self._env, self.params = env, params
+    def __init__(self, env, params=None):
+        self._env = self.env = env
+        self.params = params if params is not None else env.dielectric_params
 
     def get_debris_statistics(self) -> Dict[str, torch.Tensor]:
         return self._env.get_debris_statistics()
 
 
 class WireView:
-    def __init__(self, env, params, n_segments, wire_material, geometry):
-        self._env, self.params, self.n_segments = env, params, n_segments
-        self.wire_material, self.geometry = wire_material, geometry
+    """`WireModule`'s parameters, derived geometry and zone-mean helper (modules/wire.py:143-257,390-398)."""
+
+    def __init__(self, env, params=None):
+        self._env = self.env = env
+        self.params = params if params is not None else env.wire_params
+        self.n_segments, self.wire_material, self.geometry = env.n_segments, env.wire_material, env.geometry
 
     def compute_zone_mean_temperature(self, temperature_field=None) -> torch.Tensor:
         """wire.py:395-398 for every environment (``temperature_field``: ``[N, n_seg]``, default the state's)."""
@@ -107,5 +113,15 @@ class WireView:
 
 
 class MechanicsView:
-    def __init__(self, env, params, control_mode):
-        self._env, self.params, self.control_mode = env, params, control_mode
+    """`MechanicsModule`'s parameters and control mode (modules/mechanics.py:29-67)."""
+
+    def __init__(self, env, params=None):
+        self._env = self.env = env
+        self.params = params if params is not None else env.mechanics_params
+        self.control_mode = env.mechanics_control_mode
+
+
+# the reference's class names (wedm/__init__.py:22-42), for imports and isinstance checks; the
+# physics these classes carry in the reference runs inside the fused kernel
+IgnitionModule, WireModule, MaterialRemovalModule = IgnitionView, WireView, MaterialView
+DielectricModule, MechanicsModule = DielectricView, MechanicsView

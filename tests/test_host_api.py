@@ -256,3 +256,23 @@ def test_module_getters_match_the_reference(golden_dir):
     assert env.material.get_crater_data_for_current_mode("I99")["current_mode"] == "I1"
     assert env.wire.compute_zone_mean_temperature().shape == (len(gaps),)
     assert set(env.dielectric.get_debris_statistics()) >= {"debris_volume_mm3", "flow_condition"}
+
+
+def test_reference_class_names_and_state_utils_are_importable():
+    import sparc_amd
+    from sparc_amd import IgnitionModule, WireModule, get_gap, is_short_circuited
+    from tests._oracle_backend import OracleBackend
+
+    for name in ("EDMState", "EnvironmentConfig", "MaterialDatabase", "WireMaterial", "get_material_db", "WireEDMEnv",
+                 "IgnitionModule", "IgnitionModuleParameters", "WireModule", "WireModuleParameters",
+                 "MaterialRemovalModule", "MaterialModuleParameters", "DielectricModule", "DielectricModuleParameters",
+                 "MechanicsModule", "MechanicsModuleParameters"):          # wedm/__init__.py:22-42
+        assert hasattr(sparc_amd, name), name
+    env = WireEDMEnv(num_envs=3, device="cpu", backend=OracleBackend)
+    env.reset(seed=1)
+    assert isinstance(env.ignition, IgnitionModule) and isinstance(env.wire, WireModule)
+    assert WireModule(env).n_segments == env.n_segments and env.mechanics.control_mode == "position"
+    env.state.wire_position[1] = 60.0
+    env.state.spark_state[2] = -1
+    assert get_gap(env.state).tolist() == [50.0, 0.0, 50.0]
+    assert is_short_circuited(env.state).tolist() == [False, False, True]
