@@ -276,3 +276,22 @@ def test_reference_class_names_and_state_utils_are_importable():
     env.state.spark_state[2] = -1
     assert get_gap(env.state).tolist() == [50.0, 0.0, 50.0]
     assert is_short_circuited(env.state).tolist() == [False, False, True]
+
+
+def test_readme_usage_snippet_runs(tmp_path):
+    """The Python block of README.md, executed against the CPU test seam (small batch, short run)."""
+    import re
+    from pathlib import Path
+
+    import numpy as np
+
+    from tests._oracle_backend import OracleBackend  # noqa: F401  (used by the exec'd code)
+
+    src = (Path(__file__).resolve().parents[1] / "README.md").read_text()
+    code = re.search(r"```python\n(.*?)```", src, re.S).group(1)
+    out = tmp_path / "run.npz"
+    code = (code.replace('num_envs=65536, device="cuda"', 'num_envs=70, device="cpu", backend=OracleBackend')
+            .replace("100_000", "2_500").replace('"filepath": "run.npz"', f'"filepath": "{out}"'))
+    exec(code, {"OracleBackend": OracleBackend})
+    z = np.load(out)
+    assert z["time"].shape == (2500, 64) and z["time"][:, 0].tolist() == list(range(1, 2501))
