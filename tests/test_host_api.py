@@ -294,4 +294,4 @@ def test_readme_usage_snippet_runs(tmp_path):
             .replace("100_000", "2_500").replace('"filepath": "run.npz"', f'"filepath": "{out}"'))
     exec(code, {"OracleBackend": OracleBackend})
     z = np.load(out)
-    assert z["time"].shape == (2500, 64) and z["time"][:, 0].tolist() == list(range(1, 2501))
+    assert z["time"].shape == (2500, 64) and z["time"][:, 0].tolist() == list(range(1002, 3502))  # after 1 + 1000 us
