@@ -276,6 +276,10 @@ class WireEDMEnv:
 
     def _prepare_action(self, action) -> DeviceAction:
         if isinstance(action, DeviceAction):
+            # the kernel reads num_envs elements through raw pointers: never let a foreign action through
+            if action.servo.device != self.device or action.servo.numel() != self.num_envs:
+                raise ValueError("DeviceAction belongs to another environment (device or num_envs differ); "
+                                 "build it with this environment's make_action()")
             return action
         gc = action["generator_control"]
         mode = gc["current_mode"]

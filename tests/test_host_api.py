@@ -295,3 +295,12 @@ def test_readme_usage_snippet_runs(tmp_path):
     exec(code, {"OracleBackend": OracleBackend})
     z = np.load(out)
     assert z["time"].shape == (2500, 64) and z["time"][:, 0].tolist() == list(range(1002, 3502))  # after 1 + 1000 us
+
+
+def test_foreign_device_action_is_rejected():
+    from tests._oracle_backend import OracleBackend
+
+    a = WireEDMEnv(num_envs=4, device="cpu", backend=OracleBackend)
+    b = WireEDMEnv(num_envs=9, device="cpu", backend=OracleBackend)
+    with pytest.raises(ValueError, match="another environment"):
+        b.step(a.make_action())
