@@ -831,3 +831,13 @@ def test_single_environment_batch_follows_the_reference(golden_dir):
     env = env_from_fixture(fx, 1, device="cuda:0")
     got = run_fixture_through_trace(env, fx, exact_floats=False)
     assert (got["spark_state"] == 1).sum() > 10
+
+
+def test_two_microsecond_physics_step_fixture_on_gpu(golden_dir):
+    from tests._fixture_env import env_from_fixture, run_fixture_through_trace
+    from tests._golden import Fixture
+
+    fx = Fixture(golden_dir / "f13_dt2_philox_env4.npz")
+    env = env_from_fixture(fx, 64, device="cuda:0")
+    got = run_fixture_through_trace(env, fx, exact_floats=False)
+    assert got["time"][:3].tolist() == [2, 4, 6]

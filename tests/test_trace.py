@@ -272,3 +272,14 @@ def test_randomized_parameter_fixtures_on_the_batched_environment(golden_dir, k)
     env = env_from_fixture(fx, 64, device="cpu", backend=LibmOracleBackend)
     got = run_fixture_through_trace(env, fx, exact_floats=True)
     assert (got["spark_state"] == 1).sum() > 30
+
+
+def test_two_microsecond_physics_step_fixture(golden_dir):
+    """F13: config.dt = 2 (clocks and the servo integrate 2 us per step, the wire keeps its 1 us
+    update factor, wire.py:192-196) on the batched environment, whole trajectory, bit for bit."""
+    from tests._fixture_env import env_from_fixture, run_fixture_through_trace
+
+    fx = Fixture(golden_dir / "f13_dt2_philox_env4.npz")
+    env = env_from_fixture(fx, 8, device="cpu", backend=LibmOracleBackend)
+    got = run_fixture_through_trace(env, fx, exact_floats=True)
+    assert got["time"][:3].tolist() == [2, 4, 6] and (got["spark_state"] == 1).sum() > 30

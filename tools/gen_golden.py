@@ -531,6 +531,13 @@ def main():
                      action=make_action(0.1, 80.0, (1, 7, 15, 17)[i], 3.0, 40.0), t_snap_every=2500,
                      float_stride=5, note=f"h={h} d={d}")
 
+    # F13 — a physics step other than 1 us (config.dt = 2: clocks and mechanics scale, wire.py keeps 1e-6 s)
+    run_scenario("f13_dt2_philox_env4", n_steps=2500, seed=90, rng="philox", env_id=4,
+                 config={"dt": 2, "servo_interval": 500},
+                 state_init={"workpiece_position": 24.0, "wire_position": 10.0, "target_position": 5000.0},
+                 action=make_action(0.1, 80.0, 9, 3.0, 30.0), t_snap_every=2500, float_stride=7,
+                 note="config.dt = 2 us")
+
     # F12 — the modules' public getters over a grid (ignition.py:348-384, material.py:176-205)
     if not only or only in "f12_module_getters":
         env = ref_harness.quiet(wedm.WireEDMEnv)
