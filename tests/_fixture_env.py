@@ -71,6 +71,11 @@ def env_from_fixture(fx, n, *, device, backend=None):
     m = fx.meta
     mods = m["modules"]
     kw = dict(backend=backend) if backend is not None else {}
+    material = m["config"].get("wire_material", "brass")
+    if material != "brass":  # register the fixture's custom material the way a user would
+        from sparc_amd import WireMaterial, get_material_db
+
+        get_material_db()._wire_materials[material] = WireMaterial(name=material, **m["wire_material_constants"])
     env = WireEDMEnv(num_envs=n, device=device, mechanics_control_mode=m["control_mode"],
                      config=EnvironmentConfig(**m["config"]),
                      ignition_params=IgnitionModuleParameters(**mods["ignition"]),

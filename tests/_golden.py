@@ -77,7 +77,9 @@ def config_from_meta(meta) -> orc.Config:
     cfg = orc.default_config()
     for k, v in meta["config"].items():
         if k == "wire_material":
-            assert v == "brass"
+            if v != "brass":  # a material registered in the reference's database: its constants travel in the meta
+                for ck, cv in meta["wire_material_constants"].items():
+                    setattr(cfg, ck, cv)
             continue
         setattr(cfg, k, v)
     for mod, params in meta["modules"].items():

@@ -841,3 +841,13 @@ def test_two_microsecond_physics_step_fixture_on_gpu(golden_dir):
     env = env_from_fixture(fx, 64, device="cuda:0")
     got = run_fixture_through_trace(env, fx, exact_floats=False)
     assert got["time"][:3].tolist() == [2, 4, 6]
+
+
+def test_custom_wire_material_fixture_on_gpu(golden_dir):
+    from tests._fixture_env import env_from_fixture, run_fixture_through_trace
+    from tests._golden import Fixture
+
+    fx = Fixture(golden_dir / "f14_copper_wire_philox_env6.npz")
+    env = env_from_fixture(fx, 64, device="cuda:0")
+    got = run_fixture_through_trace(env, fx, exact_floats=False)
+    assert (got["spark_state"] == 1).sum() > 50

@@ -283,3 +283,15 @@ def test_two_microsecond_physics_step_fixture(golden_dir):
     env = env_from_fixture(fx, 8, device="cpu", backend=LibmOracleBackend)
     got = run_fixture_through_trace(env, fx, exact_floats=True)
     assert got["time"][:3].tolist() == [2, 4, 6] and (got["spark_state"] == 1).sum() > 30
+
+
+def test_custom_wire_material_fixture(golden_dir):
+    """F14: a copper wire registered in the material database (core/material_db.py:67-73) — every
+    derived constant of the wire module changes; oracle-seam run == reference, whole trajectory."""
+    from tests._fixture_env import env_from_fixture, run_fixture_through_trace
+
+    fx = Fixture(golden_dir / "f14_copper_wire_philox_env6.npz")
+    env = env_from_fixture(fx, 8, device="cpu", backend=LibmOracleBackend)
+    assert env.wire_material.name == "copper" and env.wire_material.thermal_conductivity == 401
+    got = run_fixture_through_trace(env, fx, exact_floats=True)
+    assert (got["spark_state"] == 1).sum() > 50

@@ -264,6 +264,7 @@ def run_scenario(name, *, n_steps, seed=0, config=None, control_mode="position",
         "n_seg": int(env.wire.n_segments), "zone": [int(env.wire.zone_start), int(env.wire.zone_end)],
         "contacts": [int(env.wire.contact_bottom_idx), int(env.wire.contact_top_idx)],
         "raised": raised, "numpy": np.__version__,
+        "wire_material_constants": {k: v for k, v in vars(env.wire.wire_material).items() if k != "name"},
         "float_fields": FLOAT_FIELDS, "int_fields": INT_FIELDS,
     }
     arrays = {
@@ -537,6 +538,19 @@ def main():
                  state_init={"workpiece_position": 24.0, "wire_position": 10.0, "target_position": 5000.0},
                  action=make_action(0.1, 80.0, 9, 3.0, 30.0), t_snap_every=2500, float_stride=7,
                  note="config.dt = 2 us")
+
+    # F14 — a wire material other than the built-in brass, registered in the material database
+    copper = dict(density=8960, specific_heat=385, thermal_conductivity=401, electrical_resistivity=1.68e-8,
+                  temperature_coefficient=0.00393, melting_point=1358, breaking_temperature=1600)
+    if not only or only in "f14_copper_wire_philox_env6":
+        from wedm.core.material_db import WireMaterial as RefWireMaterial, get_material_db as ref_db
+
+        ref_db()._wire_materials["copper"] = RefWireMaterial(name="copper", **copper)
+    run_scenario("f14_copper_wire_philox_env6", n_steps=2500, seed=91, rng="philox", env_id=6,
+                 config={"wire_material": "copper", "wire_diameter": 0.25},
+                 state_init={"workpiece_position": 22.0, "wire_position": 10.0, "target_position": 5000.0},
+                 action=make_action(0.1, 80.0, 15, 3.0, 25.0), t_snap_every=2500, float_stride=7,
+                 note="custom wire material through the material database")
 
     # F12 — the modules' public getters over a grid (ignition.py:348-384, material.py:176-205)
     if not only or only in "f12_module_getters":
