@@ -441,9 +441,13 @@ static double get_on_time(const wedm_oracle_env* e) {
 static double get_off_time(const wedm_oracle_env* e) {
     return e->off_time != 0.0 ? e->off_time : e->c.default_off_time;
 }
-/* ignition.py:98-113: None or unknown mode -> default mode's current */
+/* ignition.py:98-113 with the cache of ignition.py:79-81.  A fresh module starts with
+ * `_cached_current_mode = None, _cached_current_value = 60.0`, so `current_mode is None` (before
+ * the first control-step latch) HITS the cache and yields 60 A whatever `default_current_mode`
+ * says; that parameter only serves modes that are not in currents.json. */
 static double get_peak_current(const wedm_oracle_env* e) {
     int m = e->current_mode;
+    if (m == 0) return 60.0;
     if (m < 1 || m > WEDM_MAX_MODE) return e->c.default_current;
     return e->c.mode_current[m];
 }

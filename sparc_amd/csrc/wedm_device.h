@@ -288,7 +288,11 @@ __device__ __forceinline__ const T* opaque(const T* p) {
 #define WEDM_COLD_GEOM_I32(cold, hot, row, field) \
     ((hot).per_env_geometry ? (cold)->g.i32[(int64_t)(row) * (cold)->s.stride + e] : opaque((cold)->p)->field)
 
+// ignition.py:98-113 with the module's initial cache (ignition.py:79-81): mode None (0, before the
+// first latch) hits the fresh cache and yields 60 A whatever `default_current_mode` is; that
+// parameter only serves modes outside currents.json.
 __device__ __forceinline__ double peak_current(const ColdRef cold, int32_t mode) {
+    if (mode == 0) return 60.0;
     return (mode >= 1 && mode <= WEDM_MAX_MODE) ? cold->tb.mode_current[mode] : opaque(cold->p)->default_current;
 }
 

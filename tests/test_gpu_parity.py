@@ -851,3 +851,13 @@ def test_custom_wire_material_fixture_on_gpu(golden_dir):
     env = env_from_fixture(fx, 64, device="cuda:0")
     got = run_fixture_through_trace(env, fx, exact_floats=False)
     assert (got["spark_state"] == 1).sum() > 50
+
+
+def test_default_modes_before_the_first_latch_fixture_on_gpu(golden_dir):
+    from tests._fixture_env import env_from_fixture, run_fixture_through_trace
+    from tests._golden import Fixture
+
+    fx = Fixture(golden_dir / "f15_default_mode_philox_env7.npz")
+    env = env_from_fixture(fx, 64, device="cuda:0")
+    got = run_fixture_through_trace(env, fx, exact_floats=False)
+    assert (got["spark_state"][:1000] == 1).sum() > 5

@@ -18,7 +18,7 @@ PHILOX = [f"f3_philox_env{i}" for i in (0, 1, 2, 3, 777, 65535)] + ["f3_philox_c
     f"f8_geometry_{i}" for i in range(4)
 ] + ["f7_gap_controller_philox_env0", "f7_gap_controller_philox_env9", "f7_gap_controller_velocity_philox_env3",
      "f9_voltage_controller_philox_env2", "f9_voltage_controller_velocity_philox_env5",
-     "f10_crater_statistics_philox_env1", "f13_dt2_philox_env4", "f14_copper_wire_philox_env6"] + [f"f11_random_params_{k}" for k in range(8)]
+     "f10_crater_statistics_philox_env1", "f13_dt2_philox_env4", "f14_copper_wire_philox_env6", "f15_default_mode_philox_env7"] + [f"f11_random_params_{k}" for k in range(8)]
 
 
 @pytest.mark.parametrize("name", NATIVE)

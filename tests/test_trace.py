@@ -295,3 +295,17 @@ def test_custom_wire_material_fixture(golden_dir):
     assert env.wire_material.name == "copper" and env.wire_material.thermal_conductivity == 401
     got = run_fixture_through_trace(env, fx, exact_floats=True)
     assert (got["spark_state"] == 1).sum() > 50
+
+
+def test_default_modes_before_the_first_latch_fixture(golden_dir):
+    """F15: until the first control step `state.current_mode` is None.  The reference's ignition
+    module then HITS its freshly initialised cache (`_cached_current_mode = None`, 60 A,
+    ignition.py:79-81) and never consults `default_current_mode` (set to I13 here on purpose); the
+    material module falls back to I1."""
+    from tests._fixture_env import env_from_fixture, run_fixture_through_trace
+
+    fx = Fixture(golden_dir / "f15_default_mode_philox_env7.npz")
+    env = env_from_fixture(fx, 8, device="cpu", backend=LibmOracleBackend)
+    got = run_fixture_through_trace(env, fx, exact_floats=True)
+    early = (got["spark_state"][:1000] == 1)
+    assert early.sum() > 5 and set(np.unique(got["current"][:1000][early]).tolist()) == {60.0}   # not I13's 215 A

@@ -552,6 +552,15 @@ def main():
                  action=make_action(0.1, 80.0, 15, 3.0, 25.0), t_snap_every=2500, float_stride=7,
                  note="custom wire material through the material database")
 
+    # F15 — before the first latch state.current_mode is None: the ignition module's fresh cache answers
+    # 60 A (ignition.py:79-81,98-113; default_current_mode is NOT consulted), material uses "I1"
+    # (material.py:104-105)
+    run_scenario("f15_default_mode_philox_env7", n_steps=1800, seed=92, rng="philox", env_id=7,
+                 ignition={"default_current_mode": "I13"},
+                 state_init={"workpiece_position": 20.0, "wire_position": 10.0, "target_position": 5000.0},
+                 action=make_action(0.1, 90.0, 9, 2.0, 25.0), t_snap_every=1800, float_stride=3,
+                 note="sparks before the first control-step latch use the default modes")
+
     # F12 — the modules' public getters over a grid (ignition.py:348-384, material.py:176-205)
     if not only or only in "f12_module_getters":
         env = ref_harness.quiet(wedm.WireEDMEnv)
