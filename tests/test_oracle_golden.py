@@ -94,7 +94,9 @@ def test_invalid_mode_flags_where_reference_raises(orc, golden_dir):
 def test_portable_math_mode_stays_within_stated_tolerance(orc, golden_dir):
     """PORTABLE math (what the GPU computes) vs the reference: decisions identical,
     float64 state within 1e-12 relative, temperatures within 1e-4 K."""
-    for name in ("f1_config1_native", "f5_debris_short", "f3_philox_env0", "f7_gap_controller"):
+    for name in ("f1_config1_native", "f5_debris_short", "f3_philox_env0", "f7_gap_controller", "f9_voltage_controller_philox_env2",
+                 "f10_crater_statistics_philox_env1", "f13_dt2_philox_env4", "f14_copper_wire_philox_env6",
+                 "f15_default_mode_philox_env7") + tuple(f"f11_random_params_{k}" for k in range(8)):
         fx = Fixture(golden_dir / f"{name}.npz")
         bad, _ = replay(fx, math_mode=orc.MATH_PORTABLE, exact_floats=False, float_rtol=1e-12, T_atol=1e-4)
         assert not bad, name + "\n" + "\n".join(bad[:20])
