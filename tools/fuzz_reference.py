@@ -29,6 +29,7 @@ gg.OUT = Path(tempfile.mkdtemp(prefix="wedm_fuzz_"))
 valid_modes = sorted(int(k[1:]) for k in gg.env_probe_modes())
 failures = 0
 ulp_level = 0
+portable_bad = 0
 for k in range(seed0, seed0 + n_scen):
     rng = np.random.default_rng(777000 + k)
     u = rng.uniform
@@ -77,6 +78,10 @@ for k in range(seed0, seed0 + n_scen):
         print(f"{name}: reference raised {type(exc).__name__}: {exc}")
         continue
     fx = Fixture(gg.OUT / f"{name}.npz")
+    port, _ = replay(fx, math_mode=orc.MATH_PORTABLE, exact_floats=False, float_rtol=1e-12, T_atol=1e-4)
+    if port:   # what the GPU computes: decisions identical, float64 within 1e-12, T within 1e-4 K
+        portable_bad += 1
+        print(f"!! {name}: PORTABLE math outside the stated tolerance: {port[:3]}")
     bad, _ = replay(fx, math_mode=orc.MATH_LIBM)
     if bad:
         # NumPy evaluates np.exp with its own SIMD kernel on AVX512 hosts: 1 ulp off glibc's exp in ~5 % of the
@@ -90,4 +95,4 @@ for k in range(seed0, seed0 + n_scen):
         print(f"!! {name}: {len(bad)} mismatches, first: {bad[:3]}")
         print(f"   config={cfg}\n   ignition={ign}\n   wire={wire}\n   action={gg.action_row(act)} mode={mode} init={init} minit={minit}")
 print(f"{n_scen} scenarios: {n_scen - failures - ulp_level} bit-exact, {ulp_level} equal to ~1e-16 (np.exp), "
-      f"{failures} with real mismatches (recordings in {gg.OUT})")
+      f"{failures} with real mismatches; PORTABLE math outside tolerance in {portable_bad} (recordings in {gg.OUT})")
