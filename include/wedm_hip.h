@@ -35,7 +35,7 @@
 extern "C" {
 #endif
 
-#define WEDM_ABI_VERSION 2
+#define WEDM_ABI_VERSION 3
 
 /* ------------------------------------------------------------------ status */
 typedef enum wedm_status {
@@ -77,6 +77,14 @@ enum wedm_f64_field {
     WEDM_F_H_BASE,             /* WireModule.h_eff_zone outside the zone (float32 value) */
     WEDM_F_H_ZONE,             /* WireModule.h_eff_zone inside the zone  (float32 value) */
     WEDM_F_TMAX,               /* max(T) after the last step (float32 value)    */
+    /* The driver's 1 ms voltage history (experiments/run_simulation.py:258-281) as a running sum:
+     * VOLT_ACC = sum of state.voltage after every step since (and including) the last control
+     * step, in step order; at a control step the kernels publish VOLT_SUM = VOLT_ACC (this step
+     * included) and restart VOLT_ACC from this step's voltage.  With servo_interval = 1000 us
+     * VOLT_SUM is exactly the sum of the <= 1001 samples `create_voltage_controller` averages
+     * (run_simulation.py:262-270): this interval's microseconds plus the previous control step's. */
+    WEDM_F_VOLT_ACC,
+    WEDM_F_VOLT_SUM,
     WEDM_F64_COUNT
 };
 
@@ -208,7 +216,23 @@ typedef struct wedm_params {
     int32_t obs_dim;              /* columns of the obs matrix written at control steps (0 = none) */
     int32_t disable_ignition;     /* 1: skip IgnitionModule.update — the monkeypatch of
                                      experiments/single_spark_animation.py:218-223 (spark forced by the caller) */
-    int32_t reserved0;
+    /* Next-step autoreset inside the launch (the termination of wire_edm.py:172-179 handled without the
+     * host): 1 = an environment that is DONE when a wedm_step begins is re-initialised by that launch
+     * exactly as wedm_reset(mask = its DONE flag, reseed = 0) would (episode + 1, module state cleared,
+     * wire at the spool temperature, statistics and observation zeroed) and then steps on.  Its DONE /
+     * terminal flags therefore stay readable between two launches.                                   */
+    int32_t autoreset;
+    /* 0 = the reward row is never written (the reference's `_calculate_reward` is a TODO returning 0.0,
+     * wire_edm.py:185-187); 1 = every wedm_step writes, for the environments it stepped, the float32
+     * reward of that launch: (workpiece_position after - workpiece_position at the start of the launch
+     * [after an autoreset]) - reward_break_penalty * is_wire_broken.                                  */
+    int32_t reward_mode;
+    /* typing of the wire stencil (wire.py:58-123): 0 = float32 op for op (what the reference computes when
+     * NumPy-2 scalar promotion evaluates it, i.e. without Numba); 1 = float64 expressions rounded at each
+     * float32 store (how Numba types the same lines; without fastmath re-association).                 */
+    int32_t stencil_mode;
+    int32_t reserved0, reserved1;
+    double reward_break_penalty;  /* reward_mode 1 */
 } wedm_params;
 
 typedef struct wedm_state_ptrs {
@@ -219,6 +243,7 @@ typedef struct wedm_state_ptrs {
     float* obs;         /* [obs_dim][stride] or NULL */
     int64_t stride;     /* >= num_envs, multiple of 64 recommended */
     double* stats;      /* [WEDM_STAT_COUNT][stride] or NULL (statistics not kept) */
+    float* reward;      /* [stride] or NULL; written when wedm_params.reward_mode != 0 */
 } wedm_state_ptrs;
 
 typedef struct wedm_geom_ptrs {

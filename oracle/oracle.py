@@ -109,7 +109,7 @@ class Env(C.Structure):
         ("random_short_remaining", _i), ("debris_short_remaining", _i),
         ("diel_last_gap", _d), ("diel_last_density", _d), ("wire_last_flow", _d),
         ("h_base", C.c_float), ("h_zone", C.c_float),
-        ("prev_accel", _d), ("spark_count", _i),
+        ("prev_accel", _d), ("volt_acc", _d), ("volt_sum", _d), ("spark_count", _i),
         ("crater_stat_sum", _d), ("crater_stat_sumsq", _d), ("crater_stat_min", _d), ("crater_stat_max", _d),
         ("tmax", C.c_float),
         ("last_terminated", _i), ("last_ctrl_step", _i), ("last_early_return", _i),
@@ -178,7 +178,7 @@ def lib() -> C.CDLL:
     L.wedm_oracle_reset_batch.restype = _i
     L.wedm_oracle_step_batch.argtypes = [C.POINTER(_abi.Params), C.POINTER(_abi.StatePtrs),
                                          C.POINTER(_abi.GeomPtrs), C.POINTER(_abi.ActionPtrs),
-                                         _i, _i, _i, _i, _i]
+                                         _i, _i, _i, _i, _i, _i]
     L.wedm_oracle_step_batch.restype = _i
     L.wedm_oracle_max_threads.restype = _i
     _lib = L

@@ -416,6 +416,7 @@ void wedm_oracle_reset(wedm_oracle_env* e) {
     e->wire_last_flow = 0.0;                               /* wire.py:224 */
     e->h_base = 0.0f; e->h_zone = 0.0f;                    /* wire.py:205 np.zeros */
     e->prev_accel = 0.0;
+    e->volt_acc = 0.0; e->volt_sum = 0.0;
     e->spark_count = 0;
     e->crater_stat_sum = 0.0; e->crater_stat_sumsq = 0.0; e->crater_stat_min = INFINITY; e->crater_stat_max = -INFINITY;
     e->last_terminated = 0; e->last_ctrl_step = 0; e->last_early_return = 0;
@@ -822,6 +823,20 @@ static void mechanics_update(wedm_oracle_env* e) {
 }
 
 /* ------------------------------------------------------------------ step */
+/* What the reference's driver does with `state.voltage` after every `env.step()`, the terminating one
+ * included (experiments/run_simulation.py:256-270): it appends it to a history that keeps the samples of
+ * the last 1000 us.  As a running sum in step order: `volt_acc` sums every step since (and including) the
+ * last control step; a control step publishes it as `volt_sum` and restarts the accumulator from its own
+ * sample.  With servo_interval = 1000 us `volt_sum` is the sum of exactly the <= 1001 samples
+ * `create_voltage_controller` averages (run_simulation.py:70-72). */
+static void voltage_history_update(wedm_oracle_env* e) {
+    e->volt_acc = e->volt_acc + e->voltage;
+    if (e->last_ctrl_step) {
+        e->volt_sum = e->volt_acc;
+        e->volt_acc = e->voltage;
+    }
+}
+
 /* wire_edm.py:116-157, :162-179 */
 int32_t wedm_oracle_step(wedm_oracle_env* e, const wedm_oracle_action* action) {
     const wedm_oracle_consts* c = &e->c;
@@ -844,6 +859,7 @@ int32_t wedm_oracle_step(wedm_oracle_env* e, const wedm_oracle_action* action) {
     if (e->is_wire_broken) { /* :129-130 early return before mechanics and clocks */
         e->last_early_return = 1;
         e->last_terminated = 1;
+        voltage_history_update(e);
         return 1;
     }
     mechanics_update(e);
@@ -867,6 +883,7 @@ int32_t wedm_oracle_step(wedm_oracle_env* e, const wedm_oracle_action* action) {
         terminated = 1;
     }
     e->last_terminated = terminated;
+    voltage_history_update(e);
     return terminated;
 }
 
@@ -955,6 +972,7 @@ static void gather_env(const wedm_state_ptrs* s, int64_t e, wedm_oracle_env* v) 
     v->target_position = F64(WEDM_F_TARGET_POS); v->wire_unwinding_velocity = F64(WEDM_F_UNWIND_VEL);
     v->h_base = (float)F64(WEDM_F_H_BASE); v->h_zone = (float)F64(WEDM_F_H_ZONE);
     v->tmax = (float)F64(WEDM_F_TMAX);
+    v->volt_acc = F64(WEDM_F_VOLT_ACC); v->volt_sum = F64(WEDM_F_VOLT_SUM);
     v->time = I32(WEDM_I_TIME); v->time_since_servo = I32(WEDM_I_SINCE_SERVO);
     v->time_since_open_voltage = I32(WEDM_I_SINCE_OPEN_V);
     v->time_since_spark_ignition = I32(WEDM_I_SINCE_IGNITION);
@@ -990,6 +1008,7 @@ static void scatter_env(const wedm_state_ptrs* s, int64_t e, const wedm_oracle_e
     F64(WEDM_F_TARGET_POS) = v->target_position; F64(WEDM_F_UNWIND_VEL) = v->wire_unwinding_velocity;
     F64(WEDM_F_H_BASE) = (double)v->h_base; F64(WEDM_F_H_ZONE) = (double)v->h_zone;
     F64(WEDM_F_TMAX) = (double)v->tmax;
+    F64(WEDM_F_VOLT_ACC) = v->volt_acc; F64(WEDM_F_VOLT_SUM) = v->volt_sum;
     I32(WEDM_I_TIME) = v->time; I32(WEDM_I_SINCE_SERVO) = v->time_since_servo;
     I32(WEDM_I_SINCE_OPEN_V) = v->time_since_open_voltage;
     I32(WEDM_I_SINCE_IGNITION) = v->time_since_spark_ignition;
@@ -1033,46 +1052,52 @@ int32_t wedm_oracle_max_threads(void) {
 #endif
 }
 
+/* wedm_reset for one environment: every row at its constructor / reset() value (wire_edm.py:106-114 on a
+ * fresh environment), Philox episode bumped or the stream re-keyed. */
+static void reset_env_rows(const wedm_params* p, const wedm_state_ptrs* s, int64_t e, uint64_t seed, int32_t reseed) {
+    int64_t stride = s->stride;
+    for (int f = 0; f < WEDM_F64_COUNT; ++f) F64(f) = 0.0;
+    int32_t episode = I32(WEDM_I_EPISODE), klo = I32(WEDM_I_KEY_LO), khi = I32(WEDM_I_KEY_HI);
+    for (int f = 0; f < WEDM_I32_COUNT; ++f) I32(f) = 0;
+    for (int f = 0; f < WEDM_I8_COUNT; ++f) I8(f) = 0;
+    if (s->stats) {
+        STAT(WEDM_S_CRATER_SUM) = 0.0; STAT(WEDM_S_CRATER_SUMSQ) = 0.0;
+        STAT(WEDM_S_CRATER_MIN) = INFINITY; STAT(WEDM_S_CRATER_MAX) = -INFINITY;
+    }
+    if (reseed) {
+        I32(WEDM_I_EPISODE) = 0;
+        I32(WEDM_I_KEY_LO) = (int32_t)(uint32_t)seed;
+        I32(WEDM_I_KEY_HI) = (int32_t)(uint32_t)(seed >> 32);
+    } else {
+        I32(WEDM_I_EPISODE) = episode + 1;
+        I32(WEDM_I_KEY_LO) = klo;
+        I32(WEDM_I_KEY_HI) = khi;
+    }
+    F64(WEDM_F_WORKPIECE_POS) = p->initial_gap;
+    F64(WEDM_F_TARGET_POS) = p->target_cutting_distance;
+    F64(WEDM_F_UNWIND_VEL) = 0.2;
+    F64(WEDM_F_SPARK_Y) = NAN;
+    F64(WEDM_F_LAST_GAP) = -1.0;
+    F64(WEDM_F_LAST_DENSITY) = -1.0;
+    F64(WEDM_F_TMAX) = (double)(float)p->spool_T;
+    if (s->reward) s->reward[e] = 0.0f;
+}
+
 int32_t wedm_oracle_reset_batch(const wedm_params* p, const wedm_state_ptrs* s, int32_t num_envs,
                                 const uint8_t* mask, uint64_t seed, int32_t reseed) {
     if (!p || !s || !s->f64 || !s->i32 || !s->i8 || !s->T || num_envs <= 0) return WEDM_ERR_BAD_ARG;
-    int64_t stride = s->stride;
-    int n_seg_rows = p->n_seg;
     for (int64_t e = 0; e < num_envs; ++e) {
         if (mask && !mask[e]) continue;
-        for (int f = 0; f < WEDM_F64_COUNT; ++f) F64(f) = 0.0;
-        int32_t episode = I32(WEDM_I_EPISODE), klo = I32(WEDM_I_KEY_LO), khi = I32(WEDM_I_KEY_HI);
-        for (int f = 0; f < WEDM_I32_COUNT; ++f) I32(f) = 0;
-        for (int f = 0; f < WEDM_I8_COUNT; ++f) I8(f) = 0;
-        if (s->stats) {
-            STAT(WEDM_S_CRATER_SUM) = 0.0; STAT(WEDM_S_CRATER_SUMSQ) = 0.0;
-            STAT(WEDM_S_CRATER_MIN) = INFINITY; STAT(WEDM_S_CRATER_MAX) = -INFINITY;
-        }
-        if (reseed) {
-            I32(WEDM_I_EPISODE) = 0;
-            I32(WEDM_I_KEY_LO) = (int32_t)(uint32_t)seed;
-            I32(WEDM_I_KEY_HI) = (int32_t)(uint32_t)(seed >> 32);
-        } else {
-            I32(WEDM_I_EPISODE) = episode + 1;
-            I32(WEDM_I_KEY_LO) = klo;
-            I32(WEDM_I_KEY_HI) = khi;
-        }
-        F64(WEDM_F_WORKPIECE_POS) = p->initial_gap;
-        F64(WEDM_F_TARGET_POS) = p->target_cutting_distance;
-        F64(WEDM_F_UNWIND_VEL) = 0.2;
-        F64(WEDM_F_SPARK_Y) = NAN;
-        F64(WEDM_F_LAST_GAP) = -1.0;
-        F64(WEDM_F_LAST_DENSITY) = -1.0;
-        F64(WEDM_F_TMAX) = (double)(float)p->spool_T;
-        (void)n_seg_rows;
+        reset_env_rows(p, s, e, seed, reseed);
     }
     return WEDM_OK;
 }
 
 int32_t wedm_oracle_step_batch(const wedm_params* p, const wedm_state_ptrs* s, const wedm_geom_ptrs* g,
-                               const wedm_action_ptrs* a, int32_t num_envs, int32_t n_substeps,
+                               const wedm_action_ptrs* a, int32_t num_envs, int32_t n_seg_max, int32_t n_substeps,
                                int32_t math_mode, int32_t stencil_mode, int32_t n_threads) {
-    if (!p || !s || !a || num_envs <= 0 || n_substeps < 0) return WEDM_ERR_BAD_ARG;
+    if (!p || !s || !a || num_envs <= 0 || n_substeps < 0 || n_seg_max < 1) return WEDM_ERR_BAD_ARG;
+    if (n_substeps == 0) return WEDM_OK;
     if (p->per_env_geometry && (!g || !g->f64 || !g->i32)) return WEDM_ERR_BAD_ARG;
     int64_t stride = s->stride;
     int bad = 0;
@@ -1092,7 +1117,15 @@ int32_t wedm_oracle_step_batch(const wedm_params* p, const wedm_state_ptrs* s, c
 #pragma omp for schedule(static)
 #endif
         for (int64_t e = 0; e < num_envs; ++e) {
-            if (I8(WEDM_B_DONE)) continue;
+            if (I8(WEDM_B_DONE)) {
+                if (!p->autoreset) continue;
+                /* wedm_params.autoreset: next-step autoreset inside the call = wedm_reset(mask = DONE, reseed = 0)
+                 * for this environment (all n_seg_max wire rows at the spool temperature, observation zeroed) */
+                reset_env_rows(p, s, e, 0, 0);
+                for (int i = 0; i < n_seg_max; ++i) s->T[(int64_t)i * stride + e] = (float)p->spool_T;
+                if (s->obs)
+                    for (int q = 0; q < p->obs_dim; ++q) s->obs[(int64_t)q * stride + e] = 0.0f;
+            }
             if (p->per_env_geometry) apply_geometry(g, stride, e, &v->c);
             if (v->c.n_seg > WEDM_ORACLE_MAX_SEG || v->c.n_seg < 1) { bad = 1; continue; }
             gather_env(s, e, v);
@@ -1100,10 +1133,15 @@ int32_t wedm_oracle_step_batch(const wedm_params* p, const wedm_state_ptrs* s, c
             wedm_oracle_action act = {a->servo[e], a->target_voltage[e], a->on_time[e], a->off_time[e],
                                       a->current_mode[e]};
             int done = 0;
+            const double wp0 = v->workpiece_position;
             for (int k = 0; k < n_substeps && !done; ++k) {
                 done = wedm_oracle_step(v, &act);
                 if (v->last_ctrl_step) write_obs(p, s, e, v);
             }
+            /* wedm_params.reward_mode 1: the launch's progress reward (the reference's is a TODO, wire_edm.py:185-187) */
+            if (p->reward_mode && s->reward)
+                s->reward[e] = (float)(v->workpiece_position - wp0) -
+                               (float)p->reward_break_penalty * (v->is_wire_broken ? 1.0f : 0.0f);
             scatter_env(s, e, v, done);
         }
         free(v);

@@ -151,6 +151,9 @@ typedef struct wedm_oracle_env {
     double wire_last_flow;                                  /* wire.py:224 */
     float h_base, h_zone;                                   /* wire.py:205 (two distinct values) */
     double prev_accel;                                      /* mechanics.py:60 */
+    /* the driver's 1 ms voltage history as a running sum (experiments/run_simulation.py:258-281;
+     * rows WEDM_F_VOLT_ACC / WEDM_F_VOLT_SUM of include/wedm_hip.h) */
+    double volt_acc, volt_sum;
     int32_t spark_count;                                    /* len(crater_volumes_um3) */
     /* running statistics of crater_volumes_um3 (material.py:207-227): sum, sum of squares, min, max */
     double crater_stat_sum, crater_stat_sumsq, crater_stat_min, crater_stat_max;
@@ -193,7 +196,7 @@ double wedm_oracle_py_floordiv(double vx, double wx);
 int32_t wedm_oracle_reset_batch(const wedm_params* p, const wedm_state_ptrs* s, int32_t num_envs,
                                 const uint8_t* mask, uint64_t seed, int32_t reseed);
 int32_t wedm_oracle_step_batch(const wedm_params* p, const wedm_state_ptrs* s, const wedm_geom_ptrs* g,
-                               const wedm_action_ptrs* a, int32_t num_envs, int32_t n_substeps,
+                               const wedm_action_ptrs* a, int32_t num_envs, int32_t n_seg_max, int32_t n_substeps,
                                int32_t math_mode, int32_t stencil_mode, int32_t n_threads);
 int32_t wedm_oracle_max_threads(void);
 int64_t wedm_oracle_sizeof(int32_t which);

@@ -1,4 +1,4 @@
-"""ctypes mirror of ``include/wedm_hip.h`` (ABI version 1).
+"""ctypes mirror of ``include/wedm_hip.h`` (ABI version = ``ABI_VERSION`` below, cross-checked against the library by the loader).
 
 Pure declarations — no library is loaded here, so this module imports on a
 GPU-less box.  Field order and types must match the header exactly; the loader
@@ -9,7 +9,7 @@ from __future__ import annotations
 import ctypes as C
 import enum
 
-ABI_VERSION = 2
+ABI_VERSION = 3
 MAX_MODE = 19
 
 # status codes -----------------------------------------------------------------
@@ -59,9 +59,11 @@ class F64(enum.IntEnum):
     H_BASE = 21
     H_ZONE = 22
     TMAX = 23
+    VOLT_ACC = 24
+    VOLT_SUM = 25
 
 
-F64_COUNT = 24
+F64_COUNT = 26
 
 
 class I32(enum.IntEnum):
@@ -179,7 +181,9 @@ class Params(C.Structure):
         ("mode_current", _tab), ("crater_mean", _tab), ("crater_std", _tab), ("crater_depth", _tab),
         ("crater_valid", _itab),
         ("env_id_offset", C.c_uint32), ("obs_dim", _i),
-        ("disable_ignition", _i), ("reserved0", _i),
+        ("disable_ignition", _i), ("autoreset", _i), ("reward_mode", _i), ("stencil_mode", _i),
+        ("reserved0", _i), ("reserved1", _i),
+        ("reward_break_penalty", _d),
     ]
 
 
@@ -188,7 +192,7 @@ class StatePtrs(C.Structure):
 
     _fields_ = [
         ("f64", C.c_void_p), ("i32", C.c_void_p), ("i8", C.c_void_p), ("T", C.c_void_p),
-        ("obs", C.c_void_p), ("stride", C.c_int64), ("stats", C.c_void_p),
+        ("obs", C.c_void_p), ("stride", C.c_int64), ("stats", C.c_void_p), ("reward", C.c_void_p),
     ]
 
 

@@ -81,6 +81,17 @@ EXPORTS = (
 )
 
 
+class _NoGuard:
+    def __enter__(self):
+        return None
+
+    def __exit__(self, *exc):
+        return False
+
+
+_NO_GUARD = _NoGuard()
+
+
 class HipBackend:
     """Thin owner of one ``wedm_ctx``.  All memory stays with the caller (torch)."""
 
@@ -122,11 +133,23 @@ class HipBackend:
     def bind_geometry(self, ptrs: _abi.GeomPtrs) -> None:
         self._check(self._L.wedm_bind_geometry(self._ctx, C.byref(ptrs)))
 
+    def _on_device(self):
+        """The library launches on whatever device is current and refuses a handle of another one
+        (wedm_step / wedm_reset return WEDM_ERR_BAD_ARG): make this environment's device current
+        for the call when it is not (an environment on cuda:1 in a process whose current device is
+        cuda:0).  The common case — already current — costs one integer compare."""
+        torch = self._torch
+        if torch.cuda.current_device() == self.device.index:
+            return _NO_GUARD
+        return torch.cuda.device(self.device)
+
     def reset(self, mask_ptr, seed: int, reseed: bool) -> None:
-        self._check(self._L.wedm_reset(self._ctx, mask_ptr, seed & (2**64 - 1), 1 if reseed else 0, self._stream()))
+        with self._on_device():
+            self._check(self._L.wedm_reset(self._ctx, mask_ptr, seed & (2**64 - 1), 1 if reseed else 0, self._stream()))
 
     def step(self, n_substeps: int, action: _abi.ActionPtrs) -> None:
-        self._check(self._L.wedm_step(self._ctx, n_substeps, C.byref(action), self._stream()))
+        with self._on_device():
+            self._check(self._L.wedm_step(self._ctx, n_substeps, C.byref(action), self._stream()))
 
     def bind_trace(self, desc) -> None:
         """`desc` is an `_abi.TraceDesc` or None (unbind)."""

@@ -93,7 +93,8 @@ def build_params(config: EnvironmentConfig, control_mode: str, ignition: Ignitio
                  wire: WireModuleParameters, material_params: MaterialModuleParameters,
                  dielectric: DielectricModuleParameters, mechanics: MechanicsModuleParameters,
                  material: WireMaterial, *, geometry: Optional[WireGeometry], env_id_offset: int = 0,
-                 obs_dim: int = _abi.OBS_DIM, disable_ignition: bool = False) -> _abi.Params:
+                 obs_dim: int = _abi.OBS_DIM, disable_ignition: bool = False, autoreset: bool = False,
+                 reward_mode: int = 0, reward_break_penalty: float = 10.0, stencil_mode: int = 0) -> _abi.Params:
     """Fill ``struct wedm_params``.  ``geometry=None`` means per-environment rows."""
     p = _abi.Params()
     p.servo_interval = int(config.servo_interval)
@@ -166,6 +167,10 @@ def build_params(config: EnvironmentConfig, control_mode: str, ignition: Ignitio
     p.env_id_offset = int(env_id_offset) & 0xFFFFFFFF
     p.obs_dim = int(obs_dim)
     p.disable_ignition = 1 if disable_ignition else 0
+    p.autoreset = 1 if autoreset else 0
+    p.reward_mode = int(reward_mode)
+    p.stencil_mode = int(stencil_mode)
+    p.reward_break_penalty = float(reward_break_penalty)
     return p
 
 

@@ -32,6 +32,8 @@ _FIELDS = {
     "prev_accel": ("f64", F64.PREV_ACCEL), "dielectric_last_gap": ("f64", F64.LAST_GAP),
     "dielectric_last_density": ("f64", F64.LAST_DENSITY), "wire_last_flow": ("f64", F64.WIRE_LAST_FLOW),
     "h_eff_base": ("f64", F64.H_BASE), "h_eff_zone": ("f64", F64.H_ZONE),
+    # the driver's 1 ms voltage history as running sums (run_simulation.py:258-281; include/wedm_hip.h)
+    "voltage_sum_since_control_step": ("f64", F64.VOLT_ACC), "voltage_sum_at_control_step": ("f64", F64.VOLT_SUM),
     "time": ("i32", I32.TIME), "time_since_servo": ("i32", I32.SINCE_SERVO),
     "time_since_open_voltage": ("i32", I32.SINCE_OPEN_V),
     "time_since_spark_ignition": ("i32", I32.SINCE_IGNITION),
@@ -63,6 +65,8 @@ class BatchedEDMState:
         object.__setattr__(self, "obs", torch.zeros((max(obs_dim, 1), stride), dtype=torch.float32, **kw))
         # running statistics the kernels accumulate (material.py:207-227)
         object.__setattr__(self, "stats", torch.zeros((_abi.STAT_COUNT, stride), dtype=torch.float64, **kw))
+        # per-launch reward written by the kernels when wedm_params.reward_mode != 0
+        object.__setattr__(self, "reward", torch.zeros((1, stride), dtype=torch.float32, **kw))
         # read-only attributes computed on access (registered by the environment):
         # dielectric_flow_rate (dielectric.py:160-162), wire_average_temperature (wire.py:339-347)
         object.__setattr__(self, "derived", {})
@@ -111,16 +115,17 @@ class BatchedEDMState:
 
     def pointers(self, with_obs: bool) -> _abi.StatePtrs:
         return _abi.StatePtrs(self.f64.data_ptr(), self.i32.data_ptr(), self.i8.data_ptr(), self.T.data_ptr(),
-                              self.obs.data_ptr() if with_obs else None, self.stride, self.stats.data_ptr())
+                              self.obs.data_ptr() if with_obs else None, self.stride, self.stats.data_ptr(),
+                              self.reward.data_ptr())
 
     def field_names(self):
         return tuple(_FIELDS)
 
     def clone_blocks(self):
         """Host copies of the raw blocks (used by checkpointing and by the parity tests)."""
-        return {k: getattr(self, k).detach().cpu().clone() for k in ("f64", "i32", "i8", "T", "obs", "stats")}
+        return {k: getattr(self, k).detach().cpu().clone() for k in ("f64", "i32", "i8", "T", "obs", "stats", "reward")}
 
     def load_blocks(self, blocks) -> None:
-        for k in ("f64", "i32", "i8", "T", "obs", "stats"):
+        for k in ("f64", "i32", "i8", "T", "obs", "stats", "reward"):
             if k in blocks:
                 getattr(self, k).copy_(blocks[k].to(self.device))

@@ -164,6 +164,7 @@ struct Env {
     double V, I, y, last_crater, cavity;
     double tdelta, tvolt, on, off, tpos, unwind;
     double ipk;  // peak current of the latched mode (ignition.py:98-113); derived, not stored
+    double vacc; // running voltage sum since the last control step (row WEDM_F_VOLT_ACC)
     float h_base, h_zone, tmax;
     int32_t time, tss, tsov, tsi, tse, dur, rnd_rem, deb_rem, tcrit, mode, episode, sparks;
     uint32_t key0, key1;
@@ -184,6 +185,7 @@ struct Hot {
     double dt_s, damping_coeff, stiffness_coeff, omega_n, max_acceleration, max_jerk_dt, max_speed;
     float spool, tref, alpha, tdiel, tcrit, tbreak;
     int32_t servo_interval, dt_us, control_mode, disable_ignition, has_random_short, per_env_geometry;
+    int32_t autoreset, reward_mode;
     uint32_t env_id_offset;
     int32_t n_seg;  // uniform geometry only
 };
@@ -310,7 +312,7 @@ __device__ __forceinline__ void load_env(const ColdRef cold, int64_t e, Env& v) 
     v.cavity = *WEDM_ROW(s.f64, WEDM_F_CAVITY); v.tdelta = *WEDM_ROW(s.f64, WEDM_F_TARGET_DELTA);
     v.tvolt = *WEDM_ROW(s.f64, WEDM_F_TARGET_VOLTAGE); v.on = *WEDM_ROW(s.f64, WEDM_F_ON_TIME);
     v.off = *WEDM_ROW(s.f64, WEDM_F_OFF_TIME); v.tpos = *WEDM_ROW(s.f64, WEDM_F_TARGET_POS);
-    v.unwind = *WEDM_ROW(s.f64, WEDM_F_UNWIND_VEL);
+    v.unwind = *WEDM_ROW(s.f64, WEDM_F_UNWIND_VEL); v.vacc = *WEDM_ROW(s.f64, WEDM_F_VOLT_ACC);
     v.h_base = (float)*WEDM_ROW(s.f64, WEDM_F_H_BASE); v.h_zone = (float)*WEDM_ROW(s.f64, WEDM_F_H_ZONE);
     v.tmax = (float)*WEDM_ROW(s.f64, WEDM_F_TMAX);
     v.time = *WEDM_ROW(s.i32, WEDM_I_TIME); v.tss = *WEDM_ROW(s.i32, WEDM_I_SINCE_SERVO);
@@ -341,7 +343,7 @@ __device__ __forceinline__ void store_env(const ColdRef cold, int64_t e, const E
     *WEDM_ROW(s.f64, WEDM_F_SPARK_Y) = v.y; *WEDM_ROW(s.f64, WEDM_F_LAST_CRATER) = v.last_crater;
     *WEDM_ROW(s.f64, WEDM_F_CAVITY) = v.cavity; *WEDM_ROW(s.f64, WEDM_F_TARGET_DELTA) = v.tdelta;
     *WEDM_ROW(s.f64, WEDM_F_TARGET_VOLTAGE) = v.tvolt; *WEDM_ROW(s.f64, WEDM_F_ON_TIME) = v.on;
-    *WEDM_ROW(s.f64, WEDM_F_OFF_TIME) = v.off;
+    *WEDM_ROW(s.f64, WEDM_F_OFF_TIME) = v.off; *WEDM_ROW(s.f64, WEDM_F_VOLT_ACC) = v.vacc;
     *WEDM_ROW(s.f64, WEDM_F_H_BASE) = (double)v.h_base; *WEDM_ROW(s.f64, WEDM_F_H_ZONE) = (double)v.h_zone;
     *WEDM_ROW(s.f64, WEDM_F_TMAX) = (double)v.tmax;
     *WEDM_ROW(s.i32, WEDM_I_TIME) = v.time; *WEDM_ROW(s.i32, WEDM_I_SINCE_SERVO) = v.tss;
@@ -354,6 +356,87 @@ __device__ __forceinline__ void store_env(const ColdRef cold, int64_t e, const E
     *WEDM_ROW(s.i8, WEDM_B_WIRE_BROKEN) = (int8_t)v.broken; *WEDM_ROW(s.i8, WEDM_B_TARGET_REACHED) = (int8_t)v.reached;
     *WEDM_ROW(s.i8, WEDM_B_DONE) = (int8_t)v.done; *WEDM_ROW(s.i8, WEDM_B_CTRL_STEP) = (int8_t)v.ctrl;
     *WEDM_ROW(s.i8, WEDM_B_ERROR) = (int8_t)v.err;
+}
+
+// ---- single-microsecond launches (wedm_step_split2): the state crosses HBM once per microsecond, so
+// only the rows a microsecond READS are loaded and only the rows it can have CHANGED are stored.
+// Write-only rows (assigned by every step before any use): last_crater, cavity, tmax, the control-step
+// flag; with the ignition module enabled also current and is_short_circuit.
+__device__ __forceinline__ void load_env_inputs(const ColdRef cold, int64_t e, Env& v, bool ignition_on) {
+    const ColdPtr c = cold.get();
+    const int64_t stride = c->s.stride;
+    const struct { const double* f64; const int32_t* i32; const int8_t* i8; } s{c->s.f64, c->s.i32, c->s.i8};
+    v.wp = *WEDM_ROW(s.f64, WEDM_F_WORKPIECE_POS); v.x = *WEDM_ROW(s.f64, WEDM_F_WIRE_POS);
+    v.v = *WEDM_ROW(s.f64, WEDM_F_WIRE_VEL); v.prev_a = *WEDM_ROW(s.f64, WEDM_F_PREV_ACCEL);
+    v.debris = *WEDM_ROW(s.f64, WEDM_F_DEBRIS_VOLUME); v.rho = *WEDM_ROW(s.f64, WEDM_F_DEBRIS_DENSITY);
+    v.flow = *WEDM_ROW(s.f64, WEDM_F_FLOW); v.last_gap = *WEDM_ROW(s.f64, WEDM_F_LAST_GAP);
+    v.last_rho = *WEDM_ROW(s.f64, WEDM_F_LAST_DENSITY); v.wire_last_flow = *WEDM_ROW(s.f64, WEDM_F_WIRE_LAST_FLOW);
+    v.V = *WEDM_ROW(s.f64, WEDM_F_VOLTAGE); v.y = *WEDM_ROW(s.f64, WEDM_F_SPARK_Y);
+    v.tdelta = *WEDM_ROW(s.f64, WEDM_F_TARGET_DELTA); v.tvolt = *WEDM_ROW(s.f64, WEDM_F_TARGET_VOLTAGE);
+    v.on = *WEDM_ROW(s.f64, WEDM_F_ON_TIME); v.off = *WEDM_ROW(s.f64, WEDM_F_OFF_TIME);
+    v.tpos = *WEDM_ROW(s.f64, WEDM_F_TARGET_POS); v.unwind = *WEDM_ROW(s.f64, WEDM_F_UNWIND_VEL);
+    v.vacc = *WEDM_ROW(s.f64, WEDM_F_VOLT_ACC);
+    v.h_base = (float)*WEDM_ROW(s.f64, WEDM_F_H_BASE); v.h_zone = (float)*WEDM_ROW(s.f64, WEDM_F_H_ZONE);
+    v.time = *WEDM_ROW(s.i32, WEDM_I_TIME); v.tss = *WEDM_ROW(s.i32, WEDM_I_SINCE_SERVO);
+    v.tsov = *WEDM_ROW(s.i32, WEDM_I_SINCE_OPEN_V); v.tsi = *WEDM_ROW(s.i32, WEDM_I_SINCE_IGNITION);
+    v.tse = *WEDM_ROW(s.i32, WEDM_I_SINCE_SPARK_END); v.dur = *WEDM_ROW(s.i32, WEDM_I_SPARK_DUR);
+    v.rnd_rem = *WEDM_ROW(s.i32, WEDM_I_RANDOM_SHORT_REM); v.deb_rem = *WEDM_ROW(s.i32, WEDM_I_DEBRIS_SHORT_REM);
+    v.tcrit = *WEDM_ROW(s.i32, WEDM_I_TIME_CRITICAL); v.mode = *WEDM_ROW(s.i32, WEDM_I_CURRENT_MODE);
+    v.episode = *WEDM_ROW(s.i32, WEDM_I_EPISODE);
+    v.key0 = (uint32_t)*WEDM_ROW(s.i32, WEDM_I_KEY_LO); v.key1 = (uint32_t)*WEDM_ROW(s.i32, WEDM_I_KEY_HI);
+    v.sparks = *WEDM_ROW(s.i32, WEDM_I_SPARK_COUNT);
+    v.state = *WEDM_ROW(s.i8, WEDM_B_SPARK_STATE);
+    v.broken = *WEDM_ROW(s.i8, WEDM_B_WIRE_BROKEN); v.reached = *WEDM_ROW(s.i8, WEDM_B_TARGET_REACHED);
+    v.done = *WEDM_ROW(s.i8, WEDM_B_DONE); v.err = *WEDM_ROW(s.i8, WEDM_B_ERROR);
+    v.I = 0.0; v.is_short = 0;
+    if (!ignition_on) {  // the caller forces the spark (single_spark_animation.py): both are inputs then
+        v.I = *WEDM_ROW(s.f64, WEDM_F_CURRENT);
+        v.is_short = *WEDM_ROW(s.i8, WEDM_B_IS_SHORT);
+    }
+    v.last_crater = 0.0; v.cavity = 0.0; v.tmax = 0.0f; v.ctrl = 0;
+    v.ipk = 0.0;
+}
+
+// Rows that are final once the scalar prelude has run (stored while the wire is being walked).
+// `quiet_only`: every step of the launch took quiet_prelude() for the whole wave, which never assigns the
+// second group (workpiece position, dielectric / convection caches, latched action, short timers,
+// spark count, error flag): those rows are left alone.
+__device__ __forceinline__ void store_env_after_prelude(const ColdRef cold, int64_t e, const Env& v, bool quiet_only) {
+    const ColdPtr c = cold.get();
+    const int64_t stride = c->s.stride;
+    const struct { double* f64; int32_t* i32; int8_t* i8; } s{c->s.f64, c->s.i32, c->s.i8};
+    *WEDM_ROW(s.f64, WEDM_F_DEBRIS_VOLUME) = v.debris; *WEDM_ROW(s.f64, WEDM_F_DEBRIS_DENSITY) = v.rho;
+    *WEDM_ROW(s.f64, WEDM_F_VOLTAGE) = v.V; *WEDM_ROW(s.f64, WEDM_F_CURRENT) = v.I;
+    *WEDM_ROW(s.f64, WEDM_F_SPARK_Y) = v.y; *WEDM_ROW(s.f64, WEDM_F_LAST_CRATER) = v.last_crater;
+    *WEDM_ROW(s.f64, WEDM_F_CAVITY) = v.cavity;
+    *WEDM_ROW(s.i32, WEDM_I_SPARK_DUR) = v.dur;
+    *WEDM_ROW(s.i8, WEDM_B_SPARK_STATE) = (int8_t)v.state; *WEDM_ROW(s.i8, WEDM_B_IS_SHORT) = (int8_t)v.is_short;
+    *WEDM_ROW(s.i8, WEDM_B_CTRL_STEP) = (int8_t)v.ctrl;
+    if (quiet_only) return;
+    *WEDM_ROW(s.f64, WEDM_F_WORKPIECE_POS) = v.wp;
+    *WEDM_ROW(s.f64, WEDM_F_FLOW) = v.flow; *WEDM_ROW(s.f64, WEDM_F_LAST_GAP) = v.last_gap;
+    *WEDM_ROW(s.f64, WEDM_F_LAST_DENSITY) = v.last_rho; *WEDM_ROW(s.f64, WEDM_F_WIRE_LAST_FLOW) = v.wire_last_flow;
+    *WEDM_ROW(s.f64, WEDM_F_TARGET_DELTA) = v.tdelta; *WEDM_ROW(s.f64, WEDM_F_TARGET_VOLTAGE) = v.tvolt;
+    *WEDM_ROW(s.f64, WEDM_F_ON_TIME) = v.on; *WEDM_ROW(s.f64, WEDM_F_OFF_TIME) = v.off;
+    *WEDM_ROW(s.f64, WEDM_F_H_BASE) = (double)v.h_base; *WEDM_ROW(s.f64, WEDM_F_H_ZONE) = (double)v.h_zone;
+    *WEDM_ROW(s.i32, WEDM_I_RANDOM_SHORT_REM) = v.rnd_rem; *WEDM_ROW(s.i32, WEDM_I_DEBRIS_SHORT_REM) = v.deb_rem;
+    *WEDM_ROW(s.i32, WEDM_I_CURRENT_MODE) = v.mode; *WEDM_ROW(s.i32, WEDM_I_SPARK_COUNT) = v.sparks;
+    *WEDM_ROW(s.i8, WEDM_B_ERROR) = (int8_t)v.err;
+}
+
+// Rows the scalar epilogue assigns (mechanics, clocks, temperature monitor, termination, voltage sum).
+__device__ __forceinline__ void store_env_after_epilogue(const ColdRef cold, int64_t e, const Env& v) {
+    const ColdPtr c = cold.get();
+    const int64_t stride = c->s.stride;
+    const struct { double* f64; int32_t* i32; int8_t* i8; } s{c->s.f64, c->s.i32, c->s.i8};
+    *WEDM_ROW(s.f64, WEDM_F_WIRE_POS) = v.x; *WEDM_ROW(s.f64, WEDM_F_WIRE_VEL) = v.v;
+    *WEDM_ROW(s.f64, WEDM_F_PREV_ACCEL) = v.prev_a; *WEDM_ROW(s.f64, WEDM_F_TMAX) = (double)v.tmax;
+    *WEDM_ROW(s.f64, WEDM_F_VOLT_ACC) = v.vacc;
+    *WEDM_ROW(s.i32, WEDM_I_TIME) = v.time; *WEDM_ROW(s.i32, WEDM_I_SINCE_SERVO) = v.tss;
+    *WEDM_ROW(s.i32, WEDM_I_SINCE_OPEN_V) = v.tsov; *WEDM_ROW(s.i32, WEDM_I_SINCE_IGNITION) = v.tsi;
+    *WEDM_ROW(s.i32, WEDM_I_SINCE_SPARK_END) = v.tse; *WEDM_ROW(s.i32, WEDM_I_TIME_CRITICAL) = v.tcrit;
+    *WEDM_ROW(s.i8, WEDM_B_WIRE_BROKEN) = (int8_t)v.broken; *WEDM_ROW(s.i8, WEDM_B_TARGET_REACHED) = (int8_t)v.reached;
+    *WEDM_ROW(s.i8, WEDM_B_DONE) = (int8_t)v.done;
 }
 
 // ----------------------------------------------------------------- signal trace
@@ -384,6 +467,7 @@ __device__ __forceinline__ double env_f64_row(const Env& v, int row) {
         case WEDM_F_H_BASE: return (double)v.h_base;
         case WEDM_F_H_ZONE: return (double)v.h_zone;
         case WEDM_F_TMAX: return (double)v.tmax;
+        case WEDM_F_VOLT_ACC: return v.vacc;
     }
     return 0.0;
 }
@@ -798,6 +882,9 @@ __device__ __forceinline__ float stencil_cell(int i, int n_seg, float tm1, float
 // ------------------------------------------- scalar epilogue (modules 4b, 5, env)
 // wire.py:376-388, wire_edm.py:129-146,172-179, mechanics.py:79-114
 __device__ __forceinline__ void scalar_epilogue(const Hot& p, Env& s, float tmax) {
+    // the driver appends state.voltage after EVERY step(), the early-return one included
+    // (experiments/run_simulation.py:256-264): running sum in step order
+    s.vacc = s.vacc + s.V;
     s.tmax = tmax;
     if (tmax > p.tcrit) s.tcrit += 1;
     else s.tcrit = 0;
@@ -853,6 +940,64 @@ __device__ __forceinline__ void write_obs(const ColdRef cold, int64_t e, const E
     o[5 * stride] = (float)s.rho;
     o[6 * stride] = (float)s.flow;
     o[7 * stride] = s.tmax;
+}
+
+// Control step (wire_edm.py:117-121): the observation, the interval's voltage sum (row
+// WEDM_F_VOLT_SUM: this step included, plus the previous control step's sample the accumulator was
+// restarted from) and the restart of the accumulator.  Every lane of an environment restarts its
+// replica; only `writer` touches memory.
+__device__ __forceinline__ void control_step_outputs(const ColdRef cold, int64_t e, Env& s, bool writer) {
+    if (writer) {
+        write_obs(cold, e, s);
+        const ColdPtr c = cold.get();
+        c->s.f64[(int64_t)WEDM_F_VOLT_SUM * c->s.stride + e] = s.vacc;
+    }
+    s.vacc = s.V;
+}
+
+// wedm_params.autoreset: what wedm_reset_kernel(mask = DONE, reseed = 0) writes for one environment,
+// applied to the registers at the start of a launch (next-step autoreset).  `writer` also clears the
+// per-environment memory outside the register state (statistics, observation) and stores the rows
+// store_env() never writes.  The caller sets the environment's wire to the spool temperature.
+__device__ __forceinline__ void reinit_env(const ColdRef cold, int64_t e, Env& s, bool writer) {
+    const ColdPtr c = cold.get();
+    const wedm_params* p = opaque(c->p);
+    const int32_t episode = s.episode + 1;
+    const uint32_t k0 = s.key0, k1 = s.key1;
+    const float spool = (float)p->spool_T;
+    s.wp = p->initial_gap; s.x = 0.0; s.v = 0.0; s.prev_a = 0.0;
+    s.debris = 0.0; s.rho = 0.0; s.flow = 0.0; s.last_gap = -1.0; s.last_rho = -1.0; s.wire_last_flow = 0.0;
+    s.V = 0.0; s.I = 0.0; s.y = __builtin_nan(""); s.last_crater = 0.0; s.cavity = 0.0;
+    s.tdelta = 0.0; s.tvolt = 0.0; s.on = 0.0; s.off = 0.0; s.tpos = p->target_cutting_distance; s.unwind = 0.2;
+    s.vacc = 0.0;
+    s.h_base = 0.0f; s.h_zone = 0.0f; s.tmax = spool;
+    s.time = 0; s.tss = 0; s.tsov = 0; s.tsi = 0; s.tse = 0; s.dur = 0; s.rnd_rem = 0; s.deb_rem = 0; s.tcrit = 0;
+    s.mode = 0; s.episode = episode; s.sparks = 0; s.key0 = k0; s.key1 = k1;
+    s.state = 0; s.is_short = 0; s.broken = 0; s.reached = 0; s.done = 0; s.ctrl = 0; s.err = 0;
+    if (writer) {
+        const int64_t stride = c->s.stride;
+        *WEDM_ROW(c->s.f64, WEDM_F_WORKPIECE_POS) = s.wp;   // the reward's "position at the start of the launch"
+        *WEDM_ROW(c->s.f64, WEDM_F_TARGET_POS) = s.tpos;
+        *WEDM_ROW(c->s.f64, WEDM_F_UNWIND_VEL) = s.unwind;
+        *WEDM_ROW(c->s.f64, WEDM_F_VOLT_SUM) = 0.0;
+        *WEDM_ROW(c->s.i32, WEDM_I_EPISODE) = episode;
+        if (c->s.stats) {
+            *WEDM_ROW(c->s.stats, WEDM_S_CRATER_SUM) = 0.0; *WEDM_ROW(c->s.stats, WEDM_S_CRATER_SUMSQ) = 0.0;
+            *WEDM_ROW(c->s.stats, WEDM_S_CRATER_MIN) = __builtin_inf(); *WEDM_ROW(c->s.stats, WEDM_S_CRATER_MAX) = -__builtin_inf();
+        }
+        if (c->s.obs)
+            for (int q = 0; q < p->obs_dim; ++q) c->s.obs[(int64_t)q * stride + e] = 0.0f;
+    }
+}
+
+// wedm_params.reward_mode 1, called by the writer lane right BEFORE store_env(): the workpiece-position
+// row still holds the value the launch started from (reinit_env stored the reset value there).
+__device__ __forceinline__ void write_reward(const ColdRef cold, int64_t e, const Env& s) {
+    const ColdPtr c = cold.get();
+    if (!c->s.reward) return;
+    const double wp0 = c->s.f64[(int64_t)WEDM_F_WORKPIECE_POS * c->s.stride + e];
+    const double pen = opaque(c->p)->reward_break_penalty;
+    c->s.reward[e] = (float)(s.wp - wp0) - (float)pen * (s.broken ? 1.0f : 0.0f);
 }
 
 }  // namespace wedm

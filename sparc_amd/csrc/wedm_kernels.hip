@@ -165,7 +165,7 @@ __device__ __forceinline__ void run_substeps(const KArgs& k, const ColdRef cold,
             Coef c = scalar_prelude(k.hot, cold, g, e, gid, s, ps, true);  // single steps: the quiet test does not pay
             float tmax = stencil_pass(T, g, c, ps, k.hot.spool, k.hot.tref, k.hot.alpha, k.hot.tdiel);
             scalar_epilogue(k.hot, s, tmax);
-            if (s.ctrl) write_obs(cold, e, s);
+            if (s.ctrl) control_step_outputs(cold, e, s, true);
         } else if (!tracing) {
             break;
         }
@@ -181,12 +181,19 @@ __global__ void __launch_bounds__(256) wedm_step_global(const KArgs k) {
     if (e >= k.num_envs) return;
     Env s;
     load_env(cold, e, s);
-    if (s.done && !WEDM_TRACING(k)) return;
+    const bool reinit = s.done && k.hot.autoreset;
+    const bool frozen = s.done && !reinit;  // terminated and not reset: nothing to step
+    if (frozen && !WEDM_TRACING(k)) return;
+    GlobalT T{cold->s.T + e, cold->s.stride};
+    if (reinit) {  // next-step autoreset: wedm_reset for this environment, inside the launch
+        reinit_env(cold, e, s, true);
+        for (int i = 0; i < k.n_seg_max; ++i) T.st(i, k.hot.spool);
+    }
     s.ipk = s.done ? 0.0 : peak_current(cold, s.mode);
     Geom g;
     load_geom(k.hot, cold, e, g);
-    GlobalT T{cold->s.T + e, cold->s.stride};
     run_substeps<TRACE>(k, cold, g, e, k.hot.env_id_offset + (uint32_t)e, s, T);
+    if (k.hot.reward_mode && !frozen) write_reward(cold, e, s);
     store_env(cold, e, s);
 }
 
@@ -245,11 +252,20 @@ __global__ void __launch_bounds__(256) wedm_step_split(const KArgs k) {
     const int i0 = c * C, i1 = (i0 + C < n) ? i0 + C : n;  // this lane's cells [i0, i1) (may be empty)
     GlobalT T{cold->s.T + (live ? e : 0), stride};
 
+    // next-step autoreset: every wave of the block sees the environment's DONE flag
+    const bool reinit = live && k.hot.autoreset && cold->s.i8[(int64_t)WEDM_B_DONE * stride + e] != 0;
+    if (reinit) {  // this lane's rows of the wire (all n_seg_max rows, as wedm_reset does)
+        const int f1 = (i0 + C < k.n_seg_max) ? i0 + C : k.n_seg_max;
+        for (int i = i0; i < f1; ++i) T.st(i, spool);
+    }
     Env s;
     Persist ps{0.0f, 0.0f, 0.0f, 0};
+    bool frozen0 = true;
     if (c == 0) {
         if (live) load_env(cold, e, s);
         else s.done = 1;
+        if (reinit) reinit_env(cold, e, s, true);
+        frozen0 = s.done;
         if (!s.done) {
             s.ipk = peak_current(cold, s.mode);
             init_persist(k.hot, cold, e, s, ps);
@@ -274,6 +290,7 @@ __global__ void __launch_bounds__(256) wedm_step_split(const KArgs k) {
         if (live && i0 < i1) {
             if (i0 > 0) halo_l = T.ld(i0 - 1);
             if (i1 < n) halo_r = T.ld(i1);
+            if (reinit && it == 0) { halo_l = spool; halo_r = spool; }  // the neighbour wave's fill may not have landed
         }
         __syncthreads();
         WEDM_SPLIT_STAMP(2);
@@ -318,7 +335,7 @@ __global__ void __launch_bounds__(256) wedm_step_split(const KArgs k) {
 #pragma unroll
             for (int q = 1; q < WEDM_QL; ++q) m = fmax_gt(m, sh_max[q][el]);
             scalar_epilogue(k.hot, s, m);
-            if (s.ctrl) write_obs(cold, e, s);
+            if (s.ctrl) control_step_outputs(cold, e, s, true);
         }
         if (TRACE && it == trace_next) {  // wave-uniform schedule; T rows of the step just finished
             const wedm_trace_desc& tr = k.trace;
@@ -337,9 +354,216 @@ __global__ void __launch_bounds__(256) wedm_step_split(const KArgs k) {
         if (it + 1 < k.n_substeps) __syncthreads();  // the next step's halo reads follow this step's stores
     }
     WEDM_SPLIT_STAMP(5);
-    if (c == 0 && live) store_env(cold, e, s);
+    if (c == 0 && live) {
+        if (k.hot.reward_mode && !frozen0) write_reward(cold, e, s);
+        store_env(cold, e, s);
+    }
     WEDM_SPLIT_STAMP(6);
     WEDM_SPLIT_STAMP_OUT();
+}
+
+
+// ===================================================== split kernel, second design (1 us / launch)
+// What bounded wedm_step_split: (1) ~210 VGPRs -> two 256-thread blocks per CU, so a 1024-block launch ran
+// in two rounds; (2) inside a block the phases were serial — state loads, then the (general) scalar
+// prelude, and only then the first wire loads — and all resident blocks went through them together, so HBM
+// idled during the scalar phases and the scalar unit during the walks; (3) all 45 state rows crossed HBM in
+// both directions.  Here:
+//   * roles by wave: wave 0 runs the scalar physics of the block's 64 environments and owns no wire; waves
+//     1-3 each own a third of the wire and REQUEST THEIR ROWS FIRST THING (up to 46 rows in flight per lane,
+//     halos included), so the wire streams in while wave 0 loads the state and computes;
+//   * wave 0 tries the wave-uniform quiet prelude first (as the fused kernels do);
+//   * only the rows a microsecond reads are loaded (load_env_inputs), the rows that are final after the
+//     prelude are stored while the walkers work, the rest after the epilogue; a launch whose steps were all
+//     quiet does not store the rows the quiet path cannot change;
+//   * two barriers per microsecond (coefficients out, chunk maxima back).
+// T is updated in place: every OLD value a lane needs from a neighbouring chunk is in its registers before
+// the first barrier, and stores only happen after it.
+#define WEDM_S2_WALKERS 3
+#define WEDM_S2_PRE 44  // cells whose rows are requested before the scalar phase (128 segments: 43 per walker)
+template <bool TRACE, int OCC>
+__global__ void __launch_bounds__(256, OCC) wedm_step_split2(const KArgs k) {
+    const ColdRef cold = kernarg_cold();
+    __shared__ float sh_f[5][64];    // jf, q, conv_base, conv_zone, adv
+    __shared__ int32_t sh_i[4][64];  // joule_on, pidx, adv_on, skip (environment frozen)
+    __shared__ float sh_max[WEDM_S2_WALKERS][64];
+    const int tid = threadIdx.x;
+    // wave index as a SCALAR: the two roles below are two straight programs behind one scalar branch, so the
+    // kernel's register allocation is the larger of the two, not their sum (the walkers' row registers are not
+    // live across the scalar physics).  Both programs execute the same sequence of barriers.
+    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int el = tid & 63;
+    const int64_t e = (int64_t)blockIdx.x * 64 + el;
+    const bool live = e < k.num_envs;
+    const int64_t stride = cold->s.stride;
+    const float spool = k.hot.spool;
+    const bool reinit = live && k.hot.autoreset && cold->s.i8[(int64_t)WEDM_B_DONE * stride + e] != 0;
+    Geom g;
+    load_geom(k.hot, cold, live ? e : 0, g);
+    int trace_next = k.trace_next, trace_slot = k.trace_slot;
+    (void)trace_next; (void)trace_slot;
+
+    if (w == 0) {
+        // ================================================= wave 0: the scalar physics of 64 environments
+        const uint32_t gid = k.hot.env_id_offset + (uint32_t)e;
+        Env s;
+        Persist ps{0.0f, 0.0f, 0.0f, 0};
+        if (live) {
+            if (TRACE) load_env(cold, e, s);  // frozen environments are sampled too: every row
+            else load_env_inputs(cold, e, s, !k.hot.disable_ignition);
+        } else {
+            s.done = 1;
+        }
+        if (reinit) reinit_env(cold, e, s, true);
+        const bool frozen0 = s.done;
+        if (!s.done) {
+            s.ipk = peak_current(cold, s.mode);
+            init_persist(k.hot, cold, e, s, ps);
+        }
+        double wp0 = 0.0;  // workpiece position at the start of the launch (reward)
+        if (k.hot.reward_mode && !frozen0) wp0 = s.wp;
+        bool quiet_only = true;
+        for (int it = 0; it < k.n_substeps; ++it) {
+            const bool last = it + 1 == k.n_substeps;
+            Coef cf{0.0f, 0.0f, 0, -1};
+#ifdef WEDM_S2_NO_QUIET
+            if (true) {
+#else
+            if (!quiet_prelude(k.hot, g, gid, s)) {
+#endif
+                quiet_only = false;
+                if (!s.done) cf = scalar_prelude(k.hot, cold, g, e, gid, s, ps, true);
+            }
+            sh_f[0][el] = cf.jf; sh_f[1][el] = cf.q; sh_f[2][el] = ps.conv_base; sh_f[3][el] = ps.conv_zone;
+            sh_f[4][el] = ps.adv;
+            sh_i[0][el] = cf.joule_on; sh_i[1][el] = cf.pidx; sh_i[2][el] = ps.adv_on; sh_i[3][el] = s.done;
+            __syncthreads();  // (1) coefficients out
+            // rows that are final now leave while the walkers work (last microsecond of the launch only:
+            // before that the state stays in registers)
+            if (last && live && !frozen0) store_env_after_prelude(cold, e, s, quiet_only);
+            __syncthreads();  // (2) chunk maxima back
+            if (!s.done) {
+                float m = sh_max[0][el];
+#pragma unroll
+                for (int q = 1; q < WEDM_S2_WALKERS; ++q) m = fmax_gt(m, sh_max[q][el]);
+                scalar_epilogue(k.hot, s, m);
+                if (s.ctrl) control_step_outputs(cold, e, s, true);
+            }
+            if (TRACE && it == trace_next) {
+                const wedm_trace_desc& tr = k.trace;
+                const int64_t tcol = live ? trace_column(tr, e) : -1;
+                if (tcol >= 0) trace_scalars(tr, tcol, s, trace_slot);
+                trace_next += tr.every;
+                trace_slot = (trace_slot + 1 == tr.capacity) ? 0 : trace_slot + 1;
+            }
+            if (!last) __syncthreads();  // (3) the next microsecond's row requests follow this one's stores
+        }
+        if (live && !frozen0) {
+            if (k.hot.reward_mode && cold->s.reward) {
+                const double pen = opaque(cold->p)->reward_break_penalty;
+                cold->s.reward[e] = (float)(s.wp - wp0) - (float)pen * (s.broken ? 1.0f : 0.0f);
+            }
+            store_env_after_epilogue(cold, e, s);
+        }
+        return;
+    }
+
+    // ===================================================== waves 1-3: one third of the wire each
+    const float tref = k.hot.tref, alpha = k.hot.alpha, tdiel = k.hot.tdiel;
+    const int n = g.n_seg;
+    const int C = (k.n_seg_max + WEDM_S2_WALKERS - 1) / WEDM_S2_WALKERS;
+    const int c = w - 1;
+    const int i0 = c * C;
+    const int i1 = (i0 + C < n) ? i0 + C : n;  // this lane's cells [i0, i1) (may be empty)
+    GlobalT T{cold->s.T + (live ? e : 0), stride};
+    constexpr int PRE = WEDM_S2_PRE;
+    float pre[PRE + 2];   // pre[u] = OLD T[i0 - 1 + u]
+    float halo_r = 0.0f;  // OLD T[i1] when the chunk is longer than PRE cells
+    const bool mine = live && i0 < i1;
+    auto request_rows = [&]() {
+        if (mine) {
+#pragma unroll
+            for (int u = 0; u < PRE + 2; ++u) {
+                int idx = i0 - 1 + u;
+                idx = idx < 0 ? 0 : (idx < n ? idx : n - 1);  // any valid row where the value is not used
+                pre[u] = T.ld(idx);
+            }
+            if (i1 - i0 > PRE && i1 < n) halo_r = T.ld(i1);
+        }
+    };
+    request_rows();  // in flight while wave 0 loads the state and computes
+    if (reinit) {    // next-step autoreset: this lane's rows of the wire, all n_seg_max of them
+        const int f1 = (i0 + C < k.n_seg_max) ? i0 + C : k.n_seg_max;
+        for (int i = i0; i < f1; ++i) T.st(i, spool);
+#pragma unroll
+        for (int u = 0; u < PRE + 2; ++u) pre[u] = spool;
+        halo_r = spool;
+    }
+    for (int it = 0; it < k.n_substeps; ++it) {
+        const bool last = it + 1 == k.n_substeps;
+        if (it > 0) request_rows();  // behind barrier (3)
+        __syncthreads();  // (1)
+        const Coef cf{sh_f[0][el], sh_f[1][el], sh_i[0][el], sh_i[1][el]};
+        const Persist pw{sh_f[4][el], sh_f[2][el], sh_f[3][el], sh_i[2][el]};
+        const bool skip = sh_i[3][el] != 0;
+        float tmax = spool;
+        // the chunk origin re-materialised every microsecond: the per-cell zone / contact predicates are
+        // loop-invariant, and hoisted out of the microsecond loop they are ~180 mask pairs held across the
+        // barrier (630 v_writelane + 623 v_readlane of SGPR spills, VGPRs at the cap)
+        int i0s = i0;
+        asm volatile("" : "+s"(i0s));
+        if (mine && !skip) {
+#pragma unroll
+            for (int u = 0; u < PRE; ++u) {  // the cells whose rows were requested up front
+                const int i = i0s + u;
+                if (i < i1) {
+                    const float tn = (i >= 1) ? stencil_cell(i, n, (i == 1) ? spool : pre[u], pre[u + 1], pre[u + 2], g, cf, pw, tref, alpha, tdiel)
+                                              : spool;
+                    T.st(i, tn);
+                    tmax = tn > tmax ? tn : tmax;
+                }
+                if ((u & 3) == 3) __builtin_amdgcn_sched_barrier(0);  // keep the 44 unrolled cells from being interleaved (registers)
+            }
+            if (i1 - i0 > PRE) {  // longer chunks (400-segment wires): the rest in batches of rows all in flight together
+                constexpr int RB = 16;
+                float tm1 = pre[PRE];  // OLD T[i0 + PRE - 1]
+                for (int ib = i0 + PRE; ib < i1; ib += RB) {
+                    float buf[RB + 1];
+#pragma unroll
+                    for (int u = 0; u <= RB; ++u) {
+                        int idx = ib + u;
+                        idx = idx < i1 ? idx : i1 - 1;
+                        buf[u] = T.ld(idx);
+                    }
+#pragma unroll
+                    for (int u = 0; u < RB; ++u) {
+                        const int i = ib + u;
+                        if (i < i1) {
+                            const float tp1 = (i + 1 < i1) ? buf[u + 1] : halo_r;
+                            const float tn = stencil_cell(i, n, tm1, buf[u], tp1, g, cf, pw, tref, alpha, tdiel);
+                            T.st(i, tn);
+                            tmax = tn > tmax ? tn : tmax;
+                            tm1 = buf[u];
+                        }
+                    }
+                }
+            }
+        }
+        sh_max[c][el] = tmax;
+        __syncthreads();  // (2)
+        if (TRACE && it == trace_next) {  // wave-uniform schedule; T rows of the step just finished
+            const wedm_trace_desc& tr = k.trace;
+            const int64_t tcol = live ? trace_column(tr, e) : -1;
+            if (tcol >= 0 && tr.T) {
+                const int64_t tcnt = tr.env_count;
+                float* tT = tr.T + (int64_t)trace_slot * k.n_seg_max * tcnt + tcol;
+                for (int i = i0; i < i1; ++i) tT[(int64_t)i * tcnt] = T.ld(i);
+            }
+            trace_next += tr.every;
+            trace_slot = (trace_slot + 1 == tr.capacity) ? 0 : trace_slot + 1;
+        }
+        if (!last) __syncthreads();  // (3)
+    }
 }
 
 
@@ -387,12 +611,18 @@ __global__ void __launch_bounds__(256, 2) wedm_step_lanes(const KArgs k) {
     load_geom(k.hot, cold, live ? e : 0, g);
     if (live) load_env(cold, e, s);
     else { s.done = 1; s.unwind = 0.0; s.h_base = 0.0f; s.h_zone = 0.0f; }
+    float* col = lds + tid;
+    const bool reinit = live && s.done && k.hot.autoreset;  // next-step autoreset (all L lanes of the environment agree)
+    const bool frozen0 = s.done && !reinit;
+    if (reinit) {
+        reinit_env(cold, e, s, c == 0);
+        for (int j = 0; j < C; ++j) col[j * 256] = k.hot.spool;
+    }
     if (!s.done) {
         s.ipk = peak_current(cold, s.mode);
         init_persist(k.hot, cold, e, s, ps);
     }
     const uint32_t gid = k.hot.env_id_offset + (uint32_t)e;
-    float* col = lds + tid;
     const int cbase = c * C;
     const int n = g.n_seg;  // this lane's environment
     const float spool = k.hot.spool, tref = k.hot.tref, alpha = k.hot.alpha, tdiel = k.hot.tdiel;
@@ -435,7 +665,7 @@ __global__ void __launch_bounds__(256, 2) wedm_step_lanes(const KArgs k) {
         for (int m = 1; m < L; m <<= 1) tmax = fmax_gt(tmax, __shfl_xor(tmax, m));
         if (!s.done) {
             scalar_epilogue(hv, s, tmax);
-            if (s.ctrl && c == 0) write_obs(cold, e, s);
+            if (s.ctrl) control_step_outputs(cold, e, s, c == 0);
         }
         WEDM_TRACE_POINT(k, it, e, s, c == 0,
                          for (int j = 0; j < C && cbase + j < n; ++j) tT[(int64_t)(cbase + j) * tcnt] = col[j * 256]);
@@ -455,7 +685,10 @@ __global__ void __launch_bounds__(256, 2) wedm_step_lanes(const KArgs k) {
             while (ji >= C) { ji -= C; ++ci; }
         }
     }
-    if (live && c == 0) store_env(cold, e, s);
+    if (live && c == 0) {
+        if (k.hot.reward_mode && !frozen0) write_reward(cold, e, s);
+        store_env(cold, e, s);
+    }
 }
 
 // In-kernel phase stamps (diagnostic build -DWEDM_STAMPS only; never in the shipped library).
@@ -620,13 +853,19 @@ __global__ void __launch_bounds__(256, 2) wedm_step_fused(const KArgs k) {
     load_geom(k.hot, cold, live ? e : 0, g);
     if (live) load_env(cold, e, s);
     else { s.done = 1; s.unwind = 0.0; s.h_base = 0.0f; s.h_zone = 0.0f; }
+    float* col = lds + tid;
+    const bool reinit = live && s.done && k.hot.autoreset;  // next-step autoreset (all L lanes of the environment agree)
+    const bool frozen0 = s.done && !reinit;
+    if (reinit) {
+        reinit_env(cold, e, s, c == 0);
+        for (int j = 0; j < C; ++j) col[j * 256] = k.hot.spool;
+    }
     if (!s.done) {
         s.ipk = peak_current(cold, s.mode);
         init_persist(k.hot, cold, e, s, ps);
     }
     const uint32_t gid = k.hot.env_id_offset + (uint32_t)e;
 
-    float* col = lds + tid;
     const int cbase = c * C;
     const float spool = k.hot.spool, tref = k.hot.tref, alpha = k.hot.alpha, tdiel = k.hot.tdiel;
     const int n_tiles = wt->n_tiles;
@@ -823,7 +1062,7 @@ __global__ void __launch_bounds__(256, 2) wedm_step_fused(const KArgs k) {
         WEDM_STAMP(st3);
         if (!s.done) {
             scalar_epilogue(hv, s, tmax);
-            if (s.ctrl && c == 0) write_obs(cold, e, s);
+            if (s.ctrl) control_step_outputs(cold, e, s, c == 0);
         }
         WEDM_TRACE_POINT(k, it, e, s, c == 0,
                          for (int j = 0; j < C && cbase + j < n; ++j) tT[(int64_t)(cbase + j) * tcnt] = col[j * 256]);
@@ -846,7 +1085,10 @@ __global__ void __launch_bounds__(256, 2) wedm_step_fused(const KArgs k) {
             while (ji >= C) { ji -= C; ++ci; }
         }
     }
-    if (live && c == 0) store_env(cold, e, s);
+    if (live && c == 0) {
+        if (k.hot.reward_mode && !frozen0) write_reward(cold, e, s);
+        store_env(cold, e, s);
+    }
 }
 
 
@@ -916,13 +1158,19 @@ __global__ void __launch_bounds__(256, 2) wedm_step_packed(const KArgs k) {
     load_geom(k.hot, cold, live ? e : 0, g);
     if (live) load_env(cold, e, s);
     else { s.done = 1; s.unwind = 0.0; s.h_base = 0.0f; s.h_zone = 0.0f; }
+    float* col = lds + tid;
+    const bool reinit = live && s.done && k.hot.autoreset;  // next-step autoreset (all L lanes of the environment agree)
+    const bool frozen0 = s.done && !reinit;
+    if (reinit) {
+        reinit_env(cold, e, s, c == 0);
+        for (int row = 0; row < R; ++row) col[row * 256] = k.hot.spool;
+    }
     if (!s.done) {
         s.ipk = peak_current(cold, s.mode);
         init_persist(k.hot, cold, e, s, ps);
     }
     const uint32_t gid = k.hot.env_id_offset + (uint32_t)e;
 
-    float* col = lds + tid;
     const int baseA = 2 * c * Cv, baseB = baseA + Cv;  // first wire cell of each virtual chunk
     const float spool = k.hot.spool, tref = k.hot.tref, alpha = k.hot.alpha, tdiel = k.hot.tdiel;
     const int n_tiles = wt->n_tiles;
@@ -1147,7 +1395,7 @@ __global__ void __launch_bounds__(256, 2) wedm_step_packed(const KArgs k) {
         WEDM_STAMP(st3);
         if (!s.done) {
             scalar_epilogue(hv, s, tmax);
-            if (s.ctrl && c == 0) write_obs(cold, e, s);
+            if (s.ctrl) control_step_outputs(cold, e, s, c == 0);
         }
         WEDM_TRACE_POINT(k, it, e, s, c == 0,
                          for (int r = 0; r < Cv; ++r) {
@@ -1173,7 +1421,10 @@ __global__ void __launch_bounds__(256, 2) wedm_step_packed(const KArgs k) {
             while (r >= Cv) { r -= Cv; ++vc; }
         }
     }
-    if (live && c == 0) store_env(cold, e, s);
+    if (live && c == 0) {
+        if (k.hot.reward_mode && !frozen0) write_reward(cold, e, s);
+        store_env(cold, e, s);
+    }
 }
 
 
@@ -1213,6 +1464,7 @@ wedm_reset_kernel(const wedm_params p, const wedm_state_ptrs s, int32_t num_envs
     for (int i = 0; i < n_seg_max; ++i) s.T[(int64_t)i * stride + e] = spool;  // wire.py:264-269
     if (s.obs)
         for (int c = 0; c < p.obs_dim; ++c) s.obs[(int64_t)c * stride + e] = 0.0f;
+    if (s.reward) s.reward[e] = 0.0f;
 }
 
 // Probe of the device math the physics relies on (test hook; see wedm_debug_math).
@@ -1342,6 +1594,19 @@ template <bool TR> static const void* pick_packed(int L) {
         case 4: return (const void*)wedm_step_packed<4, TR>;
         default: return (const void*)wedm_step_packed<8, TR>;
     }
+}
+
+// A handle belongs to the device that was current in wedm_create: its parameter / table / walk buffers
+// live there and its launches must go to a stream of that device.  Launching with another device
+// current would hand hipLaunchKernel a foreign stream (hipErrorInvalidResourceHandle at best).
+static int32_t check_device(wedm_ctx* ctx, const char* who) {
+    int dev = -1;
+    hipError_t e = hipGetDevice(&dev);
+    if (e != hipSuccess) return hip_fail(ctx, e, "hipGetDevice");
+    if (dev != ctx->device)
+        return fail(ctx, WEDM_ERR_BAD_ARG, std::string(who) + ": handle was created on device " + std::to_string(ctx->device) +
+                                               " but device " + std::to_string(dev) + " is current (hipSetDevice first)");
+    return WEDM_OK;
 }
 
 static int lanes_index(int L) { return L == 1 ? 0 : L == 2 ? 1 : L == 4 ? 2 : L == 8 ? 3 : L == 16 ? 4 : -1; }
@@ -1491,6 +1756,8 @@ int32_t wedm_bind_trace(wedm_ctx* ctx, const wedm_trace_desc* desc) {
                    i8_all = (1u << WEDM_I8_COUNT) - 1u;
     if ((desc->f64_mask & ~f64_all) || (desc->i32_mask & ~i32_all) || (desc->i8_mask & ~i8_all))
         return fail(ctx, WEDM_ERR_BAD_ARG, "wedm_bind_trace: mask names a row that does not exist");
+    if (desc->f64_mask & (1u << WEDM_F_VOLT_SUM))
+        return fail(ctx, WEDM_ERR_BAD_ARG, "wedm_bind_trace: VOLT_SUM is published at control steps only (read it from the state block)");
     if ((desc->f64_mask != 0) != (desc->f64 != nullptr) || (desc->i32_mask != 0) != (desc->i32 != nullptr) ||
         (desc->i8_mask != 0) != (desc->i8 != nullptr))
         return fail(ctx, WEDM_ERR_BAD_ARG, "wedm_bind_trace: a buffer must be given exactly for the non-empty masks");
@@ -1509,7 +1776,7 @@ int64_t wedm_trace_samples(wedm_ctx* ctx) { return ctx ? ctx->trace_count : 0; }
 
 int32_t wedm_set_kernel(wedm_ctx* ctx, int32_t variant) {
     if (!ctx) return WEDM_ERR_BAD_ARG;
-    if (variant < 0 || variant > 5) return fail(ctx, WEDM_ERR_BAD_ARG, "wedm_set_kernel: variant must be 0..5");
+    if (variant < 0 || variant > 8) return fail(ctx, WEDM_ERR_BAD_ARG, "wedm_set_kernel: variant must be 0..8");
     ctx->variant = variant;
     return WEDM_OK;
 }
@@ -1535,6 +1802,7 @@ int32_t wedm_set_lanes(wedm_ctx* ctx, int32_t lanes) {
 int32_t wedm_reset(wedm_ctx* ctx, const uint8_t* mask, uint64_t seed, int32_t reseed, void* stream) {
     if (!ctx) return WEDM_ERR_BAD_ARG;
     if (!ctx->bound) return fail(ctx, WEDM_ERR_NOT_BOUND, "wedm_reset: call wedm_bind_state first");
+    if (int32_t rc = check_device(ctx, "wedm_reset")) return rc;
     const int block = 256;
     const int grid = (ctx->num_envs + block - 1) / block;
     hipLaunchKernelGGL(wedm_reset_kernel, dim3(grid), dim3(block), 0, (hipStream_t)stream, ctx->p, ctx->s,
@@ -1554,6 +1822,7 @@ int32_t wedm_step(wedm_ctx* ctx, int32_t n_substeps, const wedm_action_ptrs* act
     if (ctx->p.per_env_geometry && !ctx->geom_bound)
         return fail(ctx, WEDM_ERR_NOT_BOUND, "wedm_step: per_env_geometry set but wedm_bind_geometry not called");
     if (n_substeps == 0) return WEDM_OK;
+    if (int32_t rc = check_device(ctx, "wedm_step")) return rc;
 
     const wedm_params& P = ctx->p;
     KArgs k;
@@ -1575,6 +1844,7 @@ int32_t wedm_step(wedm_ctx* ctx, int32_t n_substeps, const wedm_action_ptrs* act
     h.disable_ignition = P.disable_ignition;
     h.has_random_short = P.random_short_max_probability != 0.0 ? 1 : 0;
     h.per_env_geometry = P.per_env_geometry; h.env_id_offset = P.env_id_offset; h.n_seg = P.n_seg;
+    h.autoreset = P.autoreset; h.reward_mode = (P.reward_mode && ctx->s.reward) ? 1 : 0;
     k.cold.p = ctx->params_dev;
     k.cold.g = ctx->g;
     k.cold.a = *action;
@@ -1681,6 +1951,13 @@ int32_t wedm_step(wedm_ctx* ctx, int32_t n_substeps, const wedm_action_ptrs* act
         grid = (ctx->num_envs + 63) / 64;
         fn = tr ? (const void*)wedm_step_split<true> : (const void*)wedm_step_split<false>;
         std::snprintf(name, sizeof(name), "wedm_step_split<<<%d,256>>> n_sub=%d", grid, n_substeps);
+    } else if (variant >= 6) {
+        grid = (ctx->num_envs + 63) / 64;
+        const int occ = variant - 4;  // 6, 7, 8 -> launch bounds of 2, 3, 4 waves per SIMD
+        fn = occ == 2 ? (tr ? (const void*)wedm_step_split2<true, 2> : (const void*)wedm_step_split2<false, 2>)
+           : occ == 3 ? (tr ? (const void*)wedm_step_split2<true, 3> : (const void*)wedm_step_split2<false, 3>)
+                      : (tr ? (const void*)wedm_step_split2<true, 4> : (const void*)wedm_step_split2<false, 4>);
+        std::snprintf(name, sizeof(name), "wedm_step_split2<%d><<<%d,256>>> n_sub=%d", occ, grid, n_substeps);
     } else if (variant == 2) {
         grid = (ctx->num_envs + 256 / glanes - 1) / (256 / glanes);
         fl = (size_t)((ctx->n_seg_max + glanes - 1) / glanes) * 1024;

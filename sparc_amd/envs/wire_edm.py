@@ -103,8 +103,23 @@ class WireEDMEnv:
         env_id_offset: int = 0,
         disable_ignition: bool = False,
         strict_actions: bool = True,
+        autoreset: bool = False,
+        reward: Optional[str] = None,
+        reward_break_penalty: float = 10.0,
+        stencil_dtype: str = "float32",
         backend: Optional[Callable] = None,
     ):
+        """Beyond the reference's keywords (wire_edm.py:22-34):
+
+        ``autoreset``: next-step autoreset inside the launch — an environment found terminated when a
+        step begins is reset by that kernel launch (as ``reset(options={"mask": done})`` would: next
+        Philox episode, fresh module state) and then stepped; no host round trip.
+        ``reward``: None = the reference's constant 0.0 (its `_calculate_reward` is a TODO,
+        wire_edm.py:185-187); ``"progress"`` = micrometres the workpiece front advanced during the
+        launch minus ``reward_break_penalty`` if the wire broke, written by the kernels (float32).
+        ``stencil_dtype``: ``"float32"`` = the wire stencil exactly as the reference evaluates
+        wire.py:58-123 without Numba (NumPy-2 scalar promotion: float32 op for op); ``"float64"`` =
+        as Numba types the same lines (float64 expressions rounded at each float32 store)."""
         self.render_mode = render_mode
         if mechanics_control_mode not in ["position", "velocity"]:
             raise ValueError(f"mechanics_control_mode must be 'position' or 'velocity', got {mechanics_control_mode}")
@@ -133,6 +148,13 @@ class WireEDMEnv:
         self.np_random = np.random.default_rng()
         self.strict_actions = bool(strict_actions)
         self.env_id_offset = int(env_id_offset)
+        self.autoreset = bool(autoreset)
+        if reward not in (None, "progress"):
+            raise ValueError("reward must be None (the reference's constant 0.0) or 'progress'")
+        self.reward_kind = reward
+        if stencil_dtype not in ("float32", "float64"):
+            raise ValueError("stencil_dtype must be 'float32' or 'float64'")
+        self.stencil_dtype = stencil_dtype
 
         # ---- geometry: uniform (reference behaviour) or one (h, d) pair per environment
         stride = (self.num_envs + 63) // 64 * 64
@@ -155,12 +177,16 @@ class WireEDMEnv:
         self.params = derive.build_params(
             self.config, mechanics_control_mode, self.ignition_params, self.wire_params, self.material_params,
             self.dielectric_params, self.mechanics_params, self.wire_material, geometry=self.geometry,
-            env_id_offset=self.env_id_offset, obs_dim=_abi.OBS_DIM, disable_ignition=disable_ignition)
+            env_id_offset=self.env_id_offset, obs_dim=_abi.OBS_DIM, disable_ignition=disable_ignition,
+            autoreset=self.autoreset, reward_mode=1 if reward == "progress" else 0,
+            reward_break_penalty=reward_break_penalty, stencil_mode=1 if stencil_dtype == "float64" else 0)
 
         # ---- state (caller-owned memory) + backend
         self.state = BatchedEDMState(self.num_envs, self.n_segments, _abi.OBS_DIM, self.device)
+        from ..utils.logger import dielectric_flow_rate
+
         base_flow = float(self.dielectric_params.base_flow_rate)
-        self.state.derived["dielectric_flow_rate"] = lambda: self.state.flow_rate * base_flow  # legacy alias
+        self.state.derived["dielectric_flow_rate"] = lambda: dielectric_flow_rate(self.state.flow_rate, base_flow)
         if not self.per_env_geometry:
             self.state.derived["wire_average_temperature"] = self.zone_mean_temperature
         if backend is None:
@@ -197,12 +223,13 @@ class WireEDMEnv:
         self.single_action_space = self.action_space
         self.single_observation_space = self.observation_space
 
-        self._reward = torch.zeros(self.num_envs, dtype=torch.float32, device=self.device)
+        self._reward = self.state.reward[0, : self.num_envs]  # zeros unless reward="progress" (written by the kernels)
         self._truncated = torch.zeros(self.num_envs, dtype=torch.bool, device=self.device)
         self._mask_buf = None
         self._step_out = None
         self._trace = None
         self._seed = int.from_bytes(os.urandom(8), "little")
+        self.steps_since_reset = 0  # host-side count of physics steps since the last reset of ALL environments
         self._backend.reset(None, self._seed, True)
 
     # ------------------------------------------------------------------ Gym API
@@ -222,6 +249,8 @@ class WireEDMEnv:
             self._backend.reset(mask_ptr, self._seed, True)
         else:
             self._backend.reset(mask_ptr, self._seed, False)
+        if mask_ptr is None:
+            self.steps_since_reset = 0
         return self._get_obs(), {}
 
     def step(self, action):
@@ -232,7 +261,15 @@ class WireEDMEnv:
         """``n_substeps`` consecutive ``step(action)`` calls in ONE fused kernel launch."""
         act = self._prepare_action(action)
         self._last_action = act  # keep the tensors alive while the launch is in flight
-        self._backend.step(int(n_substeps), act.ptrs)
+        n_substeps = int(n_substeps)
+        # `state.time` is an int32 microsecond count (and a Philox counter word): refuse to run past it.
+        # steps_since_reset bounds every environment's clock from above (a masked reset only lowers clocks).
+        if (self.steps_since_reset + n_substeps) * self.dt > _TIME_LIMIT_US:
+            raise OverflowError(
+                f"state.time would pass {_TIME_LIMIT_US} us (int32, ~35.8 simulated minutes) in some environment: "
+                "reset() the batch first (the reference counts time in unbounded Python ints, wire_edm.py:135)")
+        self._backend.step(n_substeps, act.ptrs)
+        self.steps_since_reset += n_substeps
         # obs / done / info are views of caller-owned memory the kernel has just (asynchronously)
         # updated: built once, handed out every step (`info` is a fresh dict of the same tensors)
         out = self._step_out
@@ -342,23 +379,43 @@ class WireEDMEnv:
         self._trace = None
 
     # ---- checkpoint / resume (the reference has none for simulation state) ---------
+    def _physics_fingerprint(self) -> str:
+        """sha256 over everything that determines the physics of a continuation: the whole
+        `wedm_params` block the kernels receive (configuration, module parameters, derived constants,
+        control mode, shard offset) and, with per-environment geometry, the geometry rows."""
+        import ctypes
+        import hashlib
+
+        h = hashlib.sha256(ctypes.string_at(ctypes.addressof(self.params), ctypes.sizeof(self.params)))
+        if self.per_env_geometry:
+            h.update(self._geom_f64.cpu().numpy().tobytes())
+            h.update(self._geom_i32.cpu().numpy().tobytes())
+        return h.hexdigest()
+
     def state_dict(self) -> Dict[str, Any]:
         """Everything a bit-identical continuation needs: the raw state blocks (Philox key, episode
-        and clocks live in them, so the random streams resume exactly) and the reset seed."""
+        and clocks live in them, so the random streams resume exactly), the reset seed, and a
+        fingerprint of the physics parameters (tensors, ints and strings only: loads with
+        ``weights_only=True``)."""
         return {"blocks": self.state.clone_blocks(), "seed": self._seed, "num_envs": self.num_envs,
-                "n_segments": self.n_segments, "env_id_offset": self.env_id_offset}
+                "n_segments": self.n_segments, "env_id_offset": self.env_id_offset,
+                "steps_since_reset": self.steps_since_reset, "physics": self._physics_fingerprint()}
 
     def load_state_dict(self, sd: Dict[str, Any]) -> None:
         if (sd["num_envs"], sd["n_segments"], sd["env_id_offset"]) != (self.num_envs, self.n_segments, self.env_id_offset):
             raise ValueError("checkpoint was taken from an environment of a different shape / shard")
+        if sd.get("physics") != self._physics_fingerprint():
+            raise ValueError("checkpoint was taken with different physics (configuration, module parameters, control "
+                             "mode or per-environment geometry): continuing would silently change the trajectory")
         self.state.load_blocks(sd["blocks"])
         self._seed = int(sd["seed"])
+        self.steps_since_reset = int(sd["steps_since_reset"])
 
     def save_checkpoint(self, path) -> None:
         torch.save(self.state_dict(), path)
 
     def load_checkpoint(self, path) -> None:
-        self.load_state_dict(torch.load(path, map_location="cpu", weights_only=False))
+        self.load_state_dict(torch.load(path, map_location="cpu", weights_only=True))
 
     def zone_mean_temperature(self) -> torch.Tensor:
         """Mean wire temperature over the workpiece zone (wire.py:390-398), per environment."""
@@ -413,6 +470,9 @@ class WireEDMEnv:
     @property
     def wire_diameter(self) -> float:
         return self.config.wire_diameter
+
+
+_TIME_LIMIT_US = 2**31 - 1
 
 
 def _to_numpy(x):

@@ -31,6 +31,7 @@ class DeviceTrace:
     def __init__(self, env, signals: Iterable[str], *, every: int = 1, capacity: int = 1000,
                  envs: Optional[Tuple[int, int]] = None, wire_temperature: bool = False):
         self.env = env
+        self.bind_step = int(getattr(env, "steps_since_reset", 0))  # physics steps since the last full reset, at the bind
         self.every, self.capacity = int(every), int(capacity)
         if self.every < 1 or self.capacity < 1:
             raise ValueError("every and capacity must be >= 1")

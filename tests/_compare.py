@@ -7,7 +7,7 @@ from sparc_amd import _abi
 
 _ROW_NAMES = {
     "f64": [f.name for f in _abi.F64], "i32": [f.name for f in _abi.I32], "i8": [f.name for f in _abi.I8],
-    "obs": list(_abi.OBS_NAMES), "stats": [f.name for f in _abi.STAT],
+    "obs": list(_abi.OBS_NAMES), "stats": [f.name for f in _abi.STAT], "reward": ["reward"],
 }
 
 
@@ -15,7 +15,7 @@ def block_diffs(got, want, n, *, skip_rows=(), T_rows=None):
     """Return a list of human-readable mismatches between two ``clone_blocks()`` dicts
     over the first ``n`` environments.  NaN == NaN.  Empty list = bit-identical."""
     out = []
-    for k in ("i32", "i8", "f64", "T", "obs", "stats"):
+    for k in ("i32", "i8", "f64", "T", "obs", "stats", "reward"):
         if k not in got or k not in want:
             continue
         a, b = got[k][:, :n], want[k][:, :n]

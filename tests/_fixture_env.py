@@ -139,3 +139,52 @@ def run_fixture_through_trace(env, fx, *, exact_floats, float_rtol=1e-12, T_atol
             assert abs(stats["mean_volume_um3"] - mean) <= 1e-12 * mean
     env.unbind_trace()
     return got
+
+
+# ------------------------------------------------------------------ the reference's own logger (fixture F16)
+LOGGER_EXACT = ("time", "voltage", "current", "wire_position", "wire_velocity", "workpiece_position", "target_delta",
+                "is_short_circuit")
+
+
+def run_logger_fixture(path, *, device, backend=None, exact):
+    """Fixture F16 = the output of the reference's `SimulationLogger` (utils/logger.py:54-237) fed by its own
+    driver loop (experiments/run_simulation.py:241-297) over its own signal list, at the three log
+    frequencies.  Runs the build's logger + `run_controlled` + on-device gap controller the same way and
+    compares key by key.  `exact`: every float bit for bit (LIBM oracle seam); otherwise positions,
+    voltages, currents and commands exact, debris / flow to 1e-12, temperatures to 1e-4 K (GPU)."""
+    import json
+
+    from sparc_amd import GapController, SimulationLogger, WireEDMEnv, WireModuleParameters, run_controlled
+
+    z = np.load(path, allow_pickle=False)
+    meta = json.loads(str(z["meta"]))
+    e, n_steps = int(meta["env_id"]), int(meta["n_steps_run"])
+    kw = dict(backend=backend) if backend is not None else {}
+    compared = 0
+    for freq in ("every_step", "interval", "control_step"):
+        signals = meta["every_step_signals"] if freq == "every_step" else meta["signals"]
+        env = WireEDMEnv(num_envs=e + 3, device=device, mechanics_control_mode=meta["control_mode"],
+                         wire_params=WireModuleParameters(**meta["modules"]["wire"]), **kw)
+        env.reset(seed=int(meta["seed"]))
+        for k, v in meta["state_init"].items():
+            setattr(env.state, k, v)
+        lf = {"type": freq, "value": int(meta["interval"])} if freq == "interval" else {"type": freq}
+        lg = SimulationLogger({"signals_to_log": signals, "log_frequency": lf, "backend": {"type": "memory"}},
+                              env_reference=env)
+        lg.attach(env)
+        run_controlled(env, GapController(), n_steps, logger=lg)
+        data = lg.get_data()
+        assert sorted(data) == sorted(signals)
+        for sig in signals:
+            want, got = z[f"{freq}/{sig}"], data[sig][:, e]
+            assert got.shape == want.shape, (freq, sig, got.shape, want.shape)
+            if want.dtype.kind in "bi" or exact or sig in LOGGER_EXACT:
+                same = (got == want) | ((got != got) & (want != want))
+                assert same.all(), f"{freq}/{sig}: first difference at sample {int(np.nonzero(~same.reshape(len(same), -1).all(axis=1))[0][0])}"
+            elif sig in ("wire_temperature", "wire_average_temperature"):
+                assert np.abs(got.astype(np.float64) - want).max() <= 1e-4, f"{freq}/{sig}"
+            else:
+                assert np.all(np.abs(got - want) <= 1e-12 * np.maximum(np.abs(got), np.abs(want))), f"{freq}/{sig}"
+            compared += 1
+        env.close()
+    return compared

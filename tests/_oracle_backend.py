@@ -56,9 +56,10 @@ class OracleBackend:
             obs[:, : self.num_envs][:, m] = 0
 
     def _run(self, n_substeps, action):
+        stencil = max(int(self.stencil_mode), int(self.params.stencil_mode))
         rc = self._L.wedm_oracle_step_batch(C.byref(self.params), C.byref(self.state), C.byref(self.geom),
-                                            C.byref(action), self.num_envs, n_substeps, self.math_mode,
-                                            self.stencil_mode, self.n_threads)
+                                            C.byref(action), self.num_envs, self.n_seg_max, n_substeps,
+                                            self.math_mode, stencil, self.n_threads)
         assert rc == 0, rc
 
     def step(self, n_substeps, action):

@@ -176,5 +176,33 @@ def test_checkpoint_resume_is_bit_identical(tmp_path):
         same = (A[k] == B[k]) | ((A[k] != A[k]) & (B[k] != B[k])) if A[k].is_floating_point() else (A[k] == B[k])
         assert bool(same.all()), k
     assert int(a.state.spark_count.sum()) > 20
+    assert b.steps_since_reset == a.steps_since_reset == 3200
     with pytest.raises(ValueError):
         WireEDMEnv(num_envs=5, device="cpu", backend=OracleBackend).load_checkpoint(tmp_path / "ck.pt")
+    # same shape, different physics (control mode / a module parameter): refused instead of silently diverging
+    from sparc_amd import MechanicsModuleParameters
+
+    with pytest.raises(ValueError, match="different physics"):
+        WireEDMEnv(num_envs=6, device="cpu", backend=OracleBackend,
+                   mechanics_control_mode="velocity").load_checkpoint(tmp_path / "ck.pt")
+    with pytest.raises(ValueError, match="different physics"):
+        WireEDMEnv(num_envs=6, device="cpu", backend=OracleBackend,
+                   mechanics_params=MechanicsModuleParameters(zeta=0.5)).load_checkpoint(tmp_path / "ck.pt")
+
+
+def test_time_counter_guard_raises_before_the_int32_clock_wraps():
+    """`state.time` is an int32 microsecond count and a Philox counter word (the reference counts in
+    Python ints, wire_edm.py:135): stepping past 2**31 - 1 us raises instead of wrapping."""
+    env = WireEDMEnv(num_envs=2, device="cpu", backend=OracleBackend)
+    env.reset(seed=1)
+    act = env.make_action()
+    env.step_many(act, 10)
+    env.steps_since_reset = 2**31 - 1 - 5     # as if ~35.8 simulated minutes had been run
+    env.step_many(act, 5)
+    with pytest.raises(OverflowError):
+        env.step_many(act, 1)
+    env.reset(options={"mask": [True, False]})  # a partial reset does not lift the bound
+    with pytest.raises(OverflowError):
+        env.step_many(act, 1)
+    env.reset()
+    env.step_many(act, 1)

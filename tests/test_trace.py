@@ -186,7 +186,7 @@ def test_logger_attached_to_the_device_trace(tmp_path):
             assert np.allclose(F[k], P[k], rtol=0, atol=1e-4), k
         else:
             assert np.array_equal(F[k], P[k], equal_nan=True), k
-    assert (F["dielectric_flow_rate"] == F["flow_rate"] * 100.0).all()
+    assert (F["dielectric_flow_rate"] == F["flow_rate"] * 100.0 / 1e9).all()   # dielectric.py:160-162
     z = np.load(tmp_path / "run.npz")
     assert np.array_equal(z["voltage"], F["voltage"]) and z["wire_temperature"].shape == (2300, 3, a.n_segments)
     # interval logging: every 50th microsecond (logger.py:130-132), on a sub-range of environments
@@ -198,6 +198,17 @@ def test_logger_attached_to_the_device_trace(tmp_path):
     assert t.shape == (24, 2) and t[:, 0].tolist() == list(range(50, 1201, 50))
     with pytest.raises(ValueError):
         SimulationLogger({"log_frequency": {"type": "control_step"}}).attach(c)
+
+
+@pytest.mark.parametrize("name", ["f16_logger_philox_env3", "f16_logger_velocity_philox_env1"])
+def test_logger_output_equals_the_reference_loggers_own_output(golden_dir, name):
+    """F16: the reference's `SimulationLogger` over its own driver loop and signal list (every_step,
+    interval, control_step; incl. `dielectric_flow_rate`'s 1e-9 scaling and the zone mean cached every
+    `zone_mean_interval` wire updates) against the build's logger fed from the device trace of fused
+    launches — every key, bit for bit on the LIBM oracle seam."""
+    from tests._fixture_env import run_logger_fixture
+
+    assert run_logger_fixture(golden_dir / f"{name}.npz", device="cpu", backend=LibmOracleBackend, exact=True) == 38
 
 
 def test_logger_and_voltage_controller_share_one_trace():

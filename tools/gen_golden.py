@@ -347,6 +347,67 @@ class VoltageDriver:
         return self.ctl(env, list(self.vh))
 
 
+def run_logger_scenario(name, *, n_steps, seed, env_id, control_mode="position", wire=None, state_init=None,
+                        interval=50):
+    """The reference's OWN `SimulationLogger` (utils/logger.py:54-237) fed by the reference's own driver
+    loop (experiments/run_simulation.py:241-297: gap controller recomputed on control steps,
+    `logger.collect(env.state, info)` after every 1-us step) over the signal list of
+    `setup_logger(log_strategy="both")` (run_simulation.py:127-147), at the three log frequencies
+    (every_step / interval / control_step), Philox variates injected.  The fixture holds what
+    `np.array(logger.get_data()[signal])` gives, key by key: `<frequency>/<signal>`."""
+    from wedm.utils.logger import SimulationLogger as RefLogger
+
+    drv = reference_driver_module()
+    cfg_file = drv.setup_logger(control_mode, log_to_file=True, log_strategy="both")  # the reference's signal list
+    signals = list(cfg_file["signals_to_log"])
+    assert "dielectric_flow_rate" in signals and "wire_average_temperature" in signals and "wire_temperature" in signals
+    wire = dict(wire or {})
+    env = ref_harness.quiet(wedm.WireEDMEnv, mechanics_control_mode=control_mode,
+                            wire_params=wedm.WireModuleParameters(**wire))
+    env.reset(seed=seed)
+    rec = PhiloxShim(seed, env_id)
+    env.np_random = rec
+    for k, v in (state_init or {}).items():
+        setattr(env.state, k, v)
+    no_field = [s for s in signals if s != "wire_temperature"]  # the every-microsecond log without the full field (size)
+    loggers = {
+        "every_step": RefLogger({"signals_to_log": no_field, "log_frequency": {"type": "every_step"},
+                                 "backend": {"type": "memory"}}, env_reference=env),
+        "interval": RefLogger({"signals_to_log": signals, "log_frequency": {"type": "interval", "value": interval},
+                               "backend": {"type": "memory"}}, env_reference=env),
+        "control_step": RefLogger({"signals_to_log": signals, "log_frequency": {"type": "control_step"},
+                                   "backend": {"type": "memory"}}, env_reference=env),
+    }
+    for lg in loggers.values():
+        lg.reset()
+    controller = drv.create_gap_controller()
+    action = controller(env)
+    for _ in range(n_steps):  # run_simulation.py:255-281
+        rec.begin_step(env.state.time)
+        obs, reward, terminated, truncated, info = env.step(action)
+        for lg in loggers.values():
+            lg.collect(env.state, info)
+        if info.get("control_step", False):
+            action = controller(env)
+        assert not (terminated or truncated)
+    arrays = {}
+    for freq, lg in loggers.items():
+        lg.finalize()
+        for sig, values in lg.get_data().items():
+            arr = np.array(values)
+            assert arr.dtype != object, (freq, sig)
+            arrays[f"{freq}/{sig}"] = arr
+    meta = {"name": name, "seed": seed, "env_id": env_id, "rng": "philox", "control_mode": control_mode,
+            "modules": {"wire": wire}, "state_init": state_init or {}, "n_steps_run": n_steps, "interval": interval,
+            "signals": signals, "every_step_signals": no_field, "n_seg": int(env.wire.n_segments),
+            "base_flow_rate": env.dielectric.params.base_flow_rate, "numpy": np.__version__}
+    arrays["meta"] = np.array(json.dumps(meta))
+    OUT.mkdir(parents=True, exist_ok=True)
+    np.savez_compressed(OUT / f"{name}.npz", **arrays)
+    print(f"{name:28s} steps={n_steps} keys={len(arrays) - 1} "
+          f"size={(OUT / (name + '.npz')).stat().st_size // 1024} KiB")
+
+
 def env_probe_modes():
     """Current modes that have crater data in the reference (material.py:108-113)."""
     env = ref_harness.quiet(wedm.WireEDMEnv)
@@ -560,6 +621,17 @@ def main():
                  state_init={"workpiece_position": 20.0, "wire_position": 10.0, "target_position": 5000.0},
                  action=make_action(0.1, 90.0, 9, 2.0, 25.0), t_snap_every=1800, float_stride=3,
                  note="sparks before the first control-step latch use the default modes")
+
+    # F16 — the reference's own SimulationLogger over its own driver loop and signal list
+    if not only or only in "f16_logger_philox_env3":
+        run_logger_scenario("f16_logger_philox_env3", n_steps=3300, seed=83, env_id=3,
+                            wire={"segment_len": 0.625, "compute_zone_mean": True},
+                            state_init={"workpiece_position": 24.0, "wire_position": 10.0, "target_position": 5000.0})
+    if not only or only in "f16_logger_velocity_philox_env1":
+        run_logger_scenario("f16_logger_velocity_philox_env1", n_steps=2200, seed=84, env_id=1, control_mode="velocity",
+                            wire={"segment_len": 0.625, "compute_zone_mean": True, "zone_mean_interval": 70},
+                            state_init={"workpiece_position": 30.0, "wire_position": 10.0, "target_position": 5000.0},
+                            interval=35)
 
     # F12 — the modules' public getters over a grid (ignition.py:348-384, material.py:176-205)
     if not only or only in "f12_module_getters":
