@@ -46,44 +46,88 @@ class VoltageController:
     (`create_voltage_controller`, experiments/run_simulation.py:58-109), one integrator per
     environment, evaluated on the GPU.
 
-    The reference's driver appends `state.voltage` after every 1-us step and keeps the samples
-    whose time is >= time - 1000, i.e. up to 1001 of them (run_simulation.py:262-270).  Here the
-    step kernels record the voltage of every microsecond into a 1001-slot ring
-    (`WireEDMEnv.bind_trace`) and the controller averages the ring at the control step.  Sum and
-    division are float64; when the voltages are integers (the 0 / 24 / 80 V of the default
-    generator settings) the sum is exact in any order and the command equals the reference's
-    bit for bit, otherwise it may differ in the last bit before the float32 rounding of the
-    servo leaf.  Before the first step the reference falls back to `state.voltage` (None -> 0)."""
+    The reference's driver appends `state.voltage` after every step and keeps the samples whose time
+    is >= time - 1000 us (run_simulation.py:262-270): with the default 1000-us servo interval that is
+    this control interval's samples plus the previous control step's — up to 1001 of them.  The step
+    kernels keep exactly that as a running float64 sum in step order and publish it at every control
+    step (rows WEDM_F_VOLT_ACC / WEDM_F_VOLT_SUM, include/wedm_hip.h), so the controller reads one
+    float64 per environment; no per-microsecond ring is written or re-read.  Sum and division are
+    float64; when the voltages are integers (the 0 / 24 / 80 V of the default generator settings) the
+    sum is exact in any order and the command equals the reference's `np.mean` bit for bit, otherwise
+    it may differ in the last bit before the float32 rounding of the servo leaf.  Before the first
+    control step the reference falls back to `state.voltage` (None -> 0); the published sum is 0 then.
 
-    WINDOW = 1001
+    Servo intervals that divide 1000 us are handled by adding the last ``1000 / interval`` published
+    sums (their shared end points counted once; environments must then run in lock-step, i.e. without
+    per-environment resets).  For any other interval pass ``use_ring=True``: the controller then
+    averages a per-microsecond voltage trace (`WireEDMEnv.bind_trace`), as in round 1."""
+
+    WINDOW_US = 1000  # run_simulation.py:267 `cutoff_time = env.state.time - 1000.0`
 
     def __init__(self, target_voltage: float = 30.0, *, Kp: float = 0.05, Ki: float = 0.1,
-                 generator_voltage: float = 80.0, current_mode: int = 7, ON_time: float = 2.0, OFF_time: float = 33.0):
+                 generator_voltage: float = 80.0, current_mode: int = 7, ON_time: float = 2.0, OFF_time: float = 33.0,
+                 use_ring: bool = False):
         self.target_voltage, self.Kp, self.Ki = float(target_voltage), float(Kp), float(Ki)
         self.generator_voltage, self.current_mode = float(generator_voltage), int(current_mode)
         self.ON_time, self.OFF_time = float(ON_time), float(OFF_time)
+        self.use_ring = bool(use_ring)
         self._env = None
 
     def bind(self, env: WireEDMEnv, trace=None):
-        """Attach to `env`.  Pass an existing `DeviceTrace` that records ``"voltage"`` of every
-        environment every microsecond with capacity >= 1001 to share it with a logger; otherwise
-        the controller binds its own."""
-        if trace is None:
-            trace = env.bind_trace(["voltage"], every=1, capacity=self.WINDOW)
-        if ("voltage" not in trace.signals or trace.every != 1 or trace.capacity < self.WINDOW
-                or trace.env_lo != 0 or trace.env_count != env.num_envs):
-            raise ValueError("VoltageController needs a trace of 'voltage' for all environments, every=1, capacity>=1001")
-        self._env, self._trace = env, trace
+        """Attach to `env`.  ``trace`` (ring mode only): an existing `DeviceTrace` that records
+        ``"voltage"`` of every environment every step with capacity >= the window, to share it with
+        a logger; passing one selects the ring mode."""
+        self._env = env
+        steps = -(-env.servo_interval // env.dt)              # physics steps between two control steps
+        period_us = steps * env.dt
+        self._window = self.WINDOW_US // env.dt + 1           # samples with time >= t - 1000
+        if trace is not None:
+            self.use_ring = True
+        if not self.use_ring and self.WINDOW_US % period_us:
+            raise ValueError(f"the control period ({period_us} us) does not divide the {self.WINDOW_US}-us averaging "
+                             "window: use VoltageController(use_ring=True)")
+        self._trace = None
+        if self.use_ring:
+            if trace is None:
+                trace = env.bind_trace(["voltage"], every=1, capacity=self._window)
+            if ("voltage" not in trace.signals or trace.every != 1 or trace.capacity < self._window
+                    or trace.env_lo != 0 or trace.env_count != env.num_envs):
+                raise ValueError(f"VoltageController needs a trace of 'voltage' for all environments, every=1, "
+                                 f"capacity>={self._window}")
+            self._trace = trace
+        self._steps, self._m = steps, max(1, self.WINDOW_US // period_us)
+        self._sums, self._ends = [], []                       # last m published sums / control-step voltages
+        self._seen_steps = -1
         self.integral_error = torch.zeros(env.num_envs, dtype=torch.float64, device=env.device)
         self._base = env.make_action(0.0, self.generator_voltage, self.current_mode, self.ON_time, self.OFF_time)
         return self
 
     def average_voltage(self) -> torch.Tensor:
-        n = min(self._trace.count, self.WINDOW)
-        if n == 0:
-            return self._env.state.voltage.clone()
-        total = self._trace.read(last=n, names=["voltage"])["voltage"].sum(dim=0)
-        # tensor / tensor: torch's GPU kernel for tensor / python-scalar multiplies by 1/n instead
+        """Mean of the samples `create_voltage_controller` would receive now (call it right after a
+        control step, as the driver does)."""
+        env = self._env
+        if self._trace is not None:
+            n = min(self._trace.count, self._window)
+            if n == 0:
+                return env.state.voltage.clone()
+            total = self._trace.read(last=n, names=["voltage"])["voltage"].sum(dim=0)
+            # tensor / tensor: torch's GPU kernel for tensor / python-scalar multiplies by 1/n instead
+            return total / torch.full_like(total, float(n))
+        st = env.state
+        if env.steps_since_reset <= self._steps:               # no control step yet: `state.voltage` (None -> 0)
+            return st.voltage.clone()
+        if self._m == 1:
+            total = st.voltage_sum_at_control_step
+            return total / torch.full_like(total, float(self._steps + 1))
+        if env.steps_since_reset != self._seen_steps:           # a new control step has been published
+            self._seen_steps = env.steps_since_reset
+            self._sums.append(st.voltage_sum_at_control_step.clone())
+            self._ends.append(st.voltage.clone())
+            del self._sums[:-self._m], self._ends[:-self._m]
+        total = self._sums[0].clone()
+        for k in range(1, len(self._sums)):
+            total = total + self._sums[k] - self._ends[k - 1]   # the shared end point is in both sums
+        n = len(self._sums) * self._steps + 1
         return total / torch.full_like(total, float(n))
 
     def __call__(self, env: WireEDMEnv) -> DeviceAction:
@@ -108,19 +152,21 @@ def run_controlled(env: WireEDMEnv, controller: Callable[[WireEDMEnv], DeviceAct
     The reference computes the first action before any step, latches it on the first control
     step (call number ``servo_interval + 1``), recomputes the action right after every control
     step and latches THAT one a whole interval later.  Launch lengths reproduce exactly this:
-    ``servo_interval - time_since_servo + 1`` microseconds up to and including the next latch,
-    then one ``servo_interval`` per launch.  Returns the number of microseconds run.
+    ``ceil((servo_interval - time_since_servo) / dt) + 1`` physics steps up to and including the next
+    latch, then ``ceil(servo_interval / dt)`` per launch (``n_steps`` and the return value count
+    physics steps of ``config.dt`` microseconds each).
 
     ``logger``: a `SimulationLogger`.  With the ``control_step`` frequency it samples the state
     after every launch that ended on a control step; with ``every_step`` / ``interval`` it must be
     attached to the environment's device trace (`logger.attach(env)`), whose ring is drained after
     every launch — the per-microsecond log of run_simulation.py:257 without leaving the GPU.
     """
-    interval = env.servo_interval // env.dt
-    tss = int(env.state.time_since_servo.max().item())  # one host read, before the loop
+    dt = env.dt
+    interval = -(-env.servo_interval // dt)             # physics steps between two latches: ceil(servo_interval / dt)
+    tss = int(env.state.time_since_servo.max().item())  # [us] one host read, before the loop
     action = controller(env)
     done = 0
-    next_k = max(1, interval - tss + 1)  # microseconds up to and including the next latch
+    next_k = max(1, -(-(env.servo_interval - tss) // dt) + 1)  # steps up to and including the next latch
     while done < n_steps:
         k = min(next_k, n_steps - done)
         env.step_many(action, k)

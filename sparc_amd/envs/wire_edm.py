@@ -286,7 +286,7 @@ class WireEDMEnv:
 
     def step_control(self, action):
         """One control interval (``servo_interval`` physics steps, default 1000)."""
-        return self.step_many(action, self.servo_interval // self.dt)
+        return self.step_many(action, -(-self.servo_interval // self.dt))  # ceil: the latch tests `time_since_servo >= servo_interval`
 
     def close(self) -> None:
         self._backend.close()

@@ -15,6 +15,22 @@ def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
 
 
+def pytest_collection_modifyitems(config, items):
+    """A plain `pytest` on a machine without an AMD GPU skips the gpu-marked tests instead of failing them."""
+    try:
+        import torch
+
+        have_gpu = torch.cuda.is_available()
+    except Exception:
+        have_gpu = False
+    if have_gpu:
+        return
+    skip = pytest.mark.skip(reason="needs an MI355X (run with -m gpu on the GPU box)")
+    for item in items:
+        if "gpu" in item.keywords:
+            item.add_marker(skip)
+
+
 @pytest.fixture(scope="session")
 def orc():
     """The CPU oracle (test infrastructure), built on demand with oracle/Makefile."""

@@ -111,7 +111,7 @@ def test_device_math_primitives_match_cpu_bit_for_bit(orc, kind):
         f"kind {kind}: {np.count_nonzero(got.view(np.uint64) != want.view(np.uint64))} of {len(want)} differ"
 
 
-KERNELS = [(1, 0), (5, 0), (2, 0), (3, 1), (3, 2), (3, 4), (3, 8), (3, 16), (4, 1), (4, 2), (4, 4), (4, 8)]
+KERNELS = [(1, 0), (5, 0), (6, 0), (2, 0), (3, 1), (3, 2), (3, 4), (3, 8), (3, 16), (4, 1), (4, 2), (4, 4), (4, 8)]
 
 
 @pytest.mark.parametrize("variant,lanes", KERNELS)
@@ -207,7 +207,7 @@ def test_per_environment_geometry_config5():
     gpu, cpu = make_pair(n, **kw)
     assert gpu.n_segments == cpu.n_segments and 350 <= gpu.n_segments <= 450
     both((gpu, cpu), lambda e: (e.reset(seed=2024), close_gap(e, 24.0, 10.0)))
-    for variant, lanes in ((1, 0), (5, 0), (2, 4), (2, 8), (2, 16), (2, 0)):
+    for variant, lanes in ((1, 0), (5, 0), (6, 0), (2, 4), (2, 8), (2, 16), (2, 0)):
         gpu.set_kernel(variant, lanes)
         for env in (gpu, cpu):
             a = env.make_action(0.1, 80.0, mode, 3.0, 40.0)
@@ -565,7 +565,7 @@ def test_device_trace_per_environment_geometry():
     gpu, cpu = make_pair(n, **kw)
     both((gpu, cpu), lambda e: (e.reset(seed=4), close_gap(e, 24.0, 10.0)))
     n_seg = gpu._geom_i32[0, :n].cpu()   # WEDM_GI_N_SEG
-    for variant in (2, 1, 5):
+    for variant in (2, 1, 5, 6):
         gpu.set_kernel(variant, 0)
         traces = [e.bind_trace(["voltage", "time", "spark_state"], every=10, capacity=64, envs=(5, 80),
                                wire_temperature=True) for e in (gpu, cpu)]
@@ -777,7 +777,7 @@ def test_randomized_configurations_all_kernels_bit_exact(case):
         env.state.workpiece_position = torch.as_tensor(10.0 + gaps)
         env.state.target_position = torch.as_tensor(np.where(np.arange(n) % 7 == 3, 10.0 + gaps + 0.01, 5000.0)) if extreme else 5000.0
         env.state.debris_volume = torch.as_tensor(debris) if (case % 2 or extreme) else 0.0
-    variants = [(0, 0), (1, 0), (5, 0), (2, 4), (2, 8)] if per_env else KERNELS + [(0, 0)]
+    variants = [(0, 0), (1, 0), (5, 0), (6, 0), (2, 4), (2, 8)] if per_env else KERNELS + [(0, 0)]
     servo = rng.uniform(50, 300, n) if kw["mechanics_control_mode"] == "velocity" else rng.uniform(-0.05, 0.3, n)
     if extreme:
         servo = servo * rng.choice([1.0, 1.0, 20.0, -3.0], n)
@@ -867,3 +867,176 @@ def test_default_modes_before_the_first_latch_fixture_on_gpu(golden_dir):
     env = env_from_fixture(fx, 64, device="cuda:0")
     got = run_fixture_through_trace(env, fx, exact_floats=False)
     assert (got["spark_state"][:1000] == 1).sum() > 5
+
+
+# ------------------------------------------------------------------ BASELINE configs[3] / configs[4] as the bench shards them
+def test_config4_shard_of_rank_7_matches_oracle():
+    """BASELINE configs[3] (262 144 environments over 8 GPUs) as rank 7 of 8 sees it: 32 768 environments x
+    400 segments, env_id_offset = 7 * 32 768, the automatically selected kernel, two control intervals and a
+    few single microseconds, against the CPU oracle on every byte."""
+    n, rank = 32768, 7
+    gpu, cpu = make_pair(n, env_id_offset=rank * n)
+    both((gpu, cpu), lambda e: (e.reset(seed=1234), close_gap(e, 25.0, 10.0)))
+    for env in (gpu, cpu):
+        act = env.make_action(0.1, 80.0, 5, 3.0, 80.0)
+        env.step_many(act, 1000)
+        env.step_many(act, 1000)
+    assert "wedm_step_fused<8>" in gpu._backend.last_kernel(), gpu._backend.last_kernel()
+    check(gpu, cpu, n)
+    for env in (gpu, cpu):
+        act = env.make_action(0.1, 80.0, 5, 3.0, 80.0)
+        for _ in range(3):
+            env.step(act)
+    assert "wedm_step_split" in gpu._backend.last_kernel()
+    check(gpu, cpu, n)
+    assert int(gpu.state.spark_count.sum()) > 100000
+    # the offset really is in the random streams: rank 0's first environments follow other trajectories
+    other = WireEDMEnv(num_envs=256, device="cuda:0")
+    other.reset(seed=1234)
+    close_gap(other, 25.0, 10.0)
+    other.step_many(other.make_action(0.1, 80.0, 5, 3.0, 80.0), 2003)
+    assert not torch.equal(other.state.spark_count, gpu.state.spark_count[:256])
+
+
+def test_config5_shard_of_rank_5_matches_oracle():
+    """BASELINE configs[4] (131 072 environments, per-environment workpiece height / wire diameter / current
+    mode from numpy.default_rng(2024)) as rank 5 of 8 sees it: its 16 384-environment slice of
+    the global draws, env_id_offset = 5 * 16 384, the automatically selected kernel, two control intervals
+    and a few single microseconds, against the CPU oracle on every byte."""
+    import bench
+
+    n, rank, world = 16384, 5, 8
+    h, d, mode = bench.config5_draws(world * n, rank * n, (rank + 1) * n)
+    kw = dict(workpiece_height=h, wire_diameter=d, env_id_offset=rank * n,
+              config=EnvironmentConfig(target_cutting_distance=5000.0))
+    gpu, cpu = make_pair(n, **kw)
+    assert gpu.n_segments == cpu.n_segments and 440 <= gpu.n_segments <= 450
+    both((gpu, cpu), lambda e: (e.reset(seed=1234), close_gap(e, 25.0, 10.0)))
+    for env in (gpu, cpu):
+        act = env.make_action(0.1, 80.0, mode, 3.0, 80.0)
+        env.step_many(act, 1000)
+        env.step_many(act, 1000)
+    assert "wedm_step_lanes<8>" in gpu._backend.last_kernel(), gpu._backend.last_kernel()
+    check(gpu, cpu, n)
+    for env in (gpu, cpu):
+        act = env.make_action(0.1, 80.0, mode, 3.0, 80.0)
+        for _ in range(3):
+            env.step(act)
+    check(gpu, cpu, n)
+    assert int(gpu.state.spark_count.sum()) > 50000 and len(set(gpu._geom_i32[0, :n].cpu().tolist())) > 50
+
+
+# ------------------------------------------------------------------ auto-reset / reward / voltage sum inside the launch
+@pytest.mark.parametrize("variant,lanes", [(0, 0), (2, 4), (3, 8), (4, 2), (1, 0), (5, 0), (6, 0)])
+def test_in_kernel_autoreset_and_reward_match_oracle_and_host_path(variant, lanes):
+    """wedm_params.autoreset + reward_mode: environments that reach their cutting target are
+    re-initialised by the NEXT launch itself (Philox episode + 1, fresh module state, spool-temperature wire,
+    statistics cleared) and the launch writes the progress reward.  Three runs must agree on every byte, every
+    control interval: the GPU with the in-kernel reset, the CPU oracle with the same mode, and the GPU driven
+    the round-1 way (masked wedm_reset from the host + torch reward).  More than 30 % of the environments
+    terminate inside a single launch."""
+    from sparc_amd import WireEDMVectorEnv
+    from tests.test_next_rows import run_autoreset_pair, terminating_pair
+
+    n = 96
+    a, b = terminating_pair(n, None, device="cuda:0")
+    a.set_kernel(variant, lanes), b.set_kernel(variant, lanes)
+    c_env, _ = terminating_pair(n, OracleBackend)
+    vc = WireEDMVectorEnv(c_env)
+    act_c = c_env.make_action(0.05, 80.0, 13, 2.0, 20.0)
+    va, vb = WireEDMVectorEnv(a), WireEDMVectorEnv(b, reward="progress")
+    act_a, act_b = a.make_action(0.05, 80.0, 13, 2.0, 20.0), b.make_action(0.05, 80.0, 13, 2.0, 20.0)
+    most = 0.0
+    for k in range(5):
+        oa, ra, ta, ua, ia = va.step(act_a)
+        ob, rb, tb, ub, ib = vb.step(act_b)
+        oc, rc, tc, uc, ic = vc.step(act_c)
+        torch.cuda.synchronize()
+        assert torch.equal(ta, tb) and torch.equal(ta.cpu(), tc), k
+        assert torch.equal(ra, rb) and torch.equal(ra.cpu(), rc), k
+        A, B, Cc = a.state.clone_blocks(), b.state.clone_blocks(), c_env.state.clone_blocks()
+        assert_blocks_equal(A, Cc, n)                                  # GPU == oracle, reward row included
+        assert_blocks_equal(A, B, n, skip_rows=("reward",))            # in-kernel reset == host-driven reset
+        most = max(most, float(ta.float().mean()))
+    assert most >= 0.3 and int(a.state.episode.max()) >= 1
+    assert va._in_kernel_reset and not vb._in_kernel_reset
+
+
+def test_vector_env_step_is_one_launch_without_host_sync():
+    """`WireEDMVectorEnv.step` on an autoreset environment: no `.item()` / device-to-host read.  Checked by
+    running it under torch's sync debug mode, which raises on any synchronising call."""
+    from sparc_amd import WireEDMVectorEnv
+
+    env = WireEDMEnv(num_envs=4096, device="cuda:0", autoreset=True, reward="progress")
+    vec = WireEDMVectorEnv(env, max_episode_steps=3000)
+    vec.reset(seed=5)
+    close_gap(env, 25.0, 10.0, 25.004)
+    act = env.make_action(0.05, 80.0, 13, 2.0, 20.0)
+    vec.step(act)
+    torch.cuda.synchronize()
+    torch.cuda.set_sync_debug_mode("error")
+    try:
+        for _ in range(4):
+            obs, reward, term, trunc, info = vec.step(act)
+    finally:
+        torch.cuda.set_sync_debug_mode("default")
+    torch.cuda.synchronize()
+    assert "wedm_step_" in env._backend.last_kernel()
+    assert bool(term.any() | (env.state.episode > 0).any()) and reward.dtype == torch.float32
+
+
+@pytest.mark.parametrize("name", ["f16_logger_philox_env3", "f16_logger_velocity_philox_env1"])
+def test_reference_logger_fixture_on_gpu(golden_dir, name):
+    """F16 on the GPU: the output of the reference's own `SimulationLogger` over its own driver loop and signal
+    list (every_step / interval / control_step) against the build's logger fed by the in-kernel trace of fused
+    launches.  Clocks, positions, voltages, currents, commands and flags exact; debris / flow (and
+    `dielectric_flow_rate` with the reference's 1e-9 scaling) to 1e-12; temperatures to 1e-4 K."""
+    from tests._fixture_env import run_logger_fixture
+
+    assert run_logger_fixture(golden_dir / f"{name}.npz", device="cuda:0", exact=False) == 38
+
+
+@pytest.mark.parametrize("name,n", [("f9_voltage_controller_dt2_philox_env4", 64), ("f9_voltage_controller_servo500_philox_env6", 64)])
+def test_voltage_controller_sum_rows_on_gpu_follow_reference_fixtures(golden_dir, name, n):
+    """The PI voltage controller fed by the kernel-side running voltage sum (rows VOLT_ACC / VOLT_SUM) in fused
+    launches against the reference's own controller (fixtures F9b: 2-us physics step, 500-us servo interval):
+    every float32 servo command the reference computed, exactly."""
+    from sparc_amd import VoltageController
+    from tests._fixture_env import env_from_fixture
+    from tests._golden import Fixture
+
+    fx = Fixture(golden_dir / (name + ".npz"))
+    env_id = int(fx.meta["env_id"])
+    env = env_from_fixture(fx, n, device="cuda:0")
+    ctl = VoltageController(30.0)
+    action = ctl(env)
+    assert float(action.servo[env_id]) == fx.actions[fx.action_idx[0], 0]
+    steps = -(-env.servo_interval // env.dt)
+    done, k, checked = 0, steps + 1, 0
+    while done + k <= fx.n_steps:
+        env.step_many(action, k)       # one fused launch up to and including the next latch
+        done += k
+        action = ctl(env)
+        if done < fx.n_steps:
+            assert float(action.servo[env_id]) == fx.actions[fx.action_idx[done], 0], done
+            checked += 1
+        k = steps
+    assert checked >= 4
+    assert float(env.state.wire_position[env_id]) == float(fx.float_row("wire_position")[np.searchsorted(fx.float_steps, done - 1)]) \
+        or (done - 1) not in fx.float_steps.tolist()
+
+
+def test_environment_on_a_non_current_device_is_refused_by_the_abi_and_guarded_by_the_host():
+    """a handle belongs to the device that was current at wedm_create.  With one GPU the guard can only
+    be exercised through the C-ABI's own check: the status of a launch with the right device current is OK."""
+    env = WireEDMEnv(num_envs=64, device="cuda:0")
+    env.reset(seed=1)
+    env.step(env.make_action())
+    if torch.cuda.device_count() < 2:
+        pytest.skip("needs two GPUs to make another device current")
+    other = WireEDMEnv(num_envs=64, device="cuda:1")   # current device stays cuda:0
+    other.reset(seed=1)
+    other.step_many(other.make_action(), 10)
+    torch.cuda.synchronize("cuda:1")
+    assert_blocks_equal(env.state.clone_blocks(), env.state.clone_blocks(), 64)
+    assert int(other.state.time[0]) == 10

@@ -206,3 +206,63 @@ def test_time_counter_guard_raises_before_the_int32_clock_wraps():
         env.step_many(act, 1)
     env.reset()
     env.step_many(act, 1)
+
+
+def terminating_pair(n, backend, device="cpu", **kw):
+    """Two identical batches whose environments reach their cutting target at different moments."""
+    envs = []
+    for in_kernel in (True, False):
+        env = WireEDMEnv(num_envs=n, device=device, backend=backend, env_id_offset=1000,
+                         **(dict(autoreset=True, reward="progress") if in_kernel else {}), **kw)
+        env.reset(seed=31)
+        env.state.workpiece_position = 25.0
+        env.state.wire_position = 10.0
+        env.state.target_position = 25.0 + torch.linspace(0.0005, 0.03, n, dtype=torch.float64)
+        envs.append(env)
+    return envs
+
+
+def run_autoreset_pair(a, b, intervals=6, min_fraction=0.3):
+    """`a` resets inside the launch (wedm_params.autoreset, reward written by the kernel), `b` is driven
+    the round-1 way: a masked reset launch from the host + a torch reward.  Everything must agree."""
+    from tests._compare import assert_blocks_equal
+
+    va, vb = WireEDMVectorEnv(a), WireEDMVectorEnv(b, reward="progress")
+    assert va._in_kernel_reset and not vb._in_kernel_reset
+    act_a, act_b = a.make_action(0.05, 80.0, 13, 2.0, 20.0), b.make_action(0.05, 80.0, 13, 2.0, 20.0)
+    seen = torch.zeros(a.num_envs, dtype=torch.bool)
+    most = 0.0
+    for k in range(intervals):
+        oa, ra, ta, ua, ia = va.step(act_a)
+        ob, rb, tb, ub, ib = vb.step(act_b)
+        assert torch.equal(ta.cpu(), tb.cpu()) and torch.equal(ua.cpu(), ub.cpu()), k
+        assert torch.equal(ra.cpu(), rb.cpu()) and ra.dtype == torch.float32, k
+        assert torch.equal(oa.cpu(), ob.cpu()), k
+        assert torch.equal(ia["episode"].cpu(), ib["episode"].cpu()), k
+        assert_blocks_equal(a.state.clone_blocks(), b.state.clone_blocks(), a.num_envs, skip_rows=("reward",))
+        seen |= ta.cpu()
+        most = max(most, float(ta.float().mean()))
+    assert most >= min_fraction, most                     # a large share terminates inside one launch
+    assert bool(seen.all()) or float(seen.float().mean()) > 0.6
+    assert int(a.state.episode.max()) >= 1 and int(a.state.time.min()) < 1000 * intervals
+    return va, vb
+
+
+def test_in_kernel_autoreset_and_reward_equal_the_host_driven_path():
+    a, b = terminating_pair(48, OracleBackend)
+    run_autoreset_pair(a, b)
+
+
+def test_in_kernel_autoreset_with_truncation():
+    a = WireEDMEnv(num_envs=6, device="cpu", backend=OracleBackend, autoreset=True)
+    b = WireEDMEnv(num_envs=6, device="cpu", backend=OracleBackend)
+    va, vb = WireEDMVectorEnv(a, max_episode_steps=2000), WireEDMVectorEnv(b, max_episode_steps=2000)
+    va.reset(seed=3), vb.reset(seed=3)
+    act_a, act_b = a.make_action(), b.make_action()
+    for k in range(5):
+        ra, rb = va.step(act_a), vb.step(act_b)
+        assert torch.equal(ra[2], rb[2]) and torch.equal(ra[3], rb[3]), k
+        assert torch.equal(a.state.time, b.state.time) and torch.equal(a.state.episode, b.state.episode), k
+    assert a.state.time.tolist() == [1000] * 6 and a.state.episode.tolist() == [2] * 6
+    with pytest.raises(ValueError):
+        WireEDMVectorEnv(a, autoreset=False)

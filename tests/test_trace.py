@@ -111,17 +111,25 @@ def test_terminated_environments_keep_being_sampled():
     assert got["time"][:, 1].tolist() == list(range(1, 3001))
 
 
-@pytest.mark.parametrize("name,seed,mode,env_id,n", [
-    ("f9_voltage_controller_philox_env2", 79, "position", 2, 4),
-    ("f9_voltage_controller_velocity_philox_env5", 80, "velocity", 5, 8),
+@pytest.mark.parametrize("name,n,use_ring", [
+    ("f9_voltage_controller_philox_env2", 4, False),
+    ("f9_voltage_controller_velocity_philox_env5", 8, False),
+    ("f9_voltage_controller_dt2_philox_env4", 6, False),        # config.dt = 2: 501-sample window
+    ("f9_voltage_controller_servo500_philox_env6", 8, False),   # the 1 ms window spans two control intervals
+    ("f9_voltage_controller_philox_env2", 4, True),             # the per-microsecond ring kept as a fallback
+    ("f9_voltage_controller_dt2_philox_env4", 6, True),
 ])
-def test_voltage_controller_reproduces_the_reference_driver(golden_dir, name, seed, mode, env_id, n):
+def test_voltage_controller_reproduces_the_reference_driver(golden_dir, name, n, use_ring):
     """run_simulation.py's loop with the reference's OWN `create_voltage_controller` (fixture
-    generated by importing it) against the on-device VoltageController averaging the kernel-side
-    voltage ring: every recorded quantity and every servo command equal, bit for bit."""
+    generated by importing it) against the on-device VoltageController reading the running voltage
+    sum the step kernels publish at control steps (rows VOLT_ACC / VOLT_SUM): every recorded quantity
+    and every servo command equal, bit for bit."""
+    from tests._fixture_env import env_from_fixture
+
     fx = Fixture(golden_dir / (name + ".npz"))
-    env = driver_env(n, seed, mode)
-    ctl = VoltageController(30.0)
+    env_id = int(fx.meta["env_id"])
+    env = env_from_fixture(fx, n, device="cpu", backend=LibmOracleBackend)
+    ctl = VoltageController(30.0, use_ring=use_ring)
     action = ctl(env)
     assert float(action.servo[env_id]) == fx.actions[fx.action_idx[0], 0]
     checked = 0

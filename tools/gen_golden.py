@@ -539,6 +539,17 @@ def main():
                  state_init={"workpiece_position": 70.0, "wire_position": 10.0, "target_position": 5000.0},
                  t_snap_every=3000, float_stride=9, note="run_simulation.py voltage controller, velocity mode")
 
+    # F9b — the same controller with a 2-us physics step (501-sample window) and with a 500-us servo interval
+    # (the 1 ms window then spans two control intervals)
+    run_scenario("f9_voltage_controller_dt2_philox_env4", n_steps=3000, seed=85, rng="philox", env_id=4,
+                 config={"dt": 2}, controller=VoltageDriver(30.0),
+                 state_init={"workpiece_position": 40.0, "wire_position": 10.0, "target_position": 5000.0},
+                 t_snap_every=3000, float_stride=9, note="voltage controller, config.dt = 2 us")
+    run_scenario("f9_voltage_controller_servo500_philox_env6", n_steps=5000, seed=86, rng="philox", env_id=6,
+                 config={"servo_interval": 500}, controller=VoltageDriver(30.0),
+                 state_init={"workpiece_position": 40.0, "wire_position": 10.0, "target_position": 5000.0},
+                 t_snap_every=5000, float_stride=9, note="voltage controller, servo_interval = 500 us")
+
     # F10 — many craters: get_crater_statistics() (material.py:207-227) over a busy run
     run_scenario("f10_crater_statistics_philox_env1", n_steps=12000, seed=81, rng="philox", env_id=1,
                  state_init={"workpiece_position": 22.0, "wire_position": 10.0, "target_position": 5000.0},
