@@ -186,6 +186,8 @@ struct Hot {
     float spool, tref, alpha, tdiel, tcrit, tbreak;
     int32_t servo_interval, dt_us, control_mode, disable_ignition, has_random_short, per_env_geometry;
     int32_t autoreset, reward_mode;
+    // stencil_mode 1 only (Numba's typing of wire.py:58-123): the float64 constants of the stencil
+    double spool64, tref64, alpha64, tdiel64;
     uint32_t env_id_offset;
     int32_t n_seg;  // uniform geometry only
 };
@@ -225,6 +227,7 @@ struct Geom {
     double cavity_coeff;
     float k, tuf;
     int32_t n_seg, az_start, az_end, cb, ct;
+    double k64, tuf64, a64;  // stencil_mode 1 only: k_cond, temp_update_factor, A as float64
 };
 
 // per-lane coefficients that survive across substeps (recomputed only when their
@@ -232,6 +235,7 @@ struct Geom {
 struct Persist {
     float adv, conv_base, conv_zone;
     int32_t adv_on;
+    double adv64;  // stencil_mode 1 only
 };
 
 // float32 per-step coefficients the scalar prelude hands to the stencil pass
@@ -239,6 +243,7 @@ struct Coef {
     float jf;  // joule_factor (wire.py:98)
     float q;   // plasma heat (wire.py:298)
     int32_t joule_on, pidx;
+    double jf64, q64;  // stencil_mode 1 only: the same two before their rounding to float32
 };
 
 struct Tables {  // device copies of wedm_params' per-mode tables
@@ -439,6 +444,22 @@ __device__ __forceinline__ void store_env_after_epilogue(const ColdRef cold, int
     *WEDM_ROW(s.i8, WEDM_B_DONE) = (int8_t)v.done;
 }
 
+// Make the compiler treat every loaded state register as USED here: it inserts the wait for the state
+// loads at this point (and afterwards knows that none of them is pending).  Needed where vector-memory
+// operations the compiler cannot count follow (the LDS-DMA loop of wedm_step_stream): a later first use of a
+// state register would otherwise be a conservative `s_waitcnt vmcnt(0)` behind them.
+__device__ __forceinline__ void env_loaded_here(Env& v) {
+    asm volatile("" : "+v"(v.wp), "+v"(v.x), "+v"(v.v), "+v"(v.prev_a), "+v"(v.debris), "+v"(v.rho), "+v"(v.flow),
+                      "+v"(v.last_gap), "+v"(v.last_rho), "+v"(v.wire_last_flow), "+v"(v.V), "+v"(v.I), "+v"(v.y),
+                      "+v"(v.last_crater), "+v"(v.cavity));
+    asm volatile("" : "+v"(v.tdelta), "+v"(v.tvolt), "+v"(v.on), "+v"(v.off), "+v"(v.tpos), "+v"(v.unwind), "+v"(v.vacc),
+                      "+v"(v.h_base), "+v"(v.h_zone), "+v"(v.tmax), "+v"(v.time), "+v"(v.tss), "+v"(v.tsov), "+v"(v.tsi),
+                      "+v"(v.tse));
+    asm volatile("" : "+v"(v.dur), "+v"(v.rnd_rem), "+v"(v.deb_rem), "+v"(v.tcrit), "+v"(v.mode), "+v"(v.episode),
+                      "+v"(v.sparks), "+v"(v.key0), "+v"(v.key1), "+v"(v.state), "+v"(v.is_short), "+v"(v.broken),
+                      "+v"(v.reached), "+v"(v.done), "+v"(v.ctrl), "+v"(v.err));
+}
+
 // ----------------------------------------------------------------- signal trace
 // Row r of each state block as the registers hold it (the value store_env would write).
 __device__ __forceinline__ double env_f64_row(const Env& v, int row) {
@@ -539,12 +560,15 @@ __device__ __forceinline__ void load_geom(const Hot& hot, const ColdRef cold, in
         g.n_seg = *WEDM_ROW(gp.i32, WEDM_GI_N_SEG);
         g.az_start = *WEDM_ROW(gp.i32, WEDM_GI_AZ_START); g.az_end = *WEDM_ROW(gp.i32, WEDM_GI_AZ_END);
         g.cb = *WEDM_ROW(gp.i32, WEDM_GI_CONTACT_BOTTOM); g.ct = *WEDM_ROW(gp.i32, WEDM_GI_CONTACT_TOP);
+        g.k64 = *WEDM_ROW(gp.f64, WEDM_G_K_COND); g.tuf64 = *WEDM_ROW(gp.f64, WEDM_G_TUF);
+        g.a64 = *WEDM_ROW(gp.f64, WEDM_G_A_SURF);
     } else {
         const wedm_params* p = c->p;
         g.cavity_coeff = p->cavity_coeff;
         g.k = (float)p->k_cond; g.tuf = (float)p->tuf;
         g.n_seg = p->n_seg; g.az_start = p->az_start; g.az_end = p->az_end;
         g.cb = p->contact_bottom; g.ct = p->contact_top;
+        g.k64 = p->k_cond; g.tuf64 = p->tuf; g.a64 = p->a_surf;
     }
 }
 
@@ -565,6 +589,7 @@ __device__ __forceinline__ void init_persist(const Hot& hot, const ColdRef cold,
     }
     ps.adv_on = __builtin_fabs(adv) > 1e-9;  // wire.py:115
     ps.adv = ps.adv_on ? (float)adv : 0.0f;
+    ps.adv64 = ps.adv_on ? adv : 0.0;
     refresh_convection(hot, cold, e, s, ps);
 }
 
@@ -765,6 +790,7 @@ __device__ __forceinline__ Coef scalar_prelude(const Hot& p, const ColdRef cold,
         }
         cf.pidx = -1;
         cf.q = 0.0f;
+        cf.q64 = 0.0;
         if (s.state == 1 && s.y == s.y) {
             const wedm_params* c = opaque(cold->p);
             const int zone_start = WEDM_COLD_GEOM_I32(cold, p, WEDM_GI_ZONE_START, zone_start);
@@ -772,14 +798,17 @@ __device__ __forceinline__ Coef scalar_prelude(const Hot& p, const ColdRef cold,
             int idx = seg != 0 ? zone_start + (int)py_floordiv(s.y, seg) : zone_start;
             if (idx >= 0 && idx < g.n_seg) {
                 cf.pidx = idx;
-                cf.q = (float)(c->plasma_efficiency * s.V * I);
+                cf.q64 = c->plasma_efficiency * s.V * I;
+                cf.q = (float)cf.q64;
             }
         }
         cf.joule_on = I2 > 1e-6;
         cf.jf = 0.0f;
+        cf.jf64 = 0.0;
         if (cf.joule_on) {
             const double joule_geom = WEDM_COLD_GEOM_F64(cold, p, WEDM_G_JOULE_GEOM, joule_geom);
-            cf.jf = (float)(joule_geom * I2 * opaque(cold->p)->rho_elec);
+            cf.jf64 = joule_geom * I2 * opaque(cold->p)->rho_elec;
+            cf.jf = (float)cf.jf64;
         }
     }
     return cf;
@@ -877,6 +906,29 @@ __device__ __forceinline__ float stencil_cell(int i, int n_seg, float tm1, float
     d = d - conv * (tc - tdiel);
     if (ps.adv_on) d = d + ps.adv * (tm1 - tc);
     return tc + d * g.tuf;
+}
+
+// The same cell as Numba types wire.py:58-123 (`@njit`: float32 array elements promoted to float64 in
+// every expression, the result rounded where it is stored into the float32 `dT_dt[i]` / `T[i]`; without
+// fastmath re-association) — wedm_params.stencil_mode 1.  h_base / h_zone are the float32 `h_eff_zone`
+// entries (wire.py:205), everything else float64 constants.
+__device__ __forceinline__ float stencil_cell_f64(int i, int n_seg, float tm1, float tc, float tp1, const Geom& g,
+                                                  const Coef& c, const Persist& ps, const Hot& h, float h_base,
+                                                  float h_zone) {
+    const double m = (double)tm1, t = (double)tc;
+    float d;
+    if (i < n_seg - 1) d = (float)(g.k64 * (m - 2.0 * t + (double)tp1));
+    else d = (float)(g.k64 * (m - t));
+    if (c.joule_on && i >= g.cb && i <= g.ct) {
+        const double rho_T = 1.0 + h.alpha64 * (t - h.tref64);
+        d = (float)((double)d + c.jf64 * rho_T);
+    }
+    if (i == c.pidx) d = (float)((double)d + c.q64);
+    const bool in_zone = (i >= g.az_start) && (i < g.az_end);
+    const double conv = (double)(in_zone ? h_zone : h_base) * g.a64;
+    d = (float)((double)d - conv * (t - h.tdiel64));
+    if (ps.adv_on) d = (float)((double)d + ps.adv64 * (m - t));
+    return (float)(t + (double)d * g.tuf64);
 }
 
 // ------------------------------------------- scalar epilogue (modules 4b, 5, env)

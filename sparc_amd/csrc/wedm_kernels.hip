@@ -121,9 +121,10 @@ struct GlobalT {
 // One in-place pass of wire.py:58-123 over the lane's wire.  Tiles of 8 cells: the 8
 // "next" temperatures are loaded before any of the tile's stores, so every cell sees
 // OLD neighbours (explicit Euler) with one load + one store per cell.
-template <class TA>
-__device__ __forceinline__ float stencil_pass(const TA& T, const Geom& g, const Coef& c, const Persist& ps,
-                                              float spool, float tref, float alpha, float tdiel) {
+template <bool F64, class TA>
+__device__ __forceinline__ float stencil_pass(const TA& T, const Geom& g, const Coef& c, const Persist& ps, const Hot& hot,
+                                              float h_base, float h_zone) {
+    const float spool = hot.spool, tref = hot.tref, alpha = hot.alpha, tdiel = hot.tdiel;
     const int n = g.n_seg;
     T.st(0, spool);  // boundary condition (wire.py:83,123)
     float tmax = spool;
@@ -141,7 +142,9 @@ __device__ __forceinline__ float stencil_pass(const TA& T, const Geom& g, const 
         for (int u = 0; u < 8; ++u) {
             int i = i0 + u;
             if (i < n) {
-                float tn = stencil_cell(i, n, tm1, tc, nx[u], g, c, ps, tref, alpha, tdiel);
+                float tn;
+                if (F64) tn = stencil_cell_f64(i, n, tm1, tc, nx[u], g, c, ps, hot, h_base, h_zone);
+                else tn = stencil_cell(i, n, tm1, tc, nx[u], g, c, ps, tref, alpha, tdiel);
                 T.st(i, tn);
                 tmax = tn > tmax ? tn : tmax;
                 tm1 = tc;
@@ -152,7 +155,7 @@ __device__ __forceinline__ float stencil_pass(const TA& T, const Geom& g, const 
     return tmax;
 }
 
-template <bool TRACE, class TA>
+template <bool TRACE, bool F64, class TA>
 __device__ __forceinline__ void run_substeps(const KArgs& k, const ColdRef cold, const Geom& g, int64_t e,
                                              uint32_t gid, Env& s, const TA& T) {
     Persist ps;
@@ -163,7 +166,7 @@ __device__ __forceinline__ void run_substeps(const KArgs& k, const ColdRef cold,
     for (int it = 0; it < k.n_substeps; ++it) {
         if (!s.done) {
             Coef c = scalar_prelude(k.hot, cold, g, e, gid, s, ps, true);  // single steps: the quiet test does not pay
-            float tmax = stencil_pass(T, g, c, ps, k.hot.spool, k.hot.tref, k.hot.alpha, k.hot.tdiel);
+            float tmax = stencil_pass<F64>(T, g, c, ps, k.hot, s.h_base, s.h_zone);
             scalar_epilogue(k.hot, s, tmax);
             if (s.ctrl) control_step_outputs(cold, e, s, true);
         } else if (!tracing) {
@@ -174,7 +177,7 @@ __device__ __forceinline__ void run_substeps(const KArgs& k, const ColdRef cold,
     }
 }
 
-template <bool TRACE>
+template <bool TRACE, bool F64>
 __global__ void __launch_bounds__(256) wedm_step_global(const KArgs k) {
     const ColdRef cold = kernarg_cold();
     const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -192,7 +195,7 @@ __global__ void __launch_bounds__(256) wedm_step_global(const KArgs k) {
     s.ipk = s.done ? 0.0 : peak_current(cold, s.mode);
     Geom g;
     load_geom(k.hot, cold, e, g);
-    run_substeps<TRACE>(k, cold, g, e, k.hot.env_id_offset + (uint32_t)e, s, T);
+    run_substeps<TRACE, F64>(k, cold, g, e, k.hot.env_id_offset + (uint32_t)e, s, T);
     if (k.hot.reward_mode && !frozen) write_reward(cold, e, s);
     store_env(cold, e, s);
 }
@@ -379,6 +382,24 @@ __global__ void __launch_bounds__(256) wedm_step_split(const KArgs k) {
 //   * two barriers per microsecond (coefficients out, chunk maxima back).
 // T is updated in place: every OLD value a lane needs from a neighbouring chunk is in its registers before
 // the first barrier, and stores only happen after it.
+#ifdef WEDM_STAMPS
+#define WEDM_S2_STAMP_DECL unsigned long long sst[8] = {0, 0, 0, 0, 0, 0, 0, 0}; \
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(sst[7])::"memory")
+#define WEDM_S2_STAMP(i) do { __builtin_amdgcn_sched_barrier(0); \
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(sst[i])::"memory"); \
+    __builtin_amdgcn_sched_barrier(0); } while (0)
+#define WEDM_S2_STAMP_VM(i) do { __builtin_amdgcn_sched_barrier(0); \
+    asm volatile("s_waitcnt vmcnt(0)\n\ts_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(sst[i])::"memory"); \
+    __builtin_amdgcn_sched_barrier(0); } while (0)
+#define WEDM_S2_STAMP_OUT() do { if (k.dbg && (threadIdx.x & 63) == 0) { \
+    unsigned long long* o = k.dbg + ((size_t)blockIdx.x * 4 + (threadIdx.x >> 6)) * 8; \
+    for (int q = 0; q < 8; ++q) o[q] = sst[q]; } } while (0)
+#else
+#define WEDM_S2_STAMP_DECL do { } while (0)
+#define WEDM_S2_STAMP(i) do { } while (0)
+#define WEDM_S2_STAMP_VM(i) do { } while (0)
+#define WEDM_S2_STAMP_OUT() do { } while (0)
+#endif
 #define WEDM_S2_WALKERS 3
 #define WEDM_S2_PRE 44  // cells whose rows are requested before the scalar phase (128 segments: 43 per walker)
 template <bool TRACE, int OCC>
@@ -402,6 +423,7 @@ __global__ void __launch_bounds__(256, OCC) wedm_step_split2(const KArgs k) {
     load_geom(k.hot, cold, live ? e : 0, g);
     int trace_next = k.trace_next, trace_slot = k.trace_slot;
     (void)trace_next; (void)trace_slot;
+    WEDM_S2_STAMP_DECL;
 
     if (w == 0) {
         // ================================================= wave 0: the scalar physics of 64 environments
@@ -423,6 +445,7 @@ __global__ void __launch_bounds__(256, OCC) wedm_step_split2(const KArgs k) {
         double wp0 = 0.0;  // workpiece position at the start of the launch (reward)
         if (k.hot.reward_mode && !frozen0) wp0 = s.wp;
         bool quiet_only = true;
+        WEDM_S2_STAMP_VM(0);  // state loaded
         for (int it = 0; it < k.n_substeps; ++it) {
             const bool last = it + 1 == k.n_substeps;
             Coef cf{0.0f, 0.0f, 0, -1};
@@ -437,11 +460,14 @@ __global__ void __launch_bounds__(256, OCC) wedm_step_split2(const KArgs k) {
             sh_f[0][el] = cf.jf; sh_f[1][el] = cf.q; sh_f[2][el] = ps.conv_base; sh_f[3][el] = ps.conv_zone;
             sh_f[4][el] = ps.adv;
             sh_i[0][el] = cf.joule_on; sh_i[1][el] = cf.pidx; sh_i[2][el] = ps.adv_on; sh_i[3][el] = s.done;
+            WEDM_S2_STAMP(1);  // prelude done
             __syncthreads();  // (1) coefficients out
+            WEDM_S2_STAMP(2);
             // rows that are final now leave while the walkers work (last microsecond of the launch only:
             // before that the state stays in registers)
             if (last && live && !frozen0) store_env_after_prelude(cold, e, s, quiet_only);
             __syncthreads();  // (2) chunk maxima back
+            WEDM_S2_STAMP(3);
             if (!s.done) {
                 float m = sh_max[0][el];
 #pragma unroll
@@ -463,8 +489,11 @@ __global__ void __launch_bounds__(256, OCC) wedm_step_split2(const KArgs k) {
                 const double pen = opaque(cold->p)->reward_break_penalty;
                 cold->s.reward[e] = (float)(s.wp - wp0) - (float)pen * (s.broken ? 1.0f : 0.0f);
             }
+            WEDM_S2_STAMP(4);  // epilogue done
             store_env_after_epilogue(cold, e, s);
         }
+        WEDM_S2_STAMP_VM(5);  // stored
+        WEDM_S2_STAMP_OUT();
         return;
     }
 
@@ -492,6 +521,7 @@ __global__ void __launch_bounds__(256, OCC) wedm_step_split2(const KArgs k) {
         }
     };
     request_rows();  // in flight while wave 0 loads the state and computes
+    WEDM_S2_STAMP(0);  // rows requested
     if (reinit) {    // next-step autoreset: this lane's rows of the wire, all n_seg_max of them
         const int f1 = (i0 + C < k.n_seg_max) ? i0 + C : k.n_seg_max;
         for (int i = i0; i < f1; ++i) T.st(i, spool);
@@ -502,7 +532,12 @@ __global__ void __launch_bounds__(256, OCC) wedm_step_split2(const KArgs k) {
     for (int it = 0; it < k.n_substeps; ++it) {
         const bool last = it + 1 == k.n_substeps;
         if (it > 0) request_rows();  // behind barrier (3)
+        WEDM_S2_STAMP(1);
         __syncthreads();  // (1)
+        WEDM_S2_STAMP(2);
+#ifdef WEDM_STAMPS
+        WEDM_S2_STAMP_VM(3);  // rows landed
+#endif
         const Coef cf{sh_f[0][el], sh_f[1][el], sh_i[0][el], sh_i[1][el]};
         const Persist pw{sh_f[4][el], sh_f[2][el], sh_f[3][el], sh_i[2][el]};
         const bool skip = sh_i[3][el] != 0;
@@ -550,7 +585,9 @@ __global__ void __launch_bounds__(256, OCC) wedm_step_split2(const KArgs k) {
             }
         }
         sh_max[c][el] = tmax;
+        WEDM_S2_STAMP(4);  // cells computed, stores issued
         __syncthreads();  // (2)
+        WEDM_S2_STAMP(5);
         if (TRACE && it == trace_next) {  // wave-uniform schedule; T rows of the step just finished
             const wedm_trace_desc& tr = k.trace;
             const int64_t tcol = live ? trace_column(tr, e) : -1;
@@ -564,6 +601,8 @@ __global__ void __launch_bounds__(256, OCC) wedm_step_split2(const KArgs k) {
         }
         if (!last) __syncthreads();  // (3)
     }
+    WEDM_S2_STAMP_VM(6);  // stores landed
+    WEDM_S2_STAMP_OUT();
 }
 
 
@@ -571,7 +610,7 @@ __global__ void __launch_bounds__(256, OCC) wedm_step_split2(const KArgs k) {
 // predicated formula with the lane's own n_seg / zone / contact indices.  LDS layout and halo
 // exchange as in the fused kernels; the chunk length is uniform, C = ceil(n_seg_max / L), so an
 // environment with a shorter wire simply leaves the tail of its last chunks unused.
-template <int L, bool TRACE>
+template <int L, bool TRACE, bool F64>
 __global__ void __launch_bounds__(256, 2) wedm_step_lanes(const KArgs k) {
     const ColdRef cold = kernarg_cold();
 #ifndef WEDM_NO_PIN_LANES
@@ -651,8 +690,11 @@ __global__ void __launch_bounds__(256, 2) wedm_step_lanes(const KArgs k) {
                 if (j < C) {
                     const int i = cbase + j;
                     if (i < n && !s.done) {
-                        const float tn = (i >= 1) ? stencil_cell(i, n, (i == 1) ? spool : tm1, tc, nx[u], g, cf, ps, tref, alpha, tdiel)
-                                                  : spool;
+                        float tn = spool;
+                        if (i >= 1) {
+                            if (F64) tn = stencil_cell_f64(i, n, (i == 1) ? spool : tm1, tc, nx[u], g, cf, ps, hv, s.h_base, s.h_zone);
+                            else tn = stencil_cell(i, n, (i == 1) ? spool : tm1, tc, nx[u], g, cf, ps, tref, alpha, tdiel);
+                        }
                         col[j * 256] = tn;
                         tmax = fmax_gt(tmax, tn);
                     }
@@ -1089,6 +1131,308 @@ __global__ void __launch_bounds__(256, 2) wedm_step_fused(const KArgs k) {
         if (k.hot.reward_mode && !frozen0) write_reward(cold, e, s);
         store_env(cold, e, s);
     }
+}
+
+
+// ===================================================== stream kernel (1 us / launch, uniform geometry)
+// The reference's own cadence: ONE microsecond per launch, so every byte of state and wire crosses HBM
+// once per launch and the roofline really is HBM.  Measured on the MI355X (tools/microbench/rowstream.hip): a
+// bare read-modify-write of the 128 x 65 536 wire block in this [segment][environment] layout takes 7.5 us
+// (one dword per lane, 9 TB/s out of the Infinity Cache), but the split kernel needs 30 us, because every wave
+// is a chain of dependent round trips — state loads, scalar prelude, barrier, batches of rows behind
+// `s_waitcnt vmcnt(0)`, barrier, epilogue — at two waves per SIMD, in two rounds of blocks that move in lock
+// step.  Stamped variants on the way here (tools/stamps_stream.py): requesting the rows by LDS-DMA costs ~200
+// cycles of issue per `global_load_lds_dword` (13 900 cycles for 64 rows), a row-by-row write-back 125 cycles per
+// row.  This kernel has ONE memory round trip for everything it reads and no barrier:
+//   * L lanes of ONE wave share an environment, as in the fused kernels (scalar physics replicated, halos
+//     from the neighbour lane's column, DPP max reduction);
+//   * at its very first instructions every lane requests its whole chunk into registers (CMAX unconditional
+//     `global_load_dword`s from clamped addresses: a count the compiler can see, so no conservative waits)
+//     and then the state rows a microsecond reads; when both have landed the chunk is dropped into the lane's
+//     LDS column and the tile walk of wedm_step_fused runs on it;
+//   * the write-back goes out 16 rows at a time (16 LDS reads, then 16 stores), fire and forget; only the state
+//     rows a microsecond can have changed are stored (store_env_after_*), and a wave whose steps were all quiet
+//     skips the rows the quiet prelude cannot change.
+// Every wave is its own pipeline, so the loads, arithmetic and stores of different waves overlap by themselves.
+#define WEDM_LDS __attribute__((address_space(3)))
+#define WEDM_GLOBAL __attribute__((address_space(1)))
+template <int L, bool TRACE, int CMAX>
+__global__ void __launch_bounds__(256, 2) wedm_step_stream(const KArgs k) {
+    const ColdRef cold = kernarg_cold();
+    const Hot& hv = k.hot;  // not pinned in VGPRs: the registers hold the wire rows in flight instead
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    constexpr int EPB = 256 / L;  // environments per block
+    const int tid = threadIdx.x;
+    const int el = tid / L, c = tid % L;
+    const int64_t e0 = (int64_t)blockIdx.x * EPB;
+    const int64_t e = e0 + el;
+    const bool live = e < k.num_envs;
+    const WalkTable* __restrict__ wt = k.walk;
+    const int C = wt->C;
+    const int n = k.hot.n_seg;
+    const int64_t stride = cold->s.stride;
+
+    const int cbase = c * C;
+    float* col = lds + tid;
+    const int jn = (!live) ? 0 : ((C < n - cbase) ? C : n - cbase);  // cells of this chunk that exist (<= 0: none)
+    WEDM_S2_STAMP_DECL;
+
+    // (1) the state rows a microsecond reads: requested FIRST, so that the scalar prelude can start as soon as
+    // they are back (the vmcnt counter is in order: the wait for them leaves the wire loads in flight)
+    Env s;
+    Geom g;
+    Persist ps{0.0f, 0.0f, 0.0f, 0};
+    load_geom(k.hot, cold, live ? e : 0, g);
+    if (live) {
+        if (TRACE) load_env(cold, e, s);  // frozen environments are sampled too: every row
+        else load_env_inputs(cold, e, s, !k.hot.disable_ignition);
+    } else {
+        s.done = 1; s.unwind = 0.0; s.h_base = 0.0f; s.h_zone = 0.0f;
+    }
+    // (2) the wire: the lane's whole chunk into registers.  Rows past the chunk repeat its last row (a lane
+    // without cells reads row 0): every load is unconditional and from a valid address, so the compiler can
+    // count them and waits for each row only where it is first used.
+    float w[CMAX];
+    {
+        const int jmax = jn > 0 ? jn - 1 : 0;
+        const float* src = cold->s.T + (int64_t)(jn > 0 ? cbase : 0) * stride + (live ? e : 0);
+#pragma unroll
+        for (int j = 0; j < CMAX; ++j) w[j] = src[(int64_t)(j < jmax ? j : jmax) * stride];
+    }
+    WEDM_S2_STAMP(0);  // everything requested
+    // next-step autoreset (all L lanes of the environment agree)
+    const bool reinit = live && s.done && k.hot.autoreset;
+    if (reinit) reinit_env(cold, e, s, c == 0);
+    const bool frozen0 = s.done;
+    double wp0 = 0.0;  // workpiece position at the start of the launch (reward)
+    if (k.hot.reward_mode && !frozen0) wp0 = s.wp;
+    if (!s.done) {
+        s.ipk = peak_current(cold, s.mode);
+        init_persist(k.hot, cold, e, s, ps);
+    }
+    const uint32_t gid = k.hot.env_id_offset + (uint32_t)e;
+
+    const float spool = k.hot.spool, tref = k.hot.tref, alpha = k.hot.alpha, tdiel = k.hot.tdiel;
+    const int n_tiles = wt->n_tiles;
+    // per-lane tile membership, gathered once (see wedm_step_fused)
+    uint32_t zone_lo = 0u, joule_lo = 0u, zone_hi = 0u, joule_hi = 0u, kind_n = 0u, kind_s = 0u;
+    uint32_t split_pack[3] = {0u, 0u, 0u};  // 4 bits per tile (WEDM_MAX_TILES <= 24)
+    for (int t = 0; t < n_tiles; ++t) {
+        const uint32_t lo = wt->zj[8 * t], hi = wt->zj[8 * t + 7], kd = wt->kind[t];
+        split_pack[t >> 3] |= (wt->split[t] & 15u) << ((t & 7) * 4);
+        zone_lo |= ((lo >> c) & 1u) << t;
+        joule_lo |= ((lo >> (16 + c)) & 1u) << t;
+        zone_hi |= ((hi >> c) & 1u) << t;
+        joule_hi |= ((hi >> (16 + c)) & 1u) << t;
+        kind_n |= (kd == TILE_N ? 1u : 0u) << t;
+        kind_s |= (kd == TILE_S ? 1u : 0u) << t;
+    }
+    kind_n = __builtin_amdgcn_readfirstlane(kind_n);
+    kind_s = __builtin_amdgcn_readfirstlane(kind_s);
+#pragma unroll
+    for (int q = 0; q < 3; ++q) split_pack[q] = __builtin_amdgcn_readfirstlane(split_pack[q]);
+    // the lane that owns the wire's last cell (Neumann boundary, wire.py:95)
+    const bool owns_last = (n >= 2) && (n - 1 >= cbase) && (n - 1 < cbase + C);
+
+    const bool tracing = WEDM_TRACING(k);
+    int trace_next = k.trace_next, trace_slot = k.trace_slot;
+    (void)trace_next; (void)trace_slot;
+    bool quiet_only = true;
+    for (int it = 0; it < k.n_substeps; ++it) {
+        if (__all(s.done) && !tracing) break;
+        Coef cf{0.0f, 0.0f, 0, -1};
+        if (!quiet_prelude(hv, g, gid, s)) {
+            quiet_only = false;
+            if (!s.done) cf = scalar_prelude(hv, cold, g, e, gid, s, ps, c == 0);
+        }
+        if (it == 0) {
+            WEDM_S2_STAMP(1);  // prelude done
+            // (3) the chunk into the lane's LDS column, behind the first prelude: the wire has been streaming in
+            // underneath it (each row is waited for where it is written)
+#pragma unroll
+            for (int j = 0; j < CMAX; ++j)
+                if (j < C) col[j * 256] = reinit ? spool : w[j];
+            if (c == 0) col[0] = spool;  // wire cell 0 is held at the spool temperature (wire.py:83)
+            WEDM_S2_STAMP(2);  // wire in LDS
+        }
+        // ---- halos: OLD neighbour values, read before any lane of this wave stores.  The right
+        // halo goes into the chunk's extra LDS row C, so cell C-1 is walked like any other.
+        const float halo_l = (c > 0) ? col[(C - 1) * 256 - 1] : spool;
+        const float halo_r = (c < L - 1) ? col[1] : 0.0f;
+        col[C * 256] = halo_r;
+
+        // a wave with a frozen environment (or a negative plasma heat) walks every cell on the
+        // predicated path; results are identical, only slower
+        const bool all_slow = __any(cf.q < 0.0f) || __any(s.done);
+        const uint32_t slow_now = all_slow ? 0xffffffffu : kind_s;
+
+        // ---- patched cells: the plasma cell and the wire's last cell are computed with the
+        // full predicated formula from OLD values now and written after the walk
+        const bool owns_pl = !s.done && cf.pidx >= 1 && cf.pidx >= cbase && cf.pidx < cbase + C;
+        float tpl = 0.0f, tlast = 0.0f;
+        if (__any(owns_pl)) {
+            if (owns_pl) {
+                const int jp = cf.pidx - cbase;
+                float tm = jp > 0 ? col[(jp - 1) * 256] : halo_l;
+                if (cf.pidx == 1) tm = spool;
+                const float tcc = col[jp * 256];
+                const float tp = jp < C - 1 ? col[(jp + 1) * 256] : halo_r;
+                tpl = stencil_cell(cf.pidx, n, tm, tcc, tp, g, cf, ps, tref, alpha, tdiel);
+            }
+        }
+        if (owns_last && !s.done) {
+            const int jl = n - 1 - cbase;
+            float tm = jl > 0 ? col[(jl - 1) * 256] : halo_l;
+            if (n - 1 == 1) tm = spool;
+            tlast = stencil_cell(n - 1, n, tm, col[jl * 256], 0.0f, g, cf, ps, tref, alpha, tdiel);
+        }
+
+        float tmax = spool;
+        float tm1 = halo_l;
+        float tc = col[0];
+        {
+            const float jf_lane = (cf.joule_on && !s.done) ? cf.jf : 0.0f;
+            const bool joule_wave = __any(jf_lane != 0.0f);
+
+            // tile t covers cells j = 8t..8t+7; cur[u] = OLD T[j+1+u]; `nxt` is loaded one tile ahead
+            // CLAMP = false: all eight rows exist (j + 8 <= C), one base address + immediate offsets
+            auto load8 = [&](auto clamp, float (&dst)[8], int j) {
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    int row = j + 1 + u;
+                    if (decltype(clamp)::value) row = row < C ? row : C;  // rows past the chunk are never used; row C is the halo
+                    dst[u] = col[row * 256];
+                }
+            };
+            auto tile = [&](int t, float (&cur)[8], float (&nxt)[8]) {
+                const int j = 8 * t;
+                (void)nxt;
+                load8(std::true_type{}, cur, j);  // (an unclamped variant for full tiles pays in the packed kernel only)
+                const float conv_lo = ((zone_lo >> t) & 1u) ? ps.conv_zone : ps.conv_base;
+                const float jfe_lo = ((joule_lo >> t) & 1u) ? jf_lane : 0.0f;
+                if (((kind_n & ~slow_now) >> t) & 1u) {
+                    float old[10], tn[8], cv[8], jv[8];
+                    old[0] = tm1; old[1] = tc;
+#pragma unroll
+                    for (int u = 0; u < 8; ++u) old[u + 2] = cur[u];
+                    cv[0] = conv_lo; jv[0] = jfe_lo;
+                    if (joule_wave && __any(jfe_lo != 0.0f))
+                        tile8_staged<float, true, false>(old, tn, g.k, g.tuf, cv, tdiel, ps.adv, jv, alpha, tref);
+                    else
+                        tile8_staged<float, false, false>(old, tn, g.k, g.tuf, cv, tdiel, ps.adv, jv, alpha, tref);
+#pragma unroll
+                    for (int u = 0; u < 8; ++u) col[(j + u) * 256] = tn[u];
+                    float m0 = fmax_gt(tn[0], tn[1]), m1 = fmax_gt(tn[2], tn[3]);
+                    m0 = fmax_gt(m0, fmax_gt(tn[4], tn[5]));
+                    m1 = fmax_gt(m1, fmax_gt(tn[6], tn[7]));
+                    tmax = fmax_gt(tmax, fmax_gt(m0, m1));
+                    tm1 = cur[6];
+                    tc = cur[7];
+                } else if (!((slow_now >> t) & 1u)) {
+                    // TILE_B: interior formula everywhere, one flag change at `split`, boundary and
+                    // out-of-wire cells excluded from the max (they are patched / never read)
+                    const int split = (int)((split_pack[t >> 3] >> ((t & 7) * 4)) & 15u);
+                    const int cnt = (C - j) < 8 ? (C - j) : 8;
+                    const float conv_hi = ((zone_hi >> t) & 1u) ? ps.conv_zone : ps.conv_base;
+                    const float jfe_hi = ((joule_hi >> t) & 1u) ? jf_lane : 0.0f;
+                    const uint32_t im1 = (uint32_t)(cbase + j - 1);  // (i - 1) of the tile's first cell
+                    const uint32_t span = (uint32_t)(n - 3);         // interior <=> (i - 1) <= n - 3 (unsigned)
+#pragma unroll
+                    for (int u = 0; u < 8; ++u) {
+                        if (u < cnt) {
+                            const float conv = u < split ? conv_lo : conv_hi;
+                            const float jfe = u < split ? jfe_lo : jfe_hi;
+                            float tn = interior_cell<true>(tm1, tc, cur[u], g.k, g.tuf, conv, tdiel, ps.adv, jfe, alpha, tref);
+                            col[(j + u) * 256] = tn;
+                            const bool inter = (n >= 3) && (im1 + (uint32_t)u <= span);
+                            tmax = inter ? fmax_gt(tmax, tn) : tmax;
+                            tm1 = tc;
+                            tc = cur[u];
+                        }
+                    }
+                } else {
+#pragma unroll 1
+                    for (int u = 0; u < 8; ++u) {
+                        const int jj = j + u;
+                        const uint32_t zj = wt->zj[jj], iv = wt->iv[jj];
+                        const bool zbit = (zj >> c) & 1u, jbit = (zj >> (16 + c)) & 1u;
+                        const bool inter = ((iv >> c) & 1u) && !all_slow;
+                        const bool valid = ((iv >> (16 + c)) & 1u) && !s.done;
+                        const float conv = zbit ? ps.conv_zone : ps.conv_base;
+                        const float jfe = jbit ? jf_lane : 0.0f;
+                        const float tp1 = cur[0];
+                        float tn = interior_cell<true>(tm1, tc, tp1, g.k, g.tuf, conv, tdiel, ps.adv, jfe, alpha, tref);
+                        if (!inter && valid) {  // boundary cells and irregular waves: predicated formula
+                            const int i = cbase + jj;
+                            tn = (i >= 1) ? stencil_cell(i, n, (i == 1) ? spool : tm1, tc, tp1, g, cf, ps, tref, alpha, tdiel)
+                                          : spool;
+                        }
+                        if (valid) {
+                            col[jj * 256] = tn;
+                            tmax = fmax_gt(tmax, tn);
+                        }
+                        tm1 = tc;
+                        tc = tp1;
+                        // rotate the prefetch window (this fallback is rare; keep its code small)
+                        float* w = const_cast<float*>(&cur[0]);
+                        float first = w[0];
+#pragma unroll
+                        for (int q = 0; q < 7; ++q) w[q] = w[q + 1];
+                        w[7] = first;
+                    }
+                }
+            };
+            float bufA[8];
+            for (int t = 0; t < n_tiles; ++t) tile(t, bufA, bufA);
+        }
+        // ---- patches (after every store of the walk): boundary condition, last cell, plasma cell
+        if (c == 0 && !s.done) col[0] = spool;
+        if (owns_last && !s.done) {
+            col[(n - 1 - cbase) * 256] = tlast;
+            tmax = fmax_gt(tmax, tlast);
+        }
+        if (owns_pl) {
+            col[(cf.pidx - cbase) * 256] = tpl;
+            tmax = fmax_gt(tmax, tpl);
+        }
+#pragma unroll
+        for (int m = 1; m < L; m <<= 1) tmax = fmax_gt(tmax, __shfl_xor(tmax, m));
+        if (!s.done) {
+            scalar_epilogue(hv, s, tmax);
+            if (s.ctrl) control_step_outputs(cold, e, s, c == 0);
+        }
+        WEDM_TRACE_POINT(k, it, e, s, c == 0,
+                         for (int j = 0; j < C && cbase + j < n; ++j) tT[(int64_t)(cbase + j) * tcnt] = col[j * 256]);
+    }
+
+    WEDM_S2_STAMP(4);  // walk + epilogue done
+    // ---- write-back: each lane its own chunk, 16 rows at a time (16 LDS reads in flight, then 16 stores);
+    // the L lanes of an environment are in one wave: nothing to wait for
+    if (!frozen0) {
+        float* dst = cold->s.T + (int64_t)cbase * stride + (live ? e : 0);
+#pragma unroll
+        for (int j0 = 0; j0 < CMAX; j0 += 16) {
+            if (j0 < C) {
+                float v[16];
+#pragma unroll
+                for (int u = 0; u < 16; ++u) v[u] = col[((j0 + u < C) ? j0 + u : C - 1) * 256];
+#pragma unroll
+                for (int u = 0; u < 16; ++u)
+                    if (j0 + u < jn) dst[(int64_t)(j0 + u) * stride] = v[u];
+            }
+        }
+    }
+    if (live && c == 0 && !frozen0) {
+        if (k.hot.reward_mode && cold->s.reward) {
+            const double pen = opaque(cold->p)->reward_break_penalty;
+            cold->s.reward[e] = (float)(s.wp - wp0) - (float)pen * (s.broken ? 1.0f : 0.0f);
+        }
+        store_env_after_prelude(cold, e, s, quiet_only);
+        store_env_after_epilogue(cold, e, s);
+    }
+    WEDM_S2_STAMP(5);     // stores issued
+    WEDM_S2_STAMP_VM(6);  // stores landed
+    WEDM_S2_STAMP_OUT();
 }
 
 
@@ -1569,13 +1913,13 @@ static bool build_walk(const wedm_params& p, int L, WalkTable& t) {
     return true;
 }
 
-template <bool TR> static const void* pick_lanes(int L) {
+template <bool TR, bool F64> static const void* pick_lanes(int L) {
     switch (L) {
-        case 1: return (const void*)wedm_step_lanes<1, TR>;
-        case 2: return (const void*)wedm_step_lanes<2, TR>;
-        case 4: return (const void*)wedm_step_lanes<4, TR>;
-        case 8: return (const void*)wedm_step_lanes<8, TR>;
-        default: return (const void*)wedm_step_lanes<16, TR>;
+        case 1: return (const void*)wedm_step_lanes<1, TR, F64>;
+        case 2: return (const void*)wedm_step_lanes<2, TR, F64>;
+        case 4: return (const void*)wedm_step_lanes<4, TR, F64>;
+        case 8: return (const void*)wedm_step_lanes<8, TR, F64>;
+        default: return (const void*)wedm_step_lanes<16, TR, F64>;
     }
 }
 template <bool TR> static const void* pick_fused(int L) {
@@ -1585,6 +1929,16 @@ template <bool TR> static const void* pick_fused(int L) {
         case 4: return (const void*)wedm_step_fused<4, TR>;
         case 8: return (const void*)wedm_step_fused<8, TR>;
         default: return (const void*)wedm_step_fused<16, TR>;
+    }
+}
+// rows a lane of the stream kernel holds in registers: 64 (128 segments over 2 lanes, 400 over 8) or 104 (400 over 4)
+template <bool TR, int CMAX> static const void* pick_stream(int L) {
+    switch (L) {
+        case 1: return (const void*)wedm_step_stream<1, TR, CMAX>;
+        case 2: return (const void*)wedm_step_stream<2, TR, CMAX>;
+        case 4: return (const void*)wedm_step_stream<4, TR, CMAX>;
+        case 8: return (const void*)wedm_step_stream<8, TR, CMAX>;
+        default: return (const void*)wedm_step_stream<16, TR, CMAX>;
     }
 }
 template <bool TR> static const void* pick_packed(int L) {
@@ -1776,7 +2130,7 @@ int64_t wedm_trace_samples(wedm_ctx* ctx) { return ctx ? ctx->trace_count : 0; }
 
 int32_t wedm_set_kernel(wedm_ctx* ctx, int32_t variant) {
     if (!ctx) return WEDM_ERR_BAD_ARG;
-    if (variant < 0 || variant > 8) return fail(ctx, WEDM_ERR_BAD_ARG, "wedm_set_kernel: variant must be 0..8");
+    if (variant < 0 || variant > 9) return fail(ctx, WEDM_ERR_BAD_ARG, "wedm_set_kernel: variant must be 0..9");
     ctx->variant = variant;
     return WEDM_OK;
 }
@@ -1845,6 +2199,7 @@ int32_t wedm_step(wedm_ctx* ctx, int32_t n_substeps, const wedm_action_ptrs* act
     h.has_random_short = P.random_short_max_probability != 0.0 ? 1 : 0;
     h.per_env_geometry = P.per_env_geometry; h.env_id_offset = P.env_id_offset; h.n_seg = P.n_seg;
     h.autoreset = P.autoreset; h.reward_mode = (P.reward_mode && ctx->s.reward) ? 1 : 0;
+    h.spool64 = P.spool_T; h.tref64 = P.temp_ref; h.alpha64 = P.alpha_rho; h.tdiel64 = P.dielectric_temperature;
     k.cold.p = ctx->params_dev;
     k.cold.g = ctx->g;
     k.cold.a = *action;
@@ -1923,7 +2278,29 @@ int32_t wedm_step(wedm_ctx* ctx, int32_t n_substeps, const wedm_action_ptrs* act
         }
     }
     const bool lanes_ok = glanes > 0;
+    // kernel 9 (stream, single microseconds, uniform geometry): the caller's lane count, else the smallest L whose
+    // chunk the tile table covers, raised until the launch has ~2 waves per SIMD
+    int slanes = 0;
+    if (uniform) {
+        const int Ls[5] = {1, 2, 4, 8, 16};
+        for (int i = 0; i < 5; ++i) {
+            if (!ctx->walk_ok[i] || ctx->walk_C[i] > 104 || ((size_t)ctx->walk_C[i] + 1) * 1024 > (size_t)ctx->lds_limit) continue;
+            if (ctx->lanes) { if (Ls[i] == ctx->lanes) slanes = Ls[i]; continue; }
+            slanes = Ls[i];
+            const long waves = (long)((ctx->num_envs + (256 / Ls[i]) - 1) / (256 / Ls[i])) * 4;
+            if (waves >= 2048) break;
+        }
+    }
+    const bool stream_ok = slanes > 0;
     int variant = ctx->variant;
+    const bool f64 = P.stencil_mode != 0;
+    if (f64) {
+        // Numba's typing of the stencil exists in the predicated kernels only (any geometry): LDS-staged when
+        // a chunk fits, else in place in global memory
+        if (variant != 0 && variant != 1 && variant != 2)
+            return fail(ctx, WEDM_ERR_UNSUPPORTED, "wedm_step: stencil_mode 1 (float64 stencil expressions) runs on kernels 1 and 2 only");
+        if (variant == 0) variant = lanes_ok ? 2 : 1;
+    }
     if (variant == 0) {
         // single-microsecond launches: the split global-memory kernel
         if (n_substeps <= 1) variant = 5;
@@ -1937,6 +2314,8 @@ int32_t wedm_step(wedm_ctx* ctx, int32_t n_substeps, const wedm_action_ptrs* act
         return fail(ctx, WEDM_ERR_UNSUPPORTED, "wedm_step: packed kernel needs uniform geometry, lanes in {1,2,4,8} and two chunks that fit in LDS");
     if (variant == 2 && !lanes_ok)
         return fail(ctx, WEDM_ERR_UNSUPPORTED, "wedm_step: no lane count puts a chunk of the wire in LDS");
+    if (variant == 9 && !stream_ok)
+        return fail(ctx, WEDM_ERR_UNSUPPORTED, "wedm_step: stream kernel needs uniform geometry and lanes in {1,2,4,8,16} with a chunk of at most 104 cells");
 
     char name[160];
     const bool tr = ctx->trace_on && k.trace_next < n_substeps;  // a sample falls into this launch
@@ -1945,12 +2324,21 @@ int32_t wedm_step(wedm_ctx* ctx, int32_t n_substeps, const wedm_action_ptrs* act
     size_t fl = 0;
     if (variant == 1) {
         grid = (ctx->num_envs + 255) / 256;
-        fn = tr ? (const void*)wedm_step_global<true> : (const void*)wedm_step_global<false>;
-        std::snprintf(name, sizeof(name), "wedm_step_global<<<%d,256>>> n_sub=%d", grid, n_substeps);
+        fn = f64 ? (tr ? (const void*)wedm_step_global<true, true> : (const void*)wedm_step_global<false, true>)
+                 : (tr ? (const void*)wedm_step_global<true, false> : (const void*)wedm_step_global<false, false>);
+        std::snprintf(name, sizeof(name), "wedm_step_global%s<<<%d,256>>> n_sub=%d", f64 ? "[f64 stencil]" : "", grid, n_substeps);
     } else if (variant == 5) {
         grid = (ctx->num_envs + 63) / 64;
         fn = tr ? (const void*)wedm_step_split<true> : (const void*)wedm_step_split<false>;
         std::snprintf(name, sizeof(name), "wedm_step_split<<<%d,256>>> n_sub=%d", grid, n_substeps);
+    } else if (variant == 9) {
+        const int sli = lanes_index(slanes);
+        grid = (ctx->num_envs + 256 / slanes - 1) / (256 / slanes);
+        fl = ((size_t)ctx->walk_C[sli] + 1) * 1024;
+        k.walk = ctx->walk_dev + sli;
+        fn = ctx->walk_C[sli] <= 64 ? (tr ? pick_stream<true, 64>(slanes) : pick_stream<false, 64>(slanes))
+                                    : (tr ? pick_stream<true, 104>(slanes) : pick_stream<false, 104>(slanes));
+        std::snprintf(name, sizeof(name), "wedm_step_stream<%d><<<%d,256,%zuB>>> n_sub=%d", slanes, grid, fl, n_substeps);
     } else if (variant >= 6) {
         grid = (ctx->num_envs + 63) / 64;
         const int occ = variant - 4;  // 6, 7, 8 -> launch bounds of 2, 3, 4 waves per SIMD
@@ -1961,8 +2349,9 @@ int32_t wedm_step(wedm_ctx* ctx, int32_t n_substeps, const wedm_action_ptrs* act
     } else if (variant == 2) {
         grid = (ctx->num_envs + 256 / glanes - 1) / (256 / glanes);
         fl = (size_t)((ctx->n_seg_max + glanes - 1) / glanes) * 1024;
-        fn = tr ? pick_lanes<true>(glanes) : pick_lanes<false>(glanes);
-        std::snprintf(name, sizeof(name), "wedm_step_lanes<%d><<<%d,256,%zuB>>> n_sub=%d", glanes, grid, fl, n_substeps);
+        fn = f64 ? (tr ? pick_lanes<true, true>(glanes) : pick_lanes<false, true>(glanes))
+                 : (tr ? pick_lanes<true, false>(glanes) : pick_lanes<false, false>(glanes));
+        std::snprintf(name, sizeof(name), "wedm_step_lanes<%d>%s<<<%d,256,%zuB>>> n_sub=%d", glanes, f64 ? "[f64 stencil]" : "", grid, fl, n_substeps);
     } else if (variant == 4) {
         grid = (ctx->num_envs + 256 / planes - 1) / (256 / planes);
         fl = (2 * (size_t)ctx->walk_C[pli] + 2) * 1024;

@@ -63,7 +63,7 @@ TRACE_CLOSE = {"debris_volume": "debris_volume", "debris_density": "debris_densi
                "cavity_volume": "cavity_volume", "last_crater_volume": "last_crater_volume"}
 
 
-def env_from_fixture(fx, n, *, device, backend=None):
+def env_from_fixture(fx, n, *, device, backend=None, **extra):
     """A batched environment configured like the fixture's reference run (constant-action scenarios)."""
     from sparc_amd import (DielectricModuleParameters, EnvironmentConfig, IgnitionModuleParameters,
                            MaterialModuleParameters, MechanicsModuleParameters, WireEDMEnv, WireModuleParameters)
@@ -71,6 +71,7 @@ def env_from_fixture(fx, n, *, device, backend=None):
     m = fx.meta
     mods = m["modules"]
     kw = dict(backend=backend) if backend is not None else {}
+    kw.update(extra)
     material = m["config"].get("wire_material", "brass")
     if material != "brass":  # register the fixture's custom material the way a user would
         from sparc_amd import WireMaterial, get_material_db

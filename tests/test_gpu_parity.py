@@ -111,7 +111,8 @@ def test_device_math_primitives_match_cpu_bit_for_bit(orc, kind):
         f"kind {kind}: {np.count_nonzero(got.view(np.uint64) != want.view(np.uint64))} of {len(want)} differ"
 
 
-KERNELS = [(1, 0), (5, 0), (6, 0), (2, 0), (3, 1), (3, 2), (3, 4), (3, 8), (3, 16), (4, 1), (4, 2), (4, 4), (4, 8)]
+KERNELS = [(1, 0), (5, 0), (6, 0), (9, 0), (9, 4), (9, 16), (2, 0), (3, 1), (3, 2), (3, 4), (3, 8), (3, 16), (4, 1), (4, 2), (4, 4),
+           (4, 8)]
 
 
 @pytest.mark.parametrize("variant,lanes", KERNELS)
@@ -597,7 +598,7 @@ def test_bind_trace_rejects_bad_descriptors():
     buf = torch.zeros(1024, dtype=torch.float64, device="cuda:0")
     ok = dict(f64=buf.data_ptr(), i32=None, i8=None, T=None, f64_mask=1, i32_mask=0, i8_mask=0, env_lo=0, env_count=8,
               every=1, capacity=4, reserved0=0)
-    for bad in (dict(f64_mask=1 << 24), dict(f64=None), dict(i32_mask=1), dict(every=0), dict(capacity=0),
+    for bad in (dict(f64_mask=1 << 26), dict(f64_mask=1 << 25), dict(f64=None), dict(i32_mask=1), dict(every=0), dict(capacity=0),
                 dict(env_lo=60, env_count=8), dict(env_count=0), dict(f64=None, f64_mask=0)):
         with pytest.raises(WedmError, match="WEDM_ERR_BAD_ARG"):
             env._backend.bind_trace(_abi.TraceDesc(**{**ok, **bad}))
@@ -927,7 +928,7 @@ def test_config5_shard_of_rank_5_matches_oracle():
 
 
 # ------------------------------------------------------------------ auto-reset / reward / voltage sum inside the launch
-@pytest.mark.parametrize("variant,lanes", [(0, 0), (2, 4), (3, 8), (4, 2), (1, 0), (5, 0), (6, 0)])
+@pytest.mark.parametrize("variant,lanes", [(0, 0), (2, 4), (3, 8), (4, 4), (1, 0), (5, 0), (6, 0), (9, 8)])
 def test_in_kernel_autoreset_and_reward_match_oracle_and_host_path(variant, lanes):
     """wedm_params.autoreset + reward_mode: environments that reach their cutting target are
     re-initialised by the NEXT launch itself (Philox episode + 1, fresh module state, spool-temperature wire,
@@ -1040,3 +1041,57 @@ def test_environment_on_a_non_current_device_is_refused_by_the_abi_and_guarded_b
     torch.cuda.synchronize("cuda:1")
     assert_blocks_equal(env.state.clone_blocks(), env.state.clone_blocks(), 64)
     assert int(other.state.time[0]) == 10
+
+
+# ------------------------------------------------------------------ the stencil as Numba types it (wedm_params.stencil_mode 1)
+@pytest.mark.parametrize("shape", ["default400", "config3", "per_env"])
+def test_float64_stencil_mode_matches_oracle_bit_for_bit(shape):
+    """`stencil_dtype="float64"`: wire.py:58-123 with Numba's typing (float64 expressions, rounded at each float32
+    store) on the device == the oracle's STENCIL_F64 restatement, every byte, fused and single-microsecond launches."""
+    n = 160
+    kw = dict(stencil_dtype="float64")
+    if shape == "config3":
+        kw["wire_params"] = WireModuleParameters(segment_len=0.625)
+    if shape == "per_env":
+        rng = np.random.default_rng(3)
+        kw.update(workpiece_height=rng.uniform(10.0, 30.0, n), wire_diameter=rng.choice([0.1, 0.2, 0.3], n),
+                  config=EnvironmentConfig(target_cutting_distance=5000.0))
+    gpu, cpu = make_pair(n, **kw)
+    both((gpu, cpu), lambda e: (e.reset(seed=77), close_gap(e, 24.0, 10.0)))
+    for variant in (0, 2, 1):
+        gpu.set_kernel(variant, 0)
+        for env in (gpu, cpu):
+            a = env.make_action(0.1, 80.0, 17, 3.0, 40.0)
+            env.step_many(a, 900)
+            for _ in range(3):
+                env.step(a)
+        assert "[f64 stencil]" in gpu._backend.last_kernel()
+        check(gpu, cpu, n)
+    assert int(gpu.state.spark_count.sum()) > 100
+    # and it really is another arithmetic: the float32 typing differs in the last bits of T
+    f32 = WireEDMEnv(num_envs=n, device="cuda:0", **{k: v for k, v in kw.items() if k != "stencil_dtype"})
+    f32.reset(seed=77)
+    close_gap(f32, 24.0, 10.0)
+    f32.step_many(f32.make_action(0.1, 80.0, 17, 3.0, 40.0), 2709)
+    d = (f32.state.T[:, :n] - gpu.state.T[:, :n]).abs().max().item()
+    assert 0.0 < d < 1e-3
+    from sparc_amd._lib import WedmError
+
+    gpu.set_kernel(3, 0)
+    with pytest.raises(WedmError, match="UNSUPPORTED"):
+        gpu.step_many(gpu.make_action(), 10)
+
+
+@pytest.mark.parametrize("env_id", [0, 777])
+def test_float64_stencil_mode_stays_within_the_stated_tolerance_of_the_reference(golden_dir, env_id):
+    """The reference as users run it (real Numba: float64 intermediates) differs from the reference as it runs
+    without Numba (float32 promotion, what the fixtures recorded) by at most 1.3e-4 K over these horizons
+    (SURVEY.md §8c); on the GPU: fixture F3 replayed with the float64 stencil — discrete state and positions
+    exact, temperatures within 1.3e-4 K."""
+    from tests._fixture_env import env_from_fixture, run_fixture_through_trace
+    from tests._golden import Fixture
+
+    fx = Fixture(golden_dir / f"f3_philox_env{env_id}.npz")
+    env = env_from_fixture(fx, env_id + 64, device="cuda:0", stencil_dtype="float64")
+    got = run_fixture_through_trace(env, fx, exact_floats=False, T_atol=1.3e-4)
+    assert (got["spark_state"] == 1).sum() > 10 and "[f64 stencil]" in env._backend.last_kernel()

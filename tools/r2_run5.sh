@@ -1,0 +1,20 @@
+#!/bin/bash
+export TMPDIR=/tmp
+OUT=gpurun_out/r2e
+mkdir -p $OUT
+python -m pytest tests -m gpu -q -x -k "default_config_fused or config3_grid or tiny_wires or device_trace_ring or in_kernel_autoreset or randomized_configurations or native_library" > $OUT/pytest.log 2>&1; echo "pytest rc=$?"; tail -4 $OUT/pytest.log
+run() {  # workload kernel lanes
+    d=$OUT/kt_$1_k$2_l$3
+    rocprofv3 --kernel-trace --stats --output-format csv -d $d -o kt -- python3 bench.py --steps 400 --warmup 50 --substeps 1 --kernel $2 --lanes $3 --workload $1 --no-cpu-baseline > $d.log 2>&1
+    f=$(find $d -name "*kernel_stats.csv" | head -1)
+    python3 - <<PY
+import csv
+for r in csv.DictReader(open("$f")):
+    if "wedm_step" in r["Name"]: print("$1 k$2 l$3", r["Name"], "calls", r["Calls"], "avg_us %.2f" % (float(r["AverageNs"])/1e3))
+PY
+}
+run config3 5 0
+for l in 1 2 4; do run config3 9 $l; done
+run config4 5 0
+for l in 4 8; do run config4 9 $l; done
+for l in 4 8 16; do run config2 9 $l; done
