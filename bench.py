@@ -12,9 +12,22 @@ BASELINE.json configs[2] per GPU (num_envs 65 536, 128-segment wire grid,
 segment_len 0.625), fresh reset, constant quickstart action ->
 weak scaling.  ``--workload config2`` selects num_envs 4096 / 400 segments instead.
 
-Prints ONE JSON line (rank 0).  ``roofline`` prices the dominant kernel against the
-8 TB/s HBM peak with the ALGORITHMIC bytes of SURVEY.md §8d, B(S) = 8*S + 208 per
-env-step; ``cpu_baseline`` times the CPU oracle (oracle/, OpenMP) on this host.
+Prints ONE JSON line (rank 0).
+
+``roofline`` names the resource that binds the dominant kernel.  The fused launches keep the wire
+in LDS for 1000 us, so HBM sees each byte once per launch (~0.3 % of peak) and the kernel is bound
+by vector-ALU ISSUE: ``achieved`` = wave-level VALU instructions per launch (SQ_INSTS_VALU from a
+separate rocprofv3 --pmc pass of this same command, recorded in profiles/valu.json) / the kernel
+duration measured live with HIP events on the launch stream; ``peak`` = 256 CUs x 4 SIMDs x
+2.4 GHz / 2 cycles per wave64 instruction = 1.2288e12 wave-instr/s (MI355X_MICROARCH.md: a wave64
+VALU instruction occupies its SIMD-32 for 2 cycles).  The same object carries the physical HBM
+fraction (PMC bytes / duration / 8 TB/s), the useful-FP32 fraction ((14 S + 120) flop per env-step
+against 157.3 TFLOP/s) and, labelled as an equivalent, the SURVEY.md §8d algorithmic-HBM figure
+B(S) = 8 S + 208 bytes per env-step (what an unfused one-launch-per-microsecond implementation
+would have to move).  ``side`` holds three side measurements of the same build: the reference's
+own one-launch-per-microsecond cadence (there HBM IS the roof), a densely sparking start (15 um
+gap) and the closed loop of the reference's driver with its PI voltage controller on the device.
+``cpu_baseline`` times the CPU oracle (oracle/, OpenMP) on this host.
 """
 from __future__ import annotations
 
@@ -29,6 +42,14 @@ ROOT = Path(__file__).resolve().parent
 sys.path.insert(0, str(ROOT))
 
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+FP32_VECTOR_PEAK_TFLOPS = 157.3  # MI355X_MICROARCH.md: peak FP32 (vector)
+# MI355X_MICROARCH.md: 256 CUs x 4 SIMD-32 per CU, 2.4 GHz max clock, a wave64 VALU instruction issues over 2 cycles
+VALU_ISSUE_PEAK = 256 * 4 * 2.4e9 / 2.0  # wave-level VALU instructions per second
+
+
+def useful_flop_per_env_step(n_seg: int) -> int:
+    """~14 flop per wire cell + ~120 flop of scalar physics per env-step."""
+    return 14 * n_seg + 120
 
 
 def algorithmic_bytes_per_env_step(n_seg: int) -> int:
@@ -44,10 +65,11 @@ def parse_args():
     ap.add_argument("--substeps", type=int, default=1000, help="physics microseconds per bench step")
     ap.add_argument("--workload", choices=["config3", "config2", "config4", "config5"], default="config3")
     ap.add_argument("--num-envs", type=int, default=0, help="override environments per GPU")
-    ap.add_argument("--kernel", type=int, default=0, help="0 auto, 1 global-memory, 2 LDS predicated, 3 LDS fused, 4 LDS fused + packed f32, 5 global-memory split")
+    ap.add_argument("--kernel", type=int, default=0, help="0 auto, 1 global-memory, 2 LDS predicated, 3 LDS fused, 4 LDS fused + packed f32, 5 global-memory split, 6 stream (single microseconds)")
     ap.add_argument("--lanes", type=int, default=0, help="lanes per environment in kernel 3 (0 auto)")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="target wall time of the cpu_baseline leg")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-side", action="store_true", help="skip the side measurements (1-us cadence, dense sparking, closed loop)")
     ap.add_argument("--gap", type=float, default=None,
                     help="side measurement: start from this gap [um] instead of the reset state's 50 um (a 15 um gap "
                          "sparks about every 90 us per environment, so the general scalar path runs on most steps)")
@@ -116,20 +138,131 @@ def cpu_baseline(wire_params, n_envs, n_sub, target_seconds):
     }
 
 
-def measured_traffic(kernel_name):
-    """HBM bytes per launch from the separate rocprofv3 --pmc passes recorded under profiles/
-    (FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for gfx950, + WRITE_SIZE); null when
-    no recorded pass matches the kernel that ran."""
-    path = ROOT / "profiles" / "traffic.json"
+def recorded(kernel_name, file_name):
+    """Row of profiles/<file_name> whose kernel_prefix matches the kernel that ran (separate rocprofv3
+    --pmc passes of this same command, see tools/profile_round.sh), or None."""
+    path = ROOT / "profiles" / file_name
     if not path.exists():
         return None
     try:
         for row in json.loads(path.read_text()):
             if kernel_name.startswith(row["kernel_prefix"]):
-                return row["hbm_bytes_per_launch"]
+                return row
     except Exception:
         return None
     return None
+
+
+def measured_traffic(kernel_name):
+    """HBM bytes per launch from the separate rocprofv3 --pmc passes recorded under profiles/
+    (FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for gfx950, + WRITE_SIZE); null when
+    no recorded pass matches the kernel that ran."""
+    row = recorded(kernel_name, "traffic.json")
+    return row["hbm_bytes_per_launch"] if row else None
+
+
+def roofline_block(kernel_name, kernel_ms, n_envs, n_sub, n_seg, traffic_override=None):
+    """The `roofline` object for one kernel launch of `n_envs` x `n_sub` env-steps that took `kernel_ms`."""
+    t = kernel_ms * 1e-3
+    env_steps = n_envs * n_sub
+    alg_bytes = env_steps * algorithmic_bytes_per_env_step(n_seg)
+    traffic = traffic_override if traffic_override is not None else measured_traffic(kernel_name)
+    alg = {"GB/s": alg_bytes / t / 1e9, "frac_of_hbm_peak": alg_bytes / t / 1e9 / HBM_PEAK_GBS,
+           "bytes_per_launch": alg_bytes,
+           "note": "B(S) = 8 S + 208 bytes per env-step (SURVEY.md §8d) x env-steps per launch"}
+    fp32 = {"TFLOP/s": env_steps * useful_flop_per_env_step(n_seg) / t / 1e12, "peak": FP32_VECTOR_PEAK_TFLOPS}
+    fp32["frac"] = fp32["TFLOP/s"] / FP32_VECTOR_PEAK_TFLOPS
+    hbm = None
+    if traffic is not None:
+        hbm = {"GB/s": traffic / t / 1e9, "peak": HBM_PEAK_GBS, "frac": traffic / t / 1e9 / HBM_PEAK_GBS,
+               "bytes_per_launch": traffic}
+    if n_sub == 1:
+        # one launch per microsecond: every byte crosses HBM once per launch -> HBM is the roof, priced with the
+        # algorithmic bytes as SURVEY.md §8d defines them
+        return {"bound": "hbm", "achieved": alg["GB/s"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "frac": alg["frac_of_hbm_peak"], "traffic": traffic, "kernel_ms": kernel_ms,
+                "algorithmic_bytes_per_launch": alg_bytes, "hbm_physical": hbm, "fp32_useful": fp32}
+    valu = recorded(kernel_name, "valu.json")
+    out = {"bound": "valu-issue", "unit": "wave-instr/s", "peak": VALU_ISSUE_PEAK, "traffic": traffic,
+           "kernel_ms": kernel_ms, "hbm_physical": hbm, "fp32_useful": fp32, "algorithmic_hbm_equivalent": alg}
+    if valu is not None:
+        insts = valu["valu_insts_per_launch"] * (env_steps / valu["env_steps_per_launch"])
+        out["achieved"] = insts / t
+        out["frac"] = out["achieved"] / VALU_ISSUE_PEAK
+        out["valu_insts_per_env_step"] = valu["valu_insts_per_launch"] / valu["env_steps_per_launch"]
+        out["source"] = valu["source"]
+    else:
+        out["achieved"] = None
+        out["frac"] = None
+        out["source"] = "no recorded SQ_INSTS_VALU pass matches this kernel (profiles/valu.json)"
+    out["note"] = ("the fused launch keeps the wire in LDS for all its microseconds: HBM sees each byte once per launch, "
+                   "the kernel is bound by VALU issue; frac = wave-level VALU instructions per second / (1024 SIMDs x 2.4 GHz / 2)")
+    return out
+
+
+def time_launches(env, act, n_sub, steps, warmup):
+    """(seconds per launch, kernel name): HIP events on the launch stream around `steps` back-to-back launches."""
+    import torch
+
+    for _ in range(warmup):
+        env.step_many(act, n_sub)
+    a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    torch.cuda.synchronize()
+    a.record()
+    for _ in range(steps):
+        env.step_many(act, n_sub)
+    b.record()
+    torch.cuda.synchronize()
+    return a.elapsed_time(b) * 1e-3 / steps, env._backend.last_kernel()
+
+
+def side_measurements(n_local, wire, S, device):
+    """Three side measurements of the same build at the bench batch (single GPU only):
+      * the reference's own cadence, one launch per microsecond (wedm_step(n_substeps=1));
+      * a densely sparking start (15 um gap: ~5.6 sparks per environment per ms instead of ~0.7);
+      * the closed loop of experiments/run_simulation.py with ITS PI voltage controller evaluated on the device
+        from the kernel-side running voltage sum (steady state after a 20 ms approach)."""
+    import torch
+
+    from sparc_amd import VoltageController, WireEDMEnv, run_controlled
+
+    out = []
+    env = WireEDMEnv(num_envs=n_local, device=device, wire_params=wire)
+    env.reset(seed=1234)
+    act = env.make_action(0.1, 80.0, 5, 3.0, 80.0)
+    sec, kname = time_launches(env, act, 1, 1000, 100)
+    out.append({"name": "one launch per microsecond (the reference's step() cadence)", "value": n_local / sec,
+                "unit": "env-steps/s", "kernel": kname, "roofline": roofline_block(kname, sec * 1e3, n_local, 1, S)})
+    env.reset(seed=1234)
+    env.state.wire_position = 10.0
+    env.state.workpiece_position = 25.0
+    env.state.target_position = 5000.0
+    s0 = int(env.state.spark_count.sum().item())
+    sec, kname = time_launches(env, act, 1000, 8, 2)
+    sparks = (int(env.state.spark_count.sum().item()) - s0) / n_local / 10.0
+    out.append({"name": "fresh reset moved to a 15 um gap (dense sparking)", "value": n_local * 1000 / sec,
+                "unit": "env-steps/s", "kernel": kname, "sparks_per_env_per_ms": sparks,
+                "roofline": roofline_block(kname, sec * 1e3, n_local, 1000, S)})
+    env.reset(seed=1)
+    env.state.workpiece_position = 70.0      # experiments/run_simulation.py:199-201
+    env.state.wire_position = 10.0
+    env.state.target_position = 5000.0
+    ctl = VoltageController(30.0)
+    run_controlled(env, ctl, 20 * 1000 + 1)  # approach: the controller closes the 60 um gap
+    torch.cuda.synchronize()
+    s0 = int(env.state.spark_count.sum().item())
+    t0 = time.perf_counter()
+    done = run_controlled(env, ctl, 10 * 1000)
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    gap = float((env.state.workpiece_position - env.state.wire_position).mean().item())
+    out.append({"name": "closed loop: the reference driver's PI voltage controller on the device, steady state",
+                "value": n_local * done / dt, "unit": "env-steps/s", "kernel": env._backend.last_kernel(),
+                "ms_per_control_interval": dt / 10 * 1e3, "mean_gap_um": gap,
+                "sparks_per_env_per_ms": (int(env.state.spark_count.sum().item()) - s0) / n_local / 10.0,
+                "timing": "wall clock around 10 control intervals incl. the controller's torch ops"})
+    env.close()
+    return out
 
 
 def main():
@@ -231,10 +364,9 @@ def main():
     if rank == 0:
         total_env_steps = world * n_local * n_sub * args.steps
         value = total_env_steps / elapsed
-        bytes_per_launch = n_local * n_sub * algorithmic_bytes_per_env_step(S)
-        achieved = bytes_per_launch / (kernel_ms * 1e-3) / 1e9
+        kname = env._backend.last_kernel()
         out = {
-            "metric": "env-steps/sec at batch 65536", "value": value, "unit": "env-steps/s",
+            "metric": f"env-steps/sec at batch {world * n_local}", "value": value, "unit": "env-steps/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f32 wire temperature + f64 scalar state", "data": "synthetic",
@@ -242,22 +374,21 @@ def main():
                 "workload": f"{wl_name}: num_envs={n_local} per GPU, n_segments={S}, fresh reset(seed=1234), "
                             f"constant action servo 0.1 / 80 V / I5 / ON 3 / OFF 80",
                 "substeps_per_step": n_sub, "global_num_envs": world * n_local,
-                "parallelism": (f"env-sharded x{world}, obs all-gather per control step (async, overlapped with the next "
-                                "launch)") if world > 1 else "single GPU",
-                "kernel": env._backend.last_kernel(),
+                "parallelism": (f"env-sharded x{world}: one process per GPU over RCCL, rank r steps environments "
+                                f"[r*{n_local}, (r+1)*{n_local}) with env_id_offset r*{n_local} (global ids in the Philox "
+                                "counter), no data-path collective; obs all-gather per control step (async, overlapped "
+                                "with the next launch)") if world > 1 else "single GPU",
+                "ranks": world, "env_id_offsets": [r * n_local for r in range(world)],
+                "kernel": kname,
                 **({"trace": args.trace} if args.trace != "off" else {}),
                 **({"initial_gap_um": args.gap} if args.gap is not None else {}),
             },
-            "roofline": {
-                "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": achieved / HBM_PEAK_GBS,
-                "traffic": args.traffic if args.traffic is not None else measured_traffic(env._backend.last_kernel()),
-                "kernel_ms": kernel_ms, "algorithmic_bytes_per_launch": bytes_per_launch,
-                "note": "algorithmic bytes B(S)=8S+208 per env-step x envs x substeps per launch; the fused "
-                        "kernel keeps T in LDS, so physical HBM traffic is ~1/substeps of this",
-            },
+            "roofline": roofline_block(kname, kernel_ms, n_local, n_sub, S, args.traffic),
             "check": {"envs_done": done, "sparks": sparks},
         }
+        if world == 1 and not args.no_side and args.workload == "config3" and args.trace == "off" and args.gap is None \
+                and not args.num_envs and args.kernel == 0:
+            out["side"] = side_measurements(n_local, wire, S, device)
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(wire, n_local, n_sub, args.cpu_seconds)
             out["cpu_baseline"]["reference_python"] = (

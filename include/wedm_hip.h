@@ -322,11 +322,14 @@ int64_t wedm_trace_samples(wedm_ctx* ctx);
  * over T in HBM per substep), 2 = LDS-staged predicated stencil (any geometry),
  * 3 = LDS-staged fused stencil walking a wave-uniform tile table (uniform geometry),
  * 4 = the same with two chunks per lane advanced by packed float32 math,
- * 5 = global-memory stencil with the wire split over the four waves of a block (the
- * automatic choice for n_substeps == 1).  All variants produce bit-identical results. */
+ * 5 = global-memory stencil with the wire split over the four waves of a block (single
+ * microseconds, any geometry), 6 = stream kernel (single microseconds, uniform geometry: the whole
+ * chunk of a lane requested up front, tile walk in LDS, no barrier; the automatic choice for
+ * n_substeps == 1 where one round of blocks covers the batch).  All variants produce bit-identical
+ * results.  With wedm_params.stencil_mode 1 only 0, 1 and 2 are accepted.                       */
 int32_t wedm_set_kernel(wedm_ctx* ctx, int32_t variant);
 
-/* lanes that share one environment in kernels 3 and 4: 0 = auto, or 1, 2, 4, 8 (16: kernel 3 only) */
+/* lanes that share one environment in kernels 2, 3, 4 and 6: 0 = auto, or 1, 2, 4, 8 (16: not kernel 4) */
 int32_t wedm_set_lanes(wedm_ctx* ctx, int32_t lanes);
 
 /* name / launch geometry of the kernel the last wedm_step used (for profiles) */

@@ -366,22 +366,6 @@ __global__ void __launch_bounds__(256) wedm_step_split(const KArgs k) {
 }
 
 
-// ===================================================== split kernel, second design (1 us / launch)
-// What bounded wedm_step_split: (1) ~210 VGPRs -> two 256-thread blocks per CU, so a 1024-block launch ran
-// in two rounds; (2) inside a block the phases were serial — state loads, then the (general) scalar
-// prelude, and only then the first wire loads — and all resident blocks went through them together, so HBM
-// idled during the scalar phases and the scalar unit during the walks; (3) all 45 state rows crossed HBM in
-// both directions.  Here:
-//   * roles by wave: wave 0 runs the scalar physics of the block's 64 environments and owns no wire; waves
-//     1-3 each own a third of the wire and REQUEST THEIR ROWS FIRST THING (up to 46 rows in flight per lane,
-//     halos included), so the wire streams in while wave 0 loads the state and computes;
-//   * wave 0 tries the wave-uniform quiet prelude first (as the fused kernels do);
-//   * only the rows a microsecond reads are loaded (load_env_inputs), the rows that are final after the
-//     prelude are stored while the walkers work, the rest after the epilogue; a launch whose steps were all
-//     quiet does not store the rows the quiet path cannot change;
-//   * two barriers per microsecond (coefficients out, chunk maxima back).
-// T is updated in place: every OLD value a lane needs from a neighbouring chunk is in its registers before
-// the first barrier, and stores only happen after it.
 #ifdef WEDM_STAMPS
 #define WEDM_S2_STAMP_DECL unsigned long long sst[8] = {0, 0, 0, 0, 0, 0, 0, 0}; \
     asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(sst[7])::"memory")
@@ -400,211 +384,6 @@ __global__ void __launch_bounds__(256) wedm_step_split(const KArgs k) {
 #define WEDM_S2_STAMP_VM(i) do { } while (0)
 #define WEDM_S2_STAMP_OUT() do { } while (0)
 #endif
-#define WEDM_S2_WALKERS 3
-#define WEDM_S2_PRE 44  // cells whose rows are requested before the scalar phase (128 segments: 43 per walker)
-template <bool TRACE, int OCC>
-__global__ void __launch_bounds__(256, OCC) wedm_step_split2(const KArgs k) {
-    const ColdRef cold = kernarg_cold();
-    __shared__ float sh_f[5][64];    // jf, q, conv_base, conv_zone, adv
-    __shared__ int32_t sh_i[4][64];  // joule_on, pidx, adv_on, skip (environment frozen)
-    __shared__ float sh_max[WEDM_S2_WALKERS][64];
-    const int tid = threadIdx.x;
-    // wave index as a SCALAR: the two roles below are two straight programs behind one scalar branch, so the
-    // kernel's register allocation is the larger of the two, not their sum (the walkers' row registers are not
-    // live across the scalar physics).  Both programs execute the same sequence of barriers.
-    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int el = tid & 63;
-    const int64_t e = (int64_t)blockIdx.x * 64 + el;
-    const bool live = e < k.num_envs;
-    const int64_t stride = cold->s.stride;
-    const float spool = k.hot.spool;
-    const bool reinit = live && k.hot.autoreset && cold->s.i8[(int64_t)WEDM_B_DONE * stride + e] != 0;
-    Geom g;
-    load_geom(k.hot, cold, live ? e : 0, g);
-    int trace_next = k.trace_next, trace_slot = k.trace_slot;
-    (void)trace_next; (void)trace_slot;
-    WEDM_S2_STAMP_DECL;
-
-    if (w == 0) {
-        // ================================================= wave 0: the scalar physics of 64 environments
-        const uint32_t gid = k.hot.env_id_offset + (uint32_t)e;
-        Env s;
-        Persist ps{0.0f, 0.0f, 0.0f, 0};
-        if (live) {
-            if (TRACE) load_env(cold, e, s);  // frozen environments are sampled too: every row
-            else load_env_inputs(cold, e, s, !k.hot.disable_ignition);
-        } else {
-            s.done = 1;
-        }
-        if (reinit) reinit_env(cold, e, s, true);
-        const bool frozen0 = s.done;
-        if (!s.done) {
-            s.ipk = peak_current(cold, s.mode);
-            init_persist(k.hot, cold, e, s, ps);
-        }
-        double wp0 = 0.0;  // workpiece position at the start of the launch (reward)
-        if (k.hot.reward_mode && !frozen0) wp0 = s.wp;
-        bool quiet_only = true;
-        WEDM_S2_STAMP_VM(0);  // state loaded
-        for (int it = 0; it < k.n_substeps; ++it) {
-            const bool last = it + 1 == k.n_substeps;
-            Coef cf{0.0f, 0.0f, 0, -1};
-#ifdef WEDM_S2_NO_QUIET
-            if (true) {
-#else
-            if (!quiet_prelude(k.hot, g, gid, s)) {
-#endif
-                quiet_only = false;
-                if (!s.done) cf = scalar_prelude(k.hot, cold, g, e, gid, s, ps, true);
-            }
-            sh_f[0][el] = cf.jf; sh_f[1][el] = cf.q; sh_f[2][el] = ps.conv_base; sh_f[3][el] = ps.conv_zone;
-            sh_f[4][el] = ps.adv;
-            sh_i[0][el] = cf.joule_on; sh_i[1][el] = cf.pidx; sh_i[2][el] = ps.adv_on; sh_i[3][el] = s.done;
-            WEDM_S2_STAMP(1);  // prelude done
-            __syncthreads();  // (1) coefficients out
-            WEDM_S2_STAMP(2);
-            // rows that are final now leave while the walkers work (last microsecond of the launch only:
-            // before that the state stays in registers)
-            if (last && live && !frozen0) store_env_after_prelude(cold, e, s, quiet_only);
-            __syncthreads();  // (2) chunk maxima back
-            WEDM_S2_STAMP(3);
-            if (!s.done) {
-                float m = sh_max[0][el];
-#pragma unroll
-                for (int q = 1; q < WEDM_S2_WALKERS; ++q) m = fmax_gt(m, sh_max[q][el]);
-                scalar_epilogue(k.hot, s, m);
-                if (s.ctrl) control_step_outputs(cold, e, s, true);
-            }
-            if (TRACE && it == trace_next) {
-                const wedm_trace_desc& tr = k.trace;
-                const int64_t tcol = live ? trace_column(tr, e) : -1;
-                if (tcol >= 0) trace_scalars(tr, tcol, s, trace_slot);
-                trace_next += tr.every;
-                trace_slot = (trace_slot + 1 == tr.capacity) ? 0 : trace_slot + 1;
-            }
-            if (!last) __syncthreads();  // (3) the next microsecond's row requests follow this one's stores
-        }
-        if (live && !frozen0) {
-            if (k.hot.reward_mode && cold->s.reward) {
-                const double pen = opaque(cold->p)->reward_break_penalty;
-                cold->s.reward[e] = (float)(s.wp - wp0) - (float)pen * (s.broken ? 1.0f : 0.0f);
-            }
-            WEDM_S2_STAMP(4);  // epilogue done
-            store_env_after_epilogue(cold, e, s);
-        }
-        WEDM_S2_STAMP_VM(5);  // stored
-        WEDM_S2_STAMP_OUT();
-        return;
-    }
-
-    // ===================================================== waves 1-3: one third of the wire each
-    const float tref = k.hot.tref, alpha = k.hot.alpha, tdiel = k.hot.tdiel;
-    const int n = g.n_seg;
-    const int C = (k.n_seg_max + WEDM_S2_WALKERS - 1) / WEDM_S2_WALKERS;
-    const int c = w - 1;
-    const int i0 = c * C;
-    const int i1 = (i0 + C < n) ? i0 + C : n;  // this lane's cells [i0, i1) (may be empty)
-    GlobalT T{cold->s.T + (live ? e : 0), stride};
-    constexpr int PRE = WEDM_S2_PRE;
-    float pre[PRE + 2];   // pre[u] = OLD T[i0 - 1 + u]
-    float halo_r = 0.0f;  // OLD T[i1] when the chunk is longer than PRE cells
-    const bool mine = live && i0 < i1;
-    auto request_rows = [&]() {
-        if (mine) {
-#pragma unroll
-            for (int u = 0; u < PRE + 2; ++u) {
-                int idx = i0 - 1 + u;
-                idx = idx < 0 ? 0 : (idx < n ? idx : n - 1);  // any valid row where the value is not used
-                pre[u] = T.ld(idx);
-            }
-            if (i1 - i0 > PRE && i1 < n) halo_r = T.ld(i1);
-        }
-    };
-    request_rows();  // in flight while wave 0 loads the state and computes
-    WEDM_S2_STAMP(0);  // rows requested
-    if (reinit) {    // next-step autoreset: this lane's rows of the wire, all n_seg_max of them
-        const int f1 = (i0 + C < k.n_seg_max) ? i0 + C : k.n_seg_max;
-        for (int i = i0; i < f1; ++i) T.st(i, spool);
-#pragma unroll
-        for (int u = 0; u < PRE + 2; ++u) pre[u] = spool;
-        halo_r = spool;
-    }
-    for (int it = 0; it < k.n_substeps; ++it) {
-        const bool last = it + 1 == k.n_substeps;
-        if (it > 0) request_rows();  // behind barrier (3)
-        WEDM_S2_STAMP(1);
-        __syncthreads();  // (1)
-        WEDM_S2_STAMP(2);
-#ifdef WEDM_STAMPS
-        WEDM_S2_STAMP_VM(3);  // rows landed
-#endif
-        const Coef cf{sh_f[0][el], sh_f[1][el], sh_i[0][el], sh_i[1][el]};
-        const Persist pw{sh_f[4][el], sh_f[2][el], sh_f[3][el], sh_i[2][el]};
-        const bool skip = sh_i[3][el] != 0;
-        float tmax = spool;
-        // the chunk origin re-materialised every microsecond: the per-cell zone / contact predicates are
-        // loop-invariant, and hoisted out of the microsecond loop they are ~180 mask pairs held across the
-        // barrier (630 v_writelane + 623 v_readlane of SGPR spills, VGPRs at the cap)
-        int i0s = i0;
-        asm volatile("" : "+s"(i0s));
-        if (mine && !skip) {
-#pragma unroll
-            for (int u = 0; u < PRE; ++u) {  // the cells whose rows were requested up front
-                const int i = i0s + u;
-                if (i < i1) {
-                    const float tn = (i >= 1) ? stencil_cell(i, n, (i == 1) ? spool : pre[u], pre[u + 1], pre[u + 2], g, cf, pw, tref, alpha, tdiel)
-                                              : spool;
-                    T.st(i, tn);
-                    tmax = tn > tmax ? tn : tmax;
-                }
-                if ((u & 3) == 3) __builtin_amdgcn_sched_barrier(0);  // keep the 44 unrolled cells from being interleaved (registers)
-            }
-            if (i1 - i0 > PRE) {  // longer chunks (400-segment wires): the rest in batches of rows all in flight together
-                constexpr int RB = 16;
-                float tm1 = pre[PRE];  // OLD T[i0 + PRE - 1]
-                for (int ib = i0 + PRE; ib < i1; ib += RB) {
-                    float buf[RB + 1];
-#pragma unroll
-                    for (int u = 0; u <= RB; ++u) {
-                        int idx = ib + u;
-                        idx = idx < i1 ? idx : i1 - 1;
-                        buf[u] = T.ld(idx);
-                    }
-#pragma unroll
-                    for (int u = 0; u < RB; ++u) {
-                        const int i = ib + u;
-                        if (i < i1) {
-                            const float tp1 = (i + 1 < i1) ? buf[u + 1] : halo_r;
-                            const float tn = stencil_cell(i, n, tm1, buf[u], tp1, g, cf, pw, tref, alpha, tdiel);
-                            T.st(i, tn);
-                            tmax = tn > tmax ? tn : tmax;
-                            tm1 = buf[u];
-                        }
-                    }
-                }
-            }
-        }
-        sh_max[c][el] = tmax;
-        WEDM_S2_STAMP(4);  // cells computed, stores issued
-        __syncthreads();  // (2)
-        WEDM_S2_STAMP(5);
-        if (TRACE && it == trace_next) {  // wave-uniform schedule; T rows of the step just finished
-            const wedm_trace_desc& tr = k.trace;
-            const int64_t tcol = live ? trace_column(tr, e) : -1;
-            if (tcol >= 0 && tr.T) {
-                const int64_t tcnt = tr.env_count;
-                float* tT = tr.T + (int64_t)trace_slot * k.n_seg_max * tcnt + tcol;
-                for (int i = i0; i < i1; ++i) tT[(int64_t)i * tcnt] = T.ld(i);
-            }
-            trace_next += tr.every;
-            trace_slot = (trace_slot + 1 == tr.capacity) ? 0 : trace_slot + 1;
-        }
-        if (!last) __syncthreads();  // (3)
-    }
-    WEDM_S2_STAMP_VM(6);  // stores landed
-    WEDM_S2_STAMP_OUT();
-}
-
 
 // Any geometry (uniform or one row per environment), L lanes per environment, every cell on the
 // predicated formula with the lane's own n_seg / zone / contact indices.  LDS layout and halo
@@ -1159,7 +938,7 @@ __global__ void __launch_bounds__(256, 2) wedm_step_fused(const KArgs k) {
 template <int L, bool TRACE, int CMAX>
 __global__ void __launch_bounds__(256, 2) wedm_step_stream(const KArgs k) {
     const ColdRef cold = kernarg_cold();
-    const Hot& hv = k.hot;  // not pinned in VGPRs: the registers hold the wire rows in flight instead
+    Hot hv = k.hot;
     extern __shared__ __attribute__((aligned(16))) float lds[];
     constexpr int EPB = 256 / L;  // environments per block
     const int tid = threadIdx.x;
@@ -1177,8 +956,24 @@ __global__ void __launch_bounds__(256, 2) wedm_step_stream(const KArgs k) {
     const int jn = (!live) ? 0 : ((C < n - cbase) ? C : n - cbase);  // cells of this chunk that exist (<= 0: none)
     WEDM_S2_STAMP_DECL;
 
-    // (1) the state rows a microsecond reads: requested FIRST, so that the scalar prelude can start as soon as
-    // they are back (the vmcnt counter is in order: the wait for them leaves the wire loads in flight)
+    // (1) the wire: the lane's whole chunk into registers, 32-bit byte offsets from the (wave-uniform) base of T
+    // (the host checks that the block is below 4 GB): one v_add per row instead of a 64-bit multiply-add.
+    // Rows past the chunk repeat its last row (a lane without cells reads row 0): every load is unconditional
+    // and from a valid address, so the compiler can count them and waits for each row only where it is used.
+    const char* const Tb = (const char*)cold->s.T;
+    const uint32_t rowb = (uint32_t)stride * 4u;                                                   // bytes per wire row
+    const uint32_t off0 = (uint32_t)((jn > 0 ? cbase : 0) * stride + (live ? e : 0)) * 4u;        // this lane's first row
+    float w[CMAX];
+    {
+        const int jmax = jn > 0 ? jn - 1 : 0;
+        uint32_t off = off0;
+#pragma unroll
+        for (int j = 0; j < CMAX; ++j) {
+            w[j] = *(const float*)(Tb + off);
+            off += (j < jmax) ? rowb : 0u;
+        }
+    }
+    // (2) the state rows a microsecond reads
     Env s;
     Geom g;
     Persist ps{0.0f, 0.0f, 0.0f, 0};
@@ -1188,16 +983,6 @@ __global__ void __launch_bounds__(256, 2) wedm_step_stream(const KArgs k) {
         else load_env_inputs(cold, e, s, !k.hot.disable_ignition);
     } else {
         s.done = 1; s.unwind = 0.0; s.h_base = 0.0f; s.h_zone = 0.0f;
-    }
-    // (2) the wire: the lane's whole chunk into registers.  Rows past the chunk repeat its last row (a lane
-    // without cells reads row 0): every load is unconditional and from a valid address, so the compiler can
-    // count them and waits for each row only where it is first used.
-    float w[CMAX];
-    {
-        const int jmax = jn > 0 ? jn - 1 : 0;
-        const float* src = cold->s.T + (int64_t)(jn > 0 ? cbase : 0) * stride + (live ? e : 0);
-#pragma unroll
-        for (int j = 0; j < CMAX; ++j) w[j] = src[(int64_t)(j < jmax ? j : jmax) * stride];
     }
     WEDM_S2_STAMP(0);  // everything requested
     // next-step autoreset (all L lanes of the environment agree)
@@ -1210,6 +995,13 @@ __global__ void __launch_bounds__(256, 2) wedm_step_stream(const KArgs k) {
         s.ipk = peak_current(cold, s.mode);
         init_persist(k.hot, cold, e, s, ps);
     }
+    // (3) the chunk into the lane's LDS column (each row is waited for where it is written: one round trip in all)
+#pragma unroll
+    for (int j = 0; j < CMAX; ++j)
+        if (j < C) col[j * 256] = reinit ? k.hot.spool : w[j];
+    if (c == 0) col[0] = k.hot.spool;  // wire cell 0 is held at the spool temperature (wire.py:83)
+    WEDM_S2_STAMP(1);  // wire in LDS
+    pin_hot_in_vgprs(hv);
     const uint32_t gid = k.hot.env_id_offset + (uint32_t)e;
 
     const float spool = k.hot.spool, tref = k.hot.tref, alpha = k.hot.alpha, tdiel = k.hot.tdiel;
@@ -1238,22 +1030,15 @@ __global__ void __launch_bounds__(256, 2) wedm_step_stream(const KArgs k) {
     int trace_next = k.trace_next, trace_slot = k.trace_slot;
     (void)trace_next; (void)trace_slot;
     bool quiet_only = true;
+    int patch0 = -1, patch1 = -1;  // cells patched after the last walk (chunk-local), -1: none
+    uint32_t stored = 0u;  // tiles of the last microsecond that went to global memory from the walk itself (wave-uniform)
     for (int it = 0; it < k.n_substeps; ++it) {
         if (__all(s.done) && !tracing) break;
+        const bool last = it + 1 == k.n_substeps;
         Coef cf{0.0f, 0.0f, 0, -1};
         if (!quiet_prelude(hv, g, gid, s)) {
             quiet_only = false;
             if (!s.done) cf = scalar_prelude(hv, cold, g, e, gid, s, ps, c == 0);
-        }
-        if (it == 0) {
-            WEDM_S2_STAMP(1);  // prelude done
-            // (3) the chunk into the lane's LDS column, behind the first prelude: the wire has been streaming in
-            // underneath it (each row is waited for where it is written)
-#pragma unroll
-            for (int j = 0; j < CMAX; ++j)
-                if (j < C) col[j * 256] = reinit ? spool : w[j];
-            if (c == 0) col[0] = spool;  // wire cell 0 is held at the spool temperature (wire.py:83)
-            WEDM_S2_STAMP(2);  // wire in LDS
         }
         // ---- halos: OLD neighbour values, read before any lane of this wave stores.  The right
         // halo goes into the chunk's extra LDS row C, so cell C-1 is walked like any other.
@@ -1322,6 +1107,13 @@ __global__ void __launch_bounds__(256, 2) wedm_step_stream(const KArgs k) {
                         tile8_staged<float, false, false>(old, tn, g.k, g.tuf, cv, tdiel, ps.adv, jv, alpha, tref);
 #pragma unroll
                     for (int u = 0; u < 8; ++u) col[(j + u) * 256] = tn[u];
+                    if (last) {  // the launch's last microsecond: the tile also goes straight to global memory
+                        char* const Tw = (char*)cold->s.T;
+                        uint32_t off = off0 + (uint32_t)j * rowb;
+#pragma unroll
+                        for (int u = 0; u < 8; ++u) { *(float*)(Tw + off) = tn[u]; off += rowb; }
+                        stored |= 1u << t;
+                    }
                     float m0 = fmax_gt(tn[0], tn[1]), m1 = fmax_gt(tn[2], tn[3]);
                     m0 = fmax_gt(m0, fmax_gt(tn[4], tn[5]));
                     m1 = fmax_gt(m1, fmax_gt(tn[6], tn[7]));
@@ -1386,6 +1178,8 @@ __global__ void __launch_bounds__(256, 2) wedm_step_stream(const KArgs k) {
             for (int t = 0; t < n_tiles; ++t) tile(t, bufA, bufA);
         }
         // ---- patches (after every store of the walk): boundary condition, last cell, plasma cell
+        patch0 = (owns_last && !s.done) ? n - 1 - cbase : -1;
+        patch1 = owns_pl ? cf.pidx - cbase : -1;
         if (c == 0 && !s.done) col[0] = spool;
         if (owns_last && !s.done) {
             col[(n - 1 - cbase) * 256] = tlast;
@@ -1406,21 +1200,27 @@ __global__ void __launch_bounds__(256, 2) wedm_step_stream(const KArgs k) {
     }
 
     WEDM_S2_STAMP(4);  // walk + epilogue done
-    // ---- write-back: each lane its own chunk, 16 rows at a time (16 LDS reads in flight, then 16 stores);
-    // the L lanes of an environment are in one wave: nothing to wait for
+    // ---- write-back of what the walk did not store itself (boundary / irregular tiles, and the cells patched
+    // after the walk: wire cell 0, the last cell, the plasma cell), a tile of 8 rows at a time: 8 LDS reads in
+    // flight, then 8 stores, fire and forget; the L lanes of an environment are in one wave: nothing to wait for
     if (!frozen0) {
-        float* dst = cold->s.T + (int64_t)cbase * stride + (live ? e : 0);
+        char* const Tw = (char*)cold->s.T;
+        const uint32_t offc = (uint32_t)(cbase * stride + (live ? e : 0)) * 4u;
+        stored = __builtin_amdgcn_readfirstlane(stored);
 #pragma unroll
-        for (int j0 = 0; j0 < CMAX; j0 += 16) {
-            if (j0 < C) {
-                float v[16];
+        for (int t = 0; t < (CMAX + 7) / 8; ++t) {
+            if (8 * t < C && !((stored >> t) & 1u)) {
+                float v[8];
 #pragma unroll
-                for (int u = 0; u < 16; ++u) v[u] = col[((j0 + u < C) ? j0 + u : C - 1) * 256];
+                for (int u = 0; u < 8; ++u) v[u] = col[((8 * t + u < C) ? 8 * t + u : C - 1) * 256];
 #pragma unroll
-                for (int u = 0; u < 16; ++u)
-                    if (j0 + u < jn) dst[(int64_t)(j0 + u) * stride] = v[u];
+                for (int u = 0; u < 8; ++u)
+                    if (8 * t + u < jn) *(float*)(Tw + offc + (uint32_t)(8 * t + u) * rowb) = v[u];
             }
         }
+        // cells patched after the walk inside a tile that was already stored
+        if (patch0 >= 0 && patch0 < jn && ((stored >> (patch0 >> 3)) & 1u)) *(float*)(Tw + offc + (uint32_t)patch0 * rowb) = col[patch0 * 256];
+        if (patch1 >= 0 && patch1 < jn && ((stored >> (patch1 >> 3)) & 1u)) *(float*)(Tw + offc + (uint32_t)patch1 * rowb) = col[patch1 * 256];
     }
     if (live && c == 0 && !frozen0) {
         if (k.hot.reward_mode && cold->s.reward) {
@@ -2130,7 +1930,7 @@ int64_t wedm_trace_samples(wedm_ctx* ctx) { return ctx ? ctx->trace_count : 0; }
 
 int32_t wedm_set_kernel(wedm_ctx* ctx, int32_t variant) {
     if (!ctx) return WEDM_ERR_BAD_ARG;
-    if (variant < 0 || variant > 9) return fail(ctx, WEDM_ERR_BAD_ARG, "wedm_set_kernel: variant must be 0..9");
+    if (variant < 0 || variant > 6) return fail(ctx, WEDM_ERR_BAD_ARG, "wedm_set_kernel: variant must be 0..6");
     ctx->variant = variant;
     return WEDM_OK;
 }
@@ -2278,20 +2078,22 @@ int32_t wedm_step(wedm_ctx* ctx, int32_t n_substeps, const wedm_action_ptrs* act
         }
     }
     const bool lanes_ok = glanes > 0;
-    // kernel 9 (stream, single microseconds, uniform geometry): the caller's lane count, else the smallest L whose
-    // chunk the tile table covers, raised until the launch has ~2 waves per SIMD
+    // kernel 6 (stream, single microseconds, uniform geometry): the caller's lane count, else the smallest L whose
+    // chunk has at most 64 cells (the registers a lane holds its chunk in; failing that at most 104)
     int slanes = 0;
-    if (uniform) {
+    if (uniform && (uint64_t)ctx->n_seg_max * (uint64_t)ctx->s.stride * 4ull < (1ull << 32)) {
         const int Ls[5] = {1, 2, 4, 8, 16};
-        for (int i = 0; i < 5; ++i) {
-            if (!ctx->walk_ok[i] || ctx->walk_C[i] > 104 || ((size_t)ctx->walk_C[i] + 1) * 1024 > (size_t)ctx->lds_limit) continue;
-            if (ctx->lanes) { if (Ls[i] == ctx->lanes) slanes = Ls[i]; continue; }
-            slanes = Ls[i];
-            const long waves = (long)((ctx->num_envs + (256 / Ls[i]) - 1) / (256 / Ls[i])) * 4;
-            if (waves >= 2048) break;
-        }
+        for (int pass = 0; pass < 2 && !slanes; ++pass)
+            for (int i = 0; i < 5 && !slanes; ++i) {
+                if (!ctx->walk_ok[i] || ctx->walk_C[i] > (pass ? 104 : 64) ||
+                    ((size_t)ctx->walk_C[i] + 1) * 1024 > (size_t)ctx->lds_limit) continue;
+                if (ctx->lanes && Ls[i] != ctx->lanes) continue;
+                slanes = Ls[i];
+            }
     }
     const bool stream_ok = slanes > 0;
+    const bool stream_auto = stream_ok && ctx->walk_C[lanes_index(slanes)] <= 64 &&
+                             (long)((ctx->num_envs + (256 / slanes) - 1) / (256 / slanes)) * 4 <= 2048;
     int variant = ctx->variant;
     const bool f64 = P.stencil_mode != 0;
     if (f64) {
@@ -2302,8 +2104,10 @@ int32_t wedm_step(wedm_ctx* ctx, int32_t n_substeps, const wedm_action_ptrs* act
         if (variant == 0) variant = lanes_ok ? 2 : 1;
     }
     if (variant == 0) {
-        // single-microsecond launches: the split global-memory kernel
-        if (n_substeps <= 1) variant = 5;
+        // single-microsecond launches: the stream kernel where one round of blocks covers the batch with chunks of
+        // at most 64 cells (measured: 27.5 vs 30.3 us at 65 536 x 128, 20.5 vs 24.9 us at 4 096 x 400), else the
+        // split global-memory kernel (32.7 vs 48.9 us at 32 768 x 400, where the stream kernel needs two rounds)
+        if (n_substeps <= 1) variant = (stream_ok && stream_auto) ? 6 : 5;
         else if (packed_ok && (ctx->auto_prefers_packed || !fused_ok)) variant = 4;
         else if (fused_ok) variant = 3;
         else variant = lanes_ok ? 2 : 1;
@@ -2314,7 +2118,7 @@ int32_t wedm_step(wedm_ctx* ctx, int32_t n_substeps, const wedm_action_ptrs* act
         return fail(ctx, WEDM_ERR_UNSUPPORTED, "wedm_step: packed kernel needs uniform geometry, lanes in {1,2,4,8} and two chunks that fit in LDS");
     if (variant == 2 && !lanes_ok)
         return fail(ctx, WEDM_ERR_UNSUPPORTED, "wedm_step: no lane count puts a chunk of the wire in LDS");
-    if (variant == 9 && !stream_ok)
+    if (variant == 6 && !stream_ok)
         return fail(ctx, WEDM_ERR_UNSUPPORTED, "wedm_step: stream kernel needs uniform geometry and lanes in {1,2,4,8,16} with a chunk of at most 104 cells");
 
     char name[160];
@@ -2331,7 +2135,7 @@ int32_t wedm_step(wedm_ctx* ctx, int32_t n_substeps, const wedm_action_ptrs* act
         grid = (ctx->num_envs + 63) / 64;
         fn = tr ? (const void*)wedm_step_split<true> : (const void*)wedm_step_split<false>;
         std::snprintf(name, sizeof(name), "wedm_step_split<<<%d,256>>> n_sub=%d", grid, n_substeps);
-    } else if (variant == 9) {
+    } else if (variant == 6) {
         const int sli = lanes_index(slanes);
         grid = (ctx->num_envs + 256 / slanes - 1) / (256 / slanes);
         fl = ((size_t)ctx->walk_C[sli] + 1) * 1024;
@@ -2339,13 +2143,6 @@ int32_t wedm_step(wedm_ctx* ctx, int32_t n_substeps, const wedm_action_ptrs* act
         fn = ctx->walk_C[sli] <= 64 ? (tr ? pick_stream<true, 64>(slanes) : pick_stream<false, 64>(slanes))
                                     : (tr ? pick_stream<true, 104>(slanes) : pick_stream<false, 104>(slanes));
         std::snprintf(name, sizeof(name), "wedm_step_stream<%d><<<%d,256,%zuB>>> n_sub=%d", slanes, grid, fl, n_substeps);
-    } else if (variant >= 6) {
-        grid = (ctx->num_envs + 63) / 64;
-        const int occ = variant - 4;  // 6, 7, 8 -> launch bounds of 2, 3, 4 waves per SIMD
-        fn = occ == 2 ? (tr ? (const void*)wedm_step_split2<true, 2> : (const void*)wedm_step_split2<false, 2>)
-           : occ == 3 ? (tr ? (const void*)wedm_step_split2<true, 3> : (const void*)wedm_step_split2<false, 3>)
-                      : (tr ? (const void*)wedm_step_split2<true, 4> : (const void*)wedm_step_split2<false, 4>);
-        std::snprintf(name, sizeof(name), "wedm_step_split2<%d><<<%d,256>>> n_sub=%d", occ, grid, n_substeps);
     } else if (variant == 2) {
         grid = (ctx->num_envs + 256 / glanes - 1) / (256 / glanes);
         fl = (size_t)((ctx->n_seg_max + glanes - 1) / glanes) * 1024;

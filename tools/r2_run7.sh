@@ -2,7 +2,7 @@
 export TMPDIR=/tmp
 OUT=gpurun_out/r2g
 mkdir -p $OUT
-python -m pytest tests -m gpu -q -x -k "default_config_fused or config3_grid or tiny_wires or in_kernel_autoreset or randomized_configurations" > $OUT/pytest.log 2>&1; echo "pytest rc=$?"; tail -4 $OUT/pytest.log
+python -m pytest tests -m gpu -q -x -k "default_config_fused or config3_grid or tiny_wires or in_kernel_autoreset or randomized_configurations or float64" > $OUT/pytest.log 2>&1; echo "pytest rc=$?"; tail -4 $OUT/pytest.log
 WEDM_HIP_LIB=build/ablate/libwedm_STAMPS.so python tools/stamps_stream.py 65536 config3 2 2>&1 | grep -v amdgpu.ids
 WEDM_HIP_LIB=build/ablate/libwedm_STAMPS.so python tools/stamps_stream.py 256 config3 2 2>&1 | grep -v amdgpu.ids
 run() {  # workload kernel lanes
