@@ -185,9 +185,6 @@ struct Hot {
     double dt_s, damping_coeff, stiffness_coeff, omega_n, max_acceleration, max_jerk_dt, max_speed;
     float spool, tref, alpha, tdiel, tcrit, tbreak;
     int32_t servo_interval, dt_us, control_mode, disable_ignition, has_random_short, per_env_geometry;
-    int32_t autoreset, reward_mode;
-    // stencil_mode 1 only (Numba's typing of wire.py:58-123): the float64 constants of the stencil
-    double spool64, tref64, alpha64, tdiel64;
     uint32_t env_id_offset;
     int32_t n_seg;  // uniform geometry only
 };
@@ -286,6 +283,10 @@ __device__ __forceinline__ const T* opaque(const T* p) {
     asm volatile("" : "+s"(p));
     return p;
 }
+
+// launch-level switches live in the device copy of wedm_params: read where they are used (kernel entry / exit)
+#define WEDM_AUTORESET(cold) (opaque((cold)->p)->autoreset != 0)
+#define WEDM_REWARD_ON(cold) (opaque((cold)->p)->reward_mode != 0 && (cold)->s.reward != nullptr)
 
 #define WEDM_ROW(ptr, row) ((ptr) + (int64_t)(row) * stride + e)
 
@@ -610,8 +611,14 @@ __device__ __forceinline__ void crater_stats_update(double* st, int64_t sd, doub
 
 // `writer`: the one lane of an environment's L lanes that updates per-environment global memory
 // beyond the state blocks (the running statistics).
+struct QuietTry {  // what a failed quiet_prelude() hands on: the step's Philox words, if it drew them (wave-uniform flag)
+    W4 w;
+    bool have_w;
+};
+
 __device__ __forceinline__ Coef scalar_prelude(const Hot& p, const ColdRef cold, const Geom& g, int64_t e,
-                                               uint32_t gid, Env& s, Persist& ps, bool writer) {
+                                               uint32_t gid, Env& s, Persist& ps, bool writer,
+                                               const QuietTry& qt = QuietTry{W4{0u, 0u, 0u, 0u}, false}) {
     // ---- control-step latch (wire_edm.py:117-121,162-170)
     s.ctrl = s.tss >= p.servo_interval;
     if (s.ctrl) {
@@ -660,7 +667,10 @@ __device__ __forceinline__ Coef scalar_prelude(const Hot& p, const ColdRef cold,
         const bool idle = s.state == 0;
         W4 w{0u, 0u, 0u, 0u};
 #ifndef WEDM_ABL_NO_PHILOX
-        if (!timers && (p_d > 0.0 || p_r > 0.0 || idle)) w = philox4(s.key0, s.key1, t, ep, gid, 0u);
+        // (the words are a pure function of key, time, episode and environment: when the quiet attempt of this
+        // step has already drawn them for the whole wave they are taken over instead of being computed again)
+        if (qt.have_w) w = qt.w;
+        else if (!timers && (p_d > 0.0 || p_r > 0.0 || idle)) w = philox4(s.key0, s.key1, t, ep, gid, 0u);
 #else
         w = W4{t * 2654435761u + gid, 1u, 0xffffffffu - (t ^ gid) * 40503u, 7u};
 #endif
@@ -823,7 +833,8 @@ __device__ __forceinline__ Coef scalar_prelude(const Hot& p, const ColdRef cold,
 // fast path is taken only if EVERY live lane of the wave qualifies and none ignites; nothing is
 // written before that is known, so otherwise the general path runs on untouched state.
 // Returns true when the step was handled (the stencil coefficients are then {0, 0, off, none}).
-__device__ __forceinline__ bool quiet_prelude(const Hot& p, const Geom& g, uint32_t gid, Env& s) {
+__device__ __forceinline__ bool quiet_prelude(const Hot& p, const Geom& g, uint32_t gid, Env& s, QuietTry& qt) {
+    qt.have_w = false;
     if (p.disable_ignition || p.has_random_short) return false;
     const bool live = !s.done;
     const double d0 = s.wp - s.x;                       // unclamped gap (>= hard_short_gap > 0.001 below)
@@ -849,6 +860,10 @@ __device__ __forceinline__ bool quiet_prelude(const Hot& p, const Geom& g, uint3
         const double lam = p.ln2 / (p.ignition_a * (d0 * d0) + p.ignition_b * d0 + p.ignition_c);
         const W4 w = philox4(s.key0, s.key1, (uint32_t)s.time, (uint32_t)s.episode, gid, 0u);
         ign = idle && live && (u32_to_unit(w.z) < lam);
+#ifndef WEDM_NO_PHILOX_REUSE
+        qt.w = w;          // every lane of the wave computed its words: the general path need not repeat them
+        qt.have_w = true;
+#endif
     }
     if (__any(ign)) return false;
     if (live) {
@@ -873,6 +888,11 @@ __device__ __forceinline__ bool quiet_prelude(const Hot& p, const Geom& g, uint3
         }
     }
     return true;
+}
+
+__device__ __forceinline__ bool quiet_prelude(const Hot& p, const Geom& g, uint32_t gid, Env& s) {
+    QuietTry qt;
+    return quiet_prelude(p, g, gid, s, qt);
 }
 
 // a - 2*b exactly as the reference rounds it: 2*b is exact in binary floating point, so
@@ -912,21 +932,24 @@ __device__ __forceinline__ float stencil_cell(int i, int n_seg, float tm1, float
 // every expression, the result rounded where it is stored into the float32 `dT_dt[i]` / `T[i]`; without
 // fastmath re-association) — wedm_params.stencil_mode 1.  h_base / h_zone are the float32 `h_eff_zone`
 // entries (wire.py:205), everything else float64 constants.
+struct StencilF64 {  // the float64 constants of that typing (read from the cold parameters by the F64 instantiations)
+    double tref, alpha, tdiel;
+};
 __device__ __forceinline__ float stencil_cell_f64(int i, int n_seg, float tm1, float tc, float tp1, const Geom& g,
-                                                  const Coef& c, const Persist& ps, const Hot& h, float h_base,
+                                                  const Coef& c, const Persist& ps, const StencilF64& h, float h_base,
                                                   float h_zone) {
     const double m = (double)tm1, t = (double)tc;
     float d;
     if (i < n_seg - 1) d = (float)(g.k64 * (m - 2.0 * t + (double)tp1));
     else d = (float)(g.k64 * (m - t));
     if (c.joule_on && i >= g.cb && i <= g.ct) {
-        const double rho_T = 1.0 + h.alpha64 * (t - h.tref64);
+        const double rho_T = 1.0 + h.alpha * (t - h.tref);
         d = (float)((double)d + c.jf64 * rho_T);
     }
     if (i == c.pidx) d = (float)((double)d + c.q64);
     const bool in_zone = (i >= g.az_start) && (i < g.az_end);
     const double conv = (double)(in_zone ? h_zone : h_base) * g.a64;
-    d = (float)((double)d - conv * (t - h.tdiel64));
+    d = (float)((double)d - conv * (t - h.tdiel));
     if (ps.adv_on) d = (float)((double)d + ps.adv64 * (m - t));
     return (float)(t + (double)d * g.tuf64);
 }
@@ -936,7 +959,9 @@ __device__ __forceinline__ float stencil_cell_f64(int i, int n_seg, float tm1, f
 __device__ __forceinline__ void scalar_epilogue(const Hot& p, Env& s, float tmax) {
     // the driver appends state.voltage after EVERY step(), the early-return one included
     // (experiments/run_simulation.py:256-264): running sum in step order
+#ifndef WEDM_ABL_NO_VACC
     s.vacc = s.vacc + s.V;
+#endif
     s.tmax = tmax;
     if (tmax > p.tcrit) s.tcrit += 1;
     else s.tcrit = 0;

@@ -1,6 +1,6 @@
 #!/usr/bin/env python
 """Phase breakdown of the fused kernels from a -DWEDM_STAMPS build (diagnostic only).
-usage: WEDM_HIP_LIB=build/ablate/libwedm_STAMPS.so python tools/stamps.py <kernel> <lanes> [workload]"""
+usage: WEDM_HIP_LIB=build/ablate/libwedm_STAMPS.so python tools/stamps.py <kernel> <lanes> [config3|config4|config2] [num_envs] [gap_um]"""
 import ctypes as C, sys
 sys.path.insert(0, ".")
 import torch
@@ -8,10 +8,14 @@ from sparc_amd import WireEDMEnv, WireModuleParameters
 kernel, lanes = int(sys.argv[1]), int(sys.argv[2])
 wl = sys.argv[3] if len(sys.argv) > 3 else "config3"
 wire = WireModuleParameters(segment_len=0.625) if wl == "config3" else WireModuleParameters()
-n = 65536
+n = int(sys.argv[4]) if len(sys.argv) > 4 else {"config3": 65536, "config4": 32768, "config2": 4096}.get(wl, 65536)
 env = WireEDMEnv(num_envs=n, device="cuda:0", wire_params=wire)
 env.set_kernel(kernel, lanes)
 env.reset(seed=1234)
+if len(sys.argv) > 5:
+    env.state.wire_position = 10.0
+    env.state.workpiece_position = 10.0 + float(sys.argv[5])
+    env.state.target_position = 5000.0
 act = env.make_action(0.1, 80.0, 5, 3.0, 80.0)
 buf = torch.zeros(n * 64, dtype=torch.int64, device="cuda")
 L = env._backend._L
