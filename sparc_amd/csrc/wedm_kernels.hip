@@ -123,8 +123,9 @@ struct GlobalT {
 // OLD neighbours (explicit Euler) with one load + one store per cell.
 template <bool F64, class TA>
 __device__ __forceinline__ float stencil_pass(const TA& T, const Geom& g, const Coef& c, const Persist& ps, const Hot& hot,
-                                              float h_base, float h_zone) {
+                                              const StencilF64& f64c, float h_base, float h_zone) {
     const float spool = hot.spool, tref = hot.tref, alpha = hot.alpha, tdiel = hot.tdiel;
+    (void)tref; (void)alpha; (void)tdiel;
     const int n = g.n_seg;
     T.st(0, spool);  // boundary condition (wire.py:83,123)
     float tmax = spool;
@@ -143,7 +144,7 @@ __device__ __forceinline__ float stencil_pass(const TA& T, const Geom& g, const 
             int i = i0 + u;
             if (i < n) {
                 float tn;
-                if (F64) tn = stencil_cell_f64(i, n, tm1, tc, nx[u], g, c, ps, hot, h_base, h_zone);
+                if (F64) tn = stencil_cell_f64(i, n, tm1, tc, nx[u], g, c, ps, f64c, h_base, h_zone);
                 else tn = stencil_cell(i, n, tm1, tc, nx[u], g, c, ps, tref, alpha, tdiel);
                 T.st(i, tn);
                 tmax = tn > tmax ? tn : tmax;
@@ -160,13 +161,15 @@ __device__ __forceinline__ void run_substeps(const KArgs& k, const ColdRef cold,
                                              uint32_t gid, Env& s, const TA& T) {
     Persist ps;
     init_persist(k.hot, cold, e, s, ps);
+    StencilF64 f64c{0.0, 0.0, 0.0};
+    if (F64) { const wedm_params* pp = cold->p; f64c = StencilF64{pp->temp_ref, pp->alpha_rho, pp->dielectric_temperature}; }
     const bool tracing = WEDM_TRACING(k);
     int trace_next = k.trace_next, trace_slot = k.trace_slot;
     (void)trace_next; (void)trace_slot;
     for (int it = 0; it < k.n_substeps; ++it) {
         if (!s.done) {
             Coef c = scalar_prelude(k.hot, cold, g, e, gid, s, ps, true);  // single steps: the quiet test does not pay
-            float tmax = stencil_pass<F64>(T, g, c, ps, k.hot, s.h_base, s.h_zone);
+            float tmax = stencil_pass<F64>(T, g, c, ps, k.hot, f64c, s.h_base, s.h_zone);
             scalar_epilogue(k.hot, s, tmax);
             if (s.ctrl) control_step_outputs(cold, e, s, true);
         } else if (!tracing) {
@@ -184,7 +187,7 @@ __global__ void __launch_bounds__(256) wedm_step_global(const KArgs k) {
     if (e >= k.num_envs) return;
     Env s;
     load_env(cold, e, s);
-    const bool reinit = s.done && k.hot.autoreset;
+    const bool reinit = s.done && WEDM_AUTORESET(cold);
     const bool frozen = s.done && !reinit;  // terminated and not reset: nothing to step
     if (frozen && !WEDM_TRACING(k)) return;
     GlobalT T{cold->s.T + e, cold->s.stride};
@@ -196,7 +199,7 @@ __global__ void __launch_bounds__(256) wedm_step_global(const KArgs k) {
     Geom g;
     load_geom(k.hot, cold, e, g);
     run_substeps<TRACE, F64>(k, cold, g, e, k.hot.env_id_offset + (uint32_t)e, s, T);
-    if (k.hot.reward_mode && !frozen) write_reward(cold, e, s);
+    if (WEDM_REWARD_ON(cold) && !frozen) write_reward(cold, e, s);
     store_env(cold, e, s);
 }
 
@@ -256,7 +259,7 @@ __global__ void __launch_bounds__(256) wedm_step_split(const KArgs k) {
     GlobalT T{cold->s.T + (live ? e : 0), stride};
 
     // next-step autoreset: every wave of the block sees the environment's DONE flag
-    const bool reinit = live && k.hot.autoreset && cold->s.i8[(int64_t)WEDM_B_DONE * stride + e] != 0;
+    const bool reinit = live && WEDM_AUTORESET(cold) && cold->s.i8[(int64_t)WEDM_B_DONE * stride + e] != 0;
     if (reinit) {  // this lane's rows of the wire (all n_seg_max rows, as wedm_reset does)
         const int f1 = (i0 + C < k.n_seg_max) ? i0 + C : k.n_seg_max;
         for (int i = i0; i < f1; ++i) T.st(i, spool);
@@ -358,7 +361,7 @@ __global__ void __launch_bounds__(256) wedm_step_split(const KArgs k) {
     }
     WEDM_SPLIT_STAMP(5);
     if (c == 0 && live) {
-        if (k.hot.reward_mode && !frozen0) write_reward(cold, e, s);
+        if (WEDM_REWARD_ON(cold) && !frozen0) write_reward(cold, e, s);
         store_env(cold, e, s);
     }
     WEDM_SPLIT_STAMP(6);
@@ -430,7 +433,7 @@ __global__ void __launch_bounds__(256, 2) wedm_step_lanes(const KArgs k) {
     if (live) load_env(cold, e, s);
     else { s.done = 1; s.unwind = 0.0; s.h_base = 0.0f; s.h_zone = 0.0f; }
     float* col = lds + tid;
-    const bool reinit = live && s.done && k.hot.autoreset;  // next-step autoreset (all L lanes of the environment agree)
+    const bool reinit = live && s.done && WEDM_AUTORESET(cold);  // next-step autoreset (all L lanes of the environment agree)
     const bool frozen0 = s.done && !reinit;
     if (reinit) {
         reinit_env(cold, e, s, c == 0);
@@ -444,6 +447,8 @@ __global__ void __launch_bounds__(256, 2) wedm_step_lanes(const KArgs k) {
     const int cbase = c * C;
     const int n = g.n_seg;  // this lane's environment
     const float spool = k.hot.spool, tref = k.hot.tref, alpha = k.hot.alpha, tdiel = k.hot.tdiel;
+    StencilF64 f64c{0.0, 0.0, 0.0};
+    if (F64) { const wedm_params* pp = cold->p; f64c = StencilF64{pp->temp_ref, pp->alpha_rho, pp->dielectric_temperature}; }
     if (c == 0) col[0] = spool;
 
     const bool tracing = WEDM_TRACING(k);
@@ -452,7 +457,8 @@ __global__ void __launch_bounds__(256, 2) wedm_step_lanes(const KArgs k) {
     for (int it = 0; it < k.n_substeps; ++it) {
         if (__all(s.done) && !tracing) break;
         Coef cf{0.0f, 0.0f, 0, -1};
-        if (!quiet_prelude(hv, g, gid, s) && !s.done) cf = scalar_prelude(hv, cold, g, e, gid, s, ps, c == 0);
+        QuietTry qt;
+        if (!quiet_prelude(hv, g, gid, s, qt) && !s.done) cf = scalar_prelude(hv, cold, g, e, gid, s, ps, c == 0, qt);
         const float halo_l = (c > 0) ? col[(C - 1) * 256 - 1] : spool;
         const float halo_r = (c < L - 1) ? col[1] : 0.0f;
         float tmax = spool, tm1 = halo_l, tc = col[0];
@@ -471,7 +477,7 @@ __global__ void __launch_bounds__(256, 2) wedm_step_lanes(const KArgs k) {
                     if (i < n && !s.done) {
                         float tn = spool;
                         if (i >= 1) {
-                            if (F64) tn = stencil_cell_f64(i, n, (i == 1) ? spool : tm1, tc, nx[u], g, cf, ps, hv, s.h_base, s.h_zone);
+                            if (F64) tn = stencil_cell_f64(i, n, (i == 1) ? spool : tm1, tc, nx[u], g, cf, ps, f64c, s.h_base, s.h_zone);
                             else tn = stencil_cell(i, n, (i == 1) ? spool : tm1, tc, nx[u], g, cf, ps, tref, alpha, tdiel);
                         }
                         col[j * 256] = tn;
@@ -507,7 +513,7 @@ __global__ void __launch_bounds__(256, 2) wedm_step_lanes(const KArgs k) {
         }
     }
     if (live && c == 0) {
-        if (k.hot.reward_mode && !frozen0) write_reward(cold, e, s);
+        if (WEDM_REWARD_ON(cold) && !frozen0) write_reward(cold, e, s);
         store_env(cold, e, s);
     }
 }
@@ -675,7 +681,7 @@ __global__ void __launch_bounds__(256, 2) wedm_step_fused(const KArgs k) {
     if (live) load_env(cold, e, s);
     else { s.done = 1; s.unwind = 0.0; s.h_base = 0.0f; s.h_zone = 0.0f; }
     float* col = lds + tid;
-    const bool reinit = live && s.done && k.hot.autoreset;  // next-step autoreset (all L lanes of the environment agree)
+    const bool reinit = live && s.done && WEDM_AUTORESET(cold);  // next-step autoreset (all L lanes of the environment agree)
     const bool frozen0 = s.done && !reinit;
     if (reinit) {
         reinit_env(cold, e, s, c == 0);
@@ -721,7 +727,8 @@ __global__ void __launch_bounds__(256, 2) wedm_step_fused(const KArgs k) {
         if (__all(s.done) && !tracing) break;
         WEDM_STAMP(st0);
         Coef cf{0.0f, 0.0f, 0, -1};
-        if (!quiet_prelude(hv, g, gid, s) && !s.done) cf = scalar_prelude(hv, cold, g, e, gid, s, ps, c == 0);
+        QuietTry qt;
+        if (!quiet_prelude(hv, g, gid, s, qt) && !s.done) cf = scalar_prelude(hv, cold, g, e, gid, s, ps, c == 0, qt);
         WEDM_STAMP(st1);
 
         // ---- halos: OLD neighbour values, read before any lane of this wave stores.  The right
@@ -907,7 +914,7 @@ __global__ void __launch_bounds__(256, 2) wedm_step_fused(const KArgs k) {
         }
     }
     if (live && c == 0) {
-        if (k.hot.reward_mode && !frozen0) write_reward(cold, e, s);
+        if (WEDM_REWARD_ON(cold) && !frozen0) write_reward(cold, e, s);
         store_env(cold, e, s);
     }
 }
@@ -986,11 +993,11 @@ __global__ void __launch_bounds__(256, 2) wedm_step_stream(const KArgs k) {
     }
     WEDM_S2_STAMP(0);  // everything requested
     // next-step autoreset (all L lanes of the environment agree)
-    const bool reinit = live && s.done && k.hot.autoreset;
+    const bool reinit = live && s.done && WEDM_AUTORESET(cold);
     if (reinit) reinit_env(cold, e, s, c == 0);
     const bool frozen0 = s.done;
     double wp0 = 0.0;  // workpiece position at the start of the launch (reward)
-    if (k.hot.reward_mode && !frozen0) wp0 = s.wp;
+    if (WEDM_REWARD_ON(cold) && !frozen0) wp0 = s.wp;
     if (!s.done) {
         s.ipk = peak_current(cold, s.mode);
         init_persist(k.hot, cold, e, s, ps);
@@ -1036,9 +1043,10 @@ __global__ void __launch_bounds__(256, 2) wedm_step_stream(const KArgs k) {
         if (__all(s.done) && !tracing) break;
         const bool last = it + 1 == k.n_substeps;
         Coef cf{0.0f, 0.0f, 0, -1};
-        if (!quiet_prelude(hv, g, gid, s)) {
+        QuietTry qt;
+        if (!quiet_prelude(hv, g, gid, s, qt)) {
             quiet_only = false;
-            if (!s.done) cf = scalar_prelude(hv, cold, g, e, gid, s, ps, c == 0);
+            if (!s.done) cf = scalar_prelude(hv, cold, g, e, gid, s, ps, c == 0, qt);
         }
         // ---- halos: OLD neighbour values, read before any lane of this wave stores.  The right
         // halo goes into the chunk's extra LDS row C, so cell C-1 is walked like any other.
@@ -1223,7 +1231,7 @@ __global__ void __launch_bounds__(256, 2) wedm_step_stream(const KArgs k) {
         if (patch1 >= 0 && patch1 < jn && ((stored >> (patch1 >> 3)) & 1u)) *(float*)(Tw + offc + (uint32_t)patch1 * rowb) = col[patch1 * 256];
     }
     if (live && c == 0 && !frozen0) {
-        if (k.hot.reward_mode && cold->s.reward) {
+        if (WEDM_REWARD_ON(cold)) {
             const double pen = opaque(cold->p)->reward_break_penalty;
             cold->s.reward[e] = (float)(s.wp - wp0) - (float)pen * (s.broken ? 1.0f : 0.0f);
         }
@@ -1303,7 +1311,7 @@ __global__ void __launch_bounds__(256, 2) wedm_step_packed(const KArgs k) {
     if (live) load_env(cold, e, s);
     else { s.done = 1; s.unwind = 0.0; s.h_base = 0.0f; s.h_zone = 0.0f; }
     float* col = lds + tid;
-    const bool reinit = live && s.done && k.hot.autoreset;  // next-step autoreset (all L lanes of the environment agree)
+    const bool reinit = live && s.done && WEDM_AUTORESET(cold);  // next-step autoreset (all L lanes of the environment agree)
     const bool frozen0 = s.done && !reinit;
     if (reinit) {
         reinit_env(cold, e, s, c == 0);
@@ -1359,7 +1367,8 @@ __global__ void __launch_bounds__(256, 2) wedm_step_packed(const KArgs k) {
         WEDM_STAMP(st1);
         if (was_quiet) { accN += st1 - st0; ++cntN; } else { accB += st1 - st0; ++cntB; }  // quiet / general prelude
 #else
-        if (!quiet_prelude(hv, g, gid, s) && !s.done) cf = scalar_prelude(hv, cold, g, e, gid, s, ps, c == 0);
+        QuietTry qt;
+        if (!quiet_prelude(hv, g, gid, s, qt) && !s.done) cf = scalar_prelude(hv, cold, g, e, gid, s, ps, c == 0, qt);
         WEDM_STAMP(st1);
 #endif
 
@@ -1566,7 +1575,7 @@ __global__ void __launch_bounds__(256, 2) wedm_step_packed(const KArgs k) {
         }
     }
     if (live && c == 0) {
-        if (k.hot.reward_mode && !frozen0) write_reward(cold, e, s);
+        if (WEDM_REWARD_ON(cold) && !frozen0) write_reward(cold, e, s);
         store_env(cold, e, s);
     }
 }
@@ -1998,8 +2007,6 @@ int32_t wedm_step(wedm_ctx* ctx, int32_t n_substeps, const wedm_action_ptrs* act
     h.disable_ignition = P.disable_ignition;
     h.has_random_short = P.random_short_max_probability != 0.0 ? 1 : 0;
     h.per_env_geometry = P.per_env_geometry; h.env_id_offset = P.env_id_offset; h.n_seg = P.n_seg;
-    h.autoreset = P.autoreset; h.reward_mode = (P.reward_mode && ctx->s.reward) ? 1 : 0;
-    h.spool64 = P.spool_T; h.tref64 = P.temp_ref; h.alpha64 = P.alpha_rho; h.tdiel64 = P.dielectric_temperature;
     k.cold.p = ctx->params_dev;
     k.cold.g = ctx->g;
     k.cold.a = *action;
