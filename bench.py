@@ -221,7 +221,7 @@ def side_measurements(n_local, wire, S, device):
       * the reference's own cadence, one launch per microsecond (wedm_step(n_substeps=1));
       * a densely sparking start (15 um gap: ~5.6 sparks per environment per ms instead of ~0.7);
       * the closed loop of experiments/run_simulation.py with ITS PI voltage controller evaluated on the device
-        from the kernel-side running voltage sum (steady state after a 20 ms approach)."""
+        from the kernel-side running voltage sum (steady state after a 100 ms approach)."""
     import torch
 
     from sparc_amd import VoltageController, WireEDMEnv, run_controlled
@@ -248,7 +248,7 @@ def side_measurements(n_local, wire, S, device):
     env.state.wire_position = 10.0
     env.state.target_position = 5000.0
     ctl = VoltageController(30.0)
-    run_controlled(env, ctl, 20 * 1000 + 1)  # approach: the controller closes the 60 um gap
+    run_controlled(env, ctl, 100 * 1000 + 1)  # approach: the controller needs ~90 ms to close the 60 um gap
     torch.cuda.synchronize()
     s0 = int(env.state.spark_count.sum().item())
     t0 = time.perf_counter()

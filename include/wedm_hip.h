@@ -285,6 +285,21 @@ typedef struct wedm_trace_desc {
     int32_t reserved0;
 } wedm_trace_desc;
 
+/* Variate injection (validation mode).  Instead of its Philox stream an environment consumes caller-provided
+ * variates: what the reference drew from its own NumPy Generator(PCG64) at the call sites ignition.py:233,239,
+ * 261,327 and material.py:127 (`env.np_random`, seeded by reset(seed), wire_edm.py:55,107), laid out by physics
+ * step since the reset and by slot,  table[(step * WEDM_REPLAY_SLOTS + slot) * stride + env],  NaN where the
+ * reference drew nothing in that step.  With it the device follows a native-seed run of the reference
+ * (fixture F1) directly.  Runs on the global-memory kernel only.                                       */
+enum wedm_replay_slot {
+    WEDM_RS_DEBRIS_ROLL = 0,   /* Generator.random() compared with p_debris   (ignition.py:233) */
+    WEDM_RS_RANDOM_ROLL,       /* Generator.random() compared with p_random   (ignition.py:239) */
+    WEDM_RS_IGNITION_ROLL,     /* Generator.random() compared with lambda     (ignition.py:327) */
+    WEDM_RS_SPARK_Y,           /* Generator.uniform(0, workpiece_height)      (ignition.py:261) */
+    WEDM_RS_CRATER_UM3,        /* Generator.normal(mean, std) [um^3]          (material.py:127) */
+    WEDM_REPLAY_SLOTS
+};
+
 typedef struct wedm_ctx wedm_ctx;
 
 /* version of this header the library was built against */
@@ -309,6 +324,10 @@ int32_t wedm_reset(wedm_ctx* ctx, const uint8_t* mask, uint64_t seed, int32_t re
  * (wire_edm.py:116-157) with the same action.  n_substeps == 1 is the
  * reference's 1 us step.                                                      */
 int32_t wedm_step(wedm_ctx* ctx, int32_t n_substeps, const wedm_action_ptrs* action, void* stream);
+
+/* binds (table != NULL) or removes (table == NULL) the variate table described at wedm_replay_slot; `n_steps`
+ * physics steps are covered (an environment stepped beyond them gets its ERROR flag set).                 */
+int32_t wedm_bind_rng_replay(wedm_ctx* ctx, const double* table, int64_t n_steps);
 
 /* binds (desc != NULL) or removes (desc == NULL) the signal trace; resets the sample counter.
  * Terminated environments keep being sampled (their frozen state).                        */

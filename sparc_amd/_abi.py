@@ -144,6 +144,8 @@ class GI32(enum.IntEnum):
 
 GEOM_I32_COUNT = 6
 
+REPLAY_SLOTS = 5  # enum wedm_replay_slot: debris roll, random-short roll, ignition roll, spark y [mm], crater volume [um^3]
+
 OBS_DIM = 8
 OBS_NAMES = ("gap", "wire_velocity", "voltage", "current", "spark_state", "debris_density", "flow_rate", "tmax")
 

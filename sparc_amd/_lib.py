@@ -58,6 +58,8 @@ def load() -> C.CDLL:
     L.wedm_step.restype = C.c_int32
     L.wedm_bind_trace.argtypes = [ctx, C.POINTER(_abi.TraceDesc)]
     L.wedm_bind_trace.restype = C.c_int32
+    L.wedm_bind_rng_replay.argtypes = [ctx, C.c_void_p, C.c_int64]
+    L.wedm_bind_rng_replay.restype = C.c_int32
     L.wedm_trace_samples.argtypes = [ctx]
     L.wedm_trace_samples.restype = C.c_int64
     L.wedm_set_kernel.argtypes = [ctx, C.c_int32]
@@ -76,7 +78,7 @@ def load() -> C.CDLL:
 
 EXPORTS = (
     "wedm_abi_version", "wedm_create", "wedm_destroy", "wedm_bind_state", "wedm_bind_geometry",
-    "wedm_reset", "wedm_step", "wedm_bind_trace", "wedm_trace_samples", "wedm_set_kernel", "wedm_set_lanes", "wedm_last_kernel", "wedm_last_error",
+    "wedm_reset", "wedm_step", "wedm_bind_trace", "wedm_bind_rng_replay", "wedm_trace_samples", "wedm_set_kernel", "wedm_set_lanes", "wedm_last_kernel", "wedm_last_error",
     "wedm_sizeof_params", "wedm_debug_math",
 )
 
@@ -154,6 +156,9 @@ class HipBackend:
     def bind_trace(self, desc) -> None:
         """`desc` is an `_abi.TraceDesc` or None (unbind)."""
         self._check(self._L.wedm_bind_trace(self._ctx, C.byref(desc) if desc is not None else None))
+
+    def bind_rng_replay(self, table_ptr, n_steps: int) -> None:
+        self._check(self._L.wedm_bind_rng_replay(self._ctx, table_ptr, int(n_steps)))
 
     def trace_samples(self) -> int:
         return int(self._L.wedm_trace_samples(self._ctx))

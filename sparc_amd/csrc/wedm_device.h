@@ -257,6 +257,8 @@ struct Cold {  // everything reachable only through rare branches
     wedm_action_ptrs a;
     wedm_state_ptrs s;
     Tables tb;
+    const double* replay;   // wedm_bind_rng_replay: [step][WEDM_REPLAY_SLOTS][stride], or NULL
+    int64_t replay_steps;
 };
 
 // The kernels never touch their by-value `Cold` argument directly: they read it THROUGH the
@@ -616,9 +618,21 @@ struct QuietTry {  // what a failed quiet_prelude() hands on: the step's Philox 
     bool have_w;
 };
 
+// REPLAY: the variates come from the caller's table (wedm_bind_rng_replay) instead of Philox — the reference's own
+// draws, so that a native-seed run of the reference can be followed on the device (validation mode, global kernel).
+template <bool REPLAY = false>
 __device__ __forceinline__ Coef scalar_prelude(const Hot& p, const ColdRef cold, const Geom& g, int64_t e,
                                                uint32_t gid, Env& s, Persist& ps, bool writer,
                                                const QuietTry& qt = QuietTry{W4{0u, 0u, 0u, 0u}, false}) {
+    double rv[WEDM_REPLAY_SLOTS] = {0.0, 0.0, 0.0, 0.0, 0.0};
+    if (REPLAY) {
+        const ColdPtr c = cold.get();
+        int64_t step = (int64_t)s.time / p.dt_us;
+        if (step >= c->replay_steps) { s.err = 1; step = c->replay_steps - 1; }
+        const double* rp = c->replay + step * (int64_t)WEDM_REPLAY_SLOTS * c->s.stride + e;
+#pragma unroll
+        for (int q = 0; q < WEDM_REPLAY_SLOTS; ++q) rv[q] = rp[(int64_t)q * c->s.stride];
+    }
     // ---- control-step latch (wire_edm.py:117-121,162-170)
     s.ctrl = s.tss >= p.servo_interval;
     if (s.ctrl) {
@@ -654,7 +668,8 @@ __device__ __forceinline__ Coef scalar_prelude(const Hot& p, const ColdRef cold,
         // every uniform is >= 2^-33 and 1/(1+e^ex) < 2^-33 for ex > 24: the roll cannot succeed,
         // so the exponential need not be evaluated there (same decision, exactly)
         double p_d = (hard || ex < -500) ? 1.0 : 0.0;
-        if (!timers && !hard && ex <= 24.0 && ex >= -500) p_d = 1.0 / (1.0 + portable_exp(ex));
+        // (a native NumPy uniform can be arbitrarily small: with injected variates the whole branch of ignition.py:136-146)
+        if (!timers && !hard && ex <= (REPLAY ? 500.0 : 24.0) && ex >= -500) p_d = 1.0 / (1.0 + portable_exp(ex));
         double p_r = 0.0;
         if (p.has_random_short) {  // ignition.py:221-230; max_probability == 0 by default
             const wedm_params* c = opaque(cold->p);
@@ -678,8 +693,8 @@ __device__ __forceinline__ Coef scalar_prelude(const Hot& p, const ColdRef cold,
         // integer -> double conversions are skipped for the whole wave
         bool new_d = false, new_r = false;
         if (__any(!timers && (p_d > 0.0 || p_r > 0.0))) {
-            new_d = !timers && (u32_to_unit(w.x) < p_d);
-            new_r = !timers && !new_d && (u32_to_unit(w.y) < p_r);
+            new_d = !timers && ((REPLAY ? rv[WEDM_RS_DEBRIS_ROLL] : u32_to_unit(w.x)) < p_d);
+            new_r = !timers && !new_d && ((REPLAY ? rv[WEDM_RS_RANDOM_ROLL] : u32_to_unit(w.y)) < p_r);
         }
         if (new_d || new_r) {  // rare: a short begins (durations are cold parameters)
             const wedm_params* c = opaque(cold->p);
@@ -701,7 +716,7 @@ __device__ __forceinline__ Coef scalar_prelude(const Hot& p, const ColdRef cold,
         // ---- spark state machine (ignition.py:186-195, 247-319) as selects
         const bool spk = s.state == 1, pls = s.state == -1, rst = s.state == -2;
         const double lam = p.ln2 / (p.ignition_a * (d0 * d0) + p.ignition_b * d0 + p.ignition_c);
-        const bool ign = idle && !shrt && (u32_to_unit(w.z) < lam);   // _should_ignite
+        const bool ign = idle && !shrt && ((REPLAY ? rv[WEDM_RS_IGNITION_ROLL] : u32_to_unit(w.z)) < lam);   // _should_ignite
         const bool to_pulse = idle && shrt;                           // short during idle -> pulse
         const int32_t dur1 = s.dur + 1;
         const double ddur = (double)dur1;
@@ -716,7 +731,7 @@ __device__ __forceinline__ Coef scalar_prelude(const Hot& p, const ColdRef cold,
         s.I = burning ? Ipk : 0.0;
         if (ign) {  // rare: spark location, Generator.uniform(0, h)
             const double h = WEDM_COLD_GEOM_F64(cold, p, WEDM_G_HEIGHT, workpiece_height);
-            s.y = 0.0 + (h - 0.0) * u32_to_unit(w.w);
+            s.y = REPLAY ? rv[WEDM_RS_SPARK_Y] : 0.0 + (h - 0.0) * u32_to_unit(w.w);
         }
         s.y = (to_pulse || end_rest) ? __builtin_nan("") : s.y;
         s.dur = idle ? ((ign || to_pulse) ? 0 : s.dur) : (end_rest ? 0 : dur1);
@@ -730,8 +745,13 @@ __device__ __forceinline__ Coef scalar_prelude(const Hot& p, const ColdRef cold,
         const Tables tb{cc->tb.mode_current, cc->tb.crater_mean, cc->tb.crater_std, cc->tb.crater_depth, cc->tb.crater_valid};
         int m = s.mode == 0 ? 1 : s.mode;  // None -> "I1" (material.py:104-105)
         if (m < 1 || m > WEDM_MAX_MODE || !tb.crater_valid[m]) { s.err = 1; m = 1; }
-        double z = philox_std_normal(s.key0, s.key1, t, ep, gid);
-        double vol = tb.crater_mean[m] + tb.crater_std[m] * z;
+        double vol;
+        if (REPLAY) {
+            vol = rv[WEDM_RS_CRATER_UM3];
+        } else {
+            const double z = philox_std_normal(s.key0, s.key1, t, ep, gid);
+            vol = tb.crater_mean[m] + tb.crater_std[m] * z;
+        }
         if (!(vol > 0)) vol = 0;
         s.sparks += 1;
         if (writer && cc->s.stats) crater_stats_update(cc->s.stats + e, cc->s.stride, vol);

@@ -156,7 +156,7 @@ __device__ __forceinline__ float stencil_pass(const TA& T, const Geom& g, const 
     return tmax;
 }
 
-template <bool TRACE, bool F64, class TA>
+template <bool TRACE, bool F64, bool REPLAY, class TA>
 __device__ __forceinline__ void run_substeps(const KArgs& k, const ColdRef cold, const Geom& g, int64_t e,
                                              uint32_t gid, Env& s, const TA& T) {
     Persist ps;
@@ -168,7 +168,7 @@ __device__ __forceinline__ void run_substeps(const KArgs& k, const ColdRef cold,
     (void)trace_next; (void)trace_slot;
     for (int it = 0; it < k.n_substeps; ++it) {
         if (!s.done) {
-            Coef c = scalar_prelude(k.hot, cold, g, e, gid, s, ps, true);  // single steps: the quiet test does not pay
+            Coef c = scalar_prelude<REPLAY>(k.hot, cold, g, e, gid, s, ps, true);  // single steps: the quiet test does not pay
             float tmax = stencil_pass<F64>(T, g, c, ps, k.hot, f64c, s.h_base, s.h_zone);
             scalar_epilogue(k.hot, s, tmax);
             if (s.ctrl) control_step_outputs(cold, e, s, true);
@@ -180,7 +180,7 @@ __device__ __forceinline__ void run_substeps(const KArgs& k, const ColdRef cold,
     }
 }
 
-template <bool TRACE, bool F64>
+template <bool TRACE, bool F64, bool REPLAY>
 __global__ void __launch_bounds__(256) wedm_step_global(const KArgs k) {
     const ColdRef cold = kernarg_cold();
     const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -198,7 +198,7 @@ __global__ void __launch_bounds__(256) wedm_step_global(const KArgs k) {
     s.ipk = s.done ? 0.0 : peak_current(cold, s.mode);
     Geom g;
     load_geom(k.hot, cold, e, g);
-    run_substeps<TRACE, F64>(k, cold, g, e, k.hot.env_id_offset + (uint32_t)e, s, T);
+    run_substeps<TRACE, F64, REPLAY>(k, cold, g, e, k.hot.env_id_offset + (uint32_t)e, s, T);
     if (WEDM_REWARD_ON(cold) && !frozen) write_reward(cold, e, s);
     store_env(cold, e, s);
 }
@@ -1664,6 +1664,8 @@ struct wedm_ctx {
     bool walk_ok[5] = {false, false, false, false, false};
     int32_t walk_C[5] = {0, 0, 0, 0, 0};
     // signal trace (wedm_bind_trace): descriptor, microseconds stepped and samples written since the bind
+    const double* replay = nullptr;    // wedm_bind_rng_replay
+    int64_t replay_steps = 0;
     bool trace_on = false;
     wedm_trace_desc trace{};
     int64_t trace_us = 0, trace_count = 0;
@@ -1937,6 +1939,14 @@ int32_t wedm_bind_trace(wedm_ctx* ctx, const wedm_trace_desc* desc) {
 
 int64_t wedm_trace_samples(wedm_ctx* ctx) { return ctx ? ctx->trace_count : 0; }
 
+int32_t wedm_bind_rng_replay(wedm_ctx* ctx, const double* table, int64_t n_steps) {
+    if (!ctx) return WEDM_ERR_BAD_ARG;
+    if (table && n_steps < 1) return fail(ctx, WEDM_ERR_BAD_ARG, "wedm_bind_rng_replay: n_steps must be >= 1");
+    ctx->replay = table;
+    ctx->replay_steps = table ? n_steps : 0;
+    return WEDM_OK;
+}
+
 int32_t wedm_set_kernel(wedm_ctx* ctx, int32_t variant) {
     if (!ctx) return WEDM_ERR_BAD_ARG;
     if (variant < 0 || variant > 6) return fail(ctx, WEDM_ERR_BAD_ARG, "wedm_set_kernel: variant must be 0..6");
@@ -2012,6 +2022,8 @@ int32_t wedm_step(wedm_ctx* ctx, int32_t n_substeps, const wedm_action_ptrs* act
     k.cold.a = *action;
     k.cold.s = ctx->s;
     k.cold.tb = ctx->tb;
+    k.cold.replay = ctx->replay;
+    k.cold.replay_steps = ctx->replay_steps;
     k.num_envs = ctx->num_envs;
     k.n_substeps = n_substeps;
     k.n_seg_max = ctx->n_seg_max;
@@ -2102,6 +2114,13 @@ int32_t wedm_step(wedm_ctx* ctx, int32_t n_substeps, const wedm_action_ptrs* act
     const bool stream_auto = stream_ok && ctx->walk_C[lanes_index(slanes)] <= 64 &&
                              (long)((ctx->num_envs + (256 / slanes) - 1) / (256 / slanes)) * 4 <= 2048;
     int variant = ctx->variant;
+    if (ctx->replay) {
+        if (variant != 0 && variant != 1)
+            return fail(ctx, WEDM_ERR_UNSUPPORTED, "wedm_step: injected variates (wedm_bind_rng_replay) run on kernel 1 only");
+        if (P.stencil_mode != 0)
+            return fail(ctx, WEDM_ERR_UNSUPPORTED, "wedm_step: injected variates and stencil_mode 1 cannot be combined");
+        variant = 1;
+    }
     const bool f64 = P.stencil_mode != 0;
     if (f64) {
         // Numba's typing of the stencil exists in the predicated kernels only (any geometry): LDS-staged when
@@ -2135,9 +2154,10 @@ int32_t wedm_step(wedm_ctx* ctx, int32_t n_substeps, const wedm_action_ptrs* act
     size_t fl = 0;
     if (variant == 1) {
         grid = (ctx->num_envs + 255) / 256;
-        fn = f64 ? (tr ? (const void*)wedm_step_global<true, true> : (const void*)wedm_step_global<false, true>)
-                 : (tr ? (const void*)wedm_step_global<true, false> : (const void*)wedm_step_global<false, false>);
-        std::snprintf(name, sizeof(name), "wedm_step_global%s<<<%d,256>>> n_sub=%d", f64 ? "[f64 stencil]" : "", grid, n_substeps);
+        fn = ctx->replay ? (tr ? (const void*)wedm_step_global<true, false, true> : (const void*)wedm_step_global<false, false, true>)
+           : f64 ? (tr ? (const void*)wedm_step_global<true, true, false> : (const void*)wedm_step_global<false, true, false>)
+                 : (tr ? (const void*)wedm_step_global<true, false, false> : (const void*)wedm_step_global<false, false, false>);
+        std::snprintf(name, sizeof(name), "wedm_step_global%s<<<%d,256>>> n_sub=%d", ctx->replay ? "[injected variates]" : f64 ? "[f64 stencil]" : "", grid, n_substeps);
     } else if (variant == 5) {
         grid = (ctx->num_envs + 63) / 64;
         fn = tr ? (const void*)wedm_step_split<true> : (const void*)wedm_step_split<false>;

@@ -374,6 +374,29 @@ class WireEDMEnv:
         self._trace = trace
         return trace
 
+    def bind_rng_replay(self, table) -> None:
+        """Validation mode: feed the environments caller-provided variates instead of their Philox streams —
+        e.g. the draws a native-seed run of the reference made from its NumPy ``Generator(PCG64)``
+        (``env.np_random``; call sites ignition.py:233,239,261,327, material.py:127).  ``table`` is
+        ``float64[n_steps, 5]`` (the same variates for every environment) or ``float64[n_steps, 5, num_envs]``:
+        per physics step since the reset the debris-short roll, the random-short roll, the ignition roll, the
+        spark location [mm] and the crater volume [um^3], NaN where nothing is drawn (`_abi.REPLAY_SLOTS`).
+        ``None`` returns to Philox.  Runs on the global-memory kernel."""
+        if table is None:
+            self._backend.bind_rng_replay(None, 0)
+            self._replay = None
+            return
+        t = torch.as_tensor(table, dtype=torch.float64)
+        if t.dim() == 2:
+            t = t.unsqueeze(-1).expand(-1, -1, self.num_envs)
+        if t.dim() != 3 or t.shape[1] != _abi.REPLAY_SLOTS or t.shape[2] != self.num_envs:
+            raise ValueError(f"table must be [n_steps, {_abi.REPLAY_SLOTS}] or [n_steps, {_abi.REPLAY_SLOTS}, num_envs]")
+        buf = torch.full((t.shape[0], _abi.REPLAY_SLOTS, self.state.stride), float("nan"), dtype=torch.float64,
+                         device=self.device)
+        buf[:, :, : self.num_envs] = t.to(self.device)
+        self._replay = buf  # keep alive: the library only borrows the pointer
+        self._backend.bind_rng_replay(buf.data_ptr(), int(t.shape[0]))
+
     def unbind_trace(self) -> None:
         self._backend.bind_trace(None)
         self._trace = None

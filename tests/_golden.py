@@ -178,3 +178,20 @@ def replay(fx: Fixture, *, math_mode=orc.MATH_LIBM, stencil_mode=orc.STENCIL_F32
     if fx.meta["rng"] == "native" and env.rng.replay_pos != len(fx.draws):
         bad.append(f"draw trace: consumed {env.rng.replay_pos} of {len(fx.draws)}")
     return bad, env
+
+
+def replay_table(fx: Fixture) -> np.ndarray:
+    """The reference's recorded draw trace (native NumPy PCG64 fixtures) as the per-step slot table of
+    `wedm_bind_rng_replay` (include/wedm_hip.h): float64[n_steps, 5], NaN where nothing was drawn.  The number of
+    draws of a step identifies the calls: 1 = debris roll only (it succeeded), 2 = + random-short
+    roll, 3 = + ignition roll, 5 = + spark location and crater volume; 0 = a short timer was running."""
+    n_draws = fx.int_row("n_draws")
+    table = np.full((fx.n_steps, 5), np.nan)
+    pos = 0
+    for step in range(fx.n_steps):
+        k = int(n_draws[step])
+        assert k in (0, 1, 2, 3, 5), (step, k)
+        table[step, :k] = fx.draws[pos:pos + k]
+        pos += k
+    assert pos == len(fx.draws)
+    return table

@@ -102,6 +102,9 @@ class OracleBackend:
     def bind_trace(self, desc):
         self._trace, self._trace_us, self._trace_count = desc, 0, 0
 
+    def bind_rng_replay(self, table_ptr, n_steps):
+        raise NotImplementedError("the CPU seam replays recorded draws per environment through oracle.Env.rng (RNG_REPLAY)")
+
     def trace_samples(self):
         return self._trace_count
 

@@ -1094,3 +1094,27 @@ def test_float64_stencil_mode_stays_within_the_stated_tolerance_of_the_reference
     env = env_from_fixture(fx, env_id + 64, device="cuda:0", stencil_dtype="float64")
     got = run_fixture_through_trace(env, fx, exact_floats=False, T_atol=1.3e-4)
     assert (got["spark_state"] == 1).sum() > 10 and "[f64 stencil]" in env._backend.last_kernel()
+
+
+def test_native_seed_reference_run_followed_on_the_gpu(golden_dir):
+    """Fixture F1 = BASELINE configs[0], the reference's OWN NumPy PCG64 stream (reset(seed=0), 10 000 us,
+    SURVEY.md §8c known answers).  The device consumes the reference's recorded draws through the variate-injection
+    mode (wedm_bind_rng_replay) and must follow the reference step by step: discrete state, clocks, positions,
+    voltage / current exact, debris / flow to 1e-12, temperatures to 1e-4 K, read back through the in-kernel trace."""
+    from tests._fixture_env import env_from_fixture, run_fixture_through_trace
+    from tests._golden import Fixture, replay_table
+
+    fx = Fixture(golden_dir / "f1_config1_native.npz")
+    env = env_from_fixture(fx, 64, device="cuda:0")
+    env.bind_rng_replay(replay_table(fx))
+    fx.meta["env_id"] = 5                       # any environment: all consume the same variates
+    got = run_fixture_through_trace(env, fx, exact_floats=False)
+    assert "[injected variates]" in env._backend.last_kernel()
+    assert (got["spark_state"] == 1).sum() == 36 and (got["spark_state"] == -2).sum() == 960   # SURVEY.md §8c F1
+    st = env.state
+    assert float(st.workpiece_position[5]) == float(fx.float_row("workpiece_position")[-1])
+    assert float(st.wire_position[5]) == float(fx.float_row("wire_position")[-1]) and int(st.spark_count[5]) == 12
+    assert not bool(st.error.any())
+    env.bind_rng_replay(None)
+    env.step_many(env.make_action(), 10)
+    assert "wedm_step_packed" in env._backend.last_kernel() or "wedm_step_fused" in env._backend.last_kernel()

@@ -130,3 +130,18 @@ def test_geometry_table(orc, golden_dir):
                   "breaking_temperature", "cavity_coeff", "debris_removal_per_us", "damping_coeff",
                   "stiffness_coeff", "max_jerk_dt", "dt_s"):
             assert getattr(c, k) == r[k], (k, getattr(c, k), r[k], r)
+
+
+def test_native_draw_trace_converts_to_the_replay_slot_table(golden_dir):
+    """Host side of the device's variate-injection mode (wedm_bind_rng_replay): the reference's own PCG64 draws of
+    fixture F1, laid out by step and slot."""
+    from tests._golden import Fixture, replay_table
+
+    fx = Fixture(golden_dir / "f1_config1_native.npz")
+    table = replay_table(fx)
+    assert table.shape == (10000, 5)
+    drawn = ~np.isnan(table)
+    assert drawn.sum() == len(fx.draws) == 29028        # SURVEY.md §8a a11: 29 004 random + 12 uniform + 12 normal
+    assert (drawn.sum(axis=1) == fx.int_row("n_draws")).all()
+    sparks = drawn[:, 4].sum()
+    assert sparks == 12 and np.all(table[drawn[:, 3], 3] < 20.0) and np.all(table[drawn[:, 4], 4] > 0)
