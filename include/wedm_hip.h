@@ -244,6 +244,12 @@ typedef struct wedm_state_ptrs {
     int64_t stride;     /* >= num_envs, multiple of 64 recommended */
     double* stats;      /* [WEDM_STAT_COUNT][stride] or NULL (statistics not kept) */
     float* reward;      /* [stride] or NULL; written when wedm_params.reward_mode != 0 */
+    /* `MaterialRemovalModule.crater_volumes_um3` (material.py:133): every sampled crater volume [um^3] of an
+     * environment, in spark order — crater number k (0-based since the reset) lands in
+     * crater_log[(k % crater_log_capacity) * stride + env]; WEDM_I_SPARK_COUNT says how many there are.  NULL /
+     * capacity 0: not kept.                                                                              */
+    double* crater_log; /* [crater_log_capacity][stride] or NULL */
+    int64_t crater_log_capacity;
 } wedm_state_ptrs;
 
 typedef struct wedm_geom_ptrs {

@@ -111,6 +111,7 @@ class Env(C.Structure):
         ("h_base", C.c_float), ("h_zone", C.c_float),
         ("prev_accel", _d), ("volt_acc", _d), ("volt_sum", _d), ("spark_count", _i),
         ("crater_stat_sum", _d), ("crater_stat_sumsq", _d), ("crater_stat_min", _d), ("crater_stat_max", _d),
+        ("crater_log", C.c_void_p), ("crater_log_capacity", C.c_int64), ("crater_log_stride", C.c_int64),
         ("tmax", C.c_float),
         ("last_terminated", _i), ("last_ctrl_step", _i), ("last_early_return", _i),
         ("T", C.c_float * MAX_SEG), ("dT", C.c_float * MAX_SEG),

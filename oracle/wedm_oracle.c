@@ -587,6 +587,8 @@ static void material_update(wedm_oracle_env* e) {
         }
         double sampled_um3 = rng_normal(e, c->crater_mean[mode], c->crater_std[mode]); /* :127 */
         if (!(sampled_um3 > 0)) sampled_um3 = 0; /* max(0, x) :130 */
+        if (e->crater_log && e->crater_log_capacity > 0) /* crater_volumes_um3.append(sampled_volume_um3) :133 */
+            e->crater_log[((int64_t)e->spark_count % e->crater_log_capacity) * e->crater_log_stride] = sampled_um3;
         e->spark_count += 1;                     /* :133 */
         /* running form of get_crater_statistics (material.py:207-227) */
         e->crater_stat_sum += sampled_um3;
@@ -1129,6 +1131,9 @@ int32_t wedm_oracle_step_batch(const wedm_params* p, const wedm_state_ptrs* s, c
             if (p->per_env_geometry) apply_geometry(g, stride, e, &v->c);
             if (v->c.n_seg > WEDM_ORACLE_MAX_SEG || v->c.n_seg < 1) { bad = 1; continue; }
             gather_env(s, e, v);
+            v->crater_log = s->crater_log ? s->crater_log + e : NULL;
+            v->crater_log_capacity = s->crater_log_capacity;
+            v->crater_log_stride = stride;
             v->rng.env_id = p->env_id_offset + (uint32_t)e;
             wedm_oracle_action act = {a->servo[e], a->target_voltage[e], a->on_time[e], a->off_time[e],
                                       a->current_mode[e]};

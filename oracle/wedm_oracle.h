@@ -157,6 +157,9 @@ typedef struct wedm_oracle_env {
     int32_t spark_count;                                    /* len(crater_volumes_um3) */
     /* running statistics of crater_volumes_um3 (material.py:207-227): sum, sum of squares, min, max */
     double crater_stat_sum, crater_stat_sumsq, crater_stat_min, crater_stat_max;
+    /* crater_volumes_um3 (material.py:133), batch driver only: where this environment's list lives (SoA column) */
+    double* crater_log;
+    int64_t crater_log_capacity, crater_log_stride;
     float tmax;
     /* step() outputs */
     int32_t last_terminated, last_ctrl_step, last_early_return;

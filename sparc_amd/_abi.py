@@ -195,6 +195,7 @@ class StatePtrs(C.Structure):
     _fields_ = [
         ("f64", C.c_void_p), ("i32", C.c_void_p), ("i8", C.c_void_p), ("T", C.c_void_p),
         ("obs", C.c_void_p), ("stride", C.c_int64), ("stats", C.c_void_p), ("reward", C.c_void_p),
+        ("crater_log", C.c_void_p), ("crater_log_capacity", C.c_int64),
     ]
 
 

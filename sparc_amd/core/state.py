@@ -50,7 +50,7 @@ _FIELDS = {
 
 
 class BatchedEDMState:
-    def __init__(self, num_envs: int, n_seg_max: int, obs_dim: int, device):
+    def __init__(self, num_envs: int, n_seg_max: int, obs_dim: int, device, crater_log_capacity: int = 0):
         stride = (num_envs + 63) // 64 * 64
         object.__setattr__(self, "num_envs", num_envs)
         object.__setattr__(self, "n_seg_max", n_seg_max)
@@ -67,6 +67,9 @@ class BatchedEDMState:
         object.__setattr__(self, "stats", torch.zeros((_abi.STAT_COUNT, stride), dtype=torch.float64, **kw))
         # per-launch reward written by the kernels when wedm_params.reward_mode != 0
         object.__setattr__(self, "reward", torch.zeros((1, stride), dtype=torch.float32, **kw))
+        # `MaterialRemovalModule.crater_volumes_um3` (material.py:133) as a ring per environment, optional
+        object.__setattr__(self, "crater_log", torch.zeros((crater_log_capacity, stride), dtype=torch.float64, **kw)
+                           if crater_log_capacity > 0 else None)
         # read-only attributes computed on access (registered by the environment):
         # dielectric_flow_rate (dielectric.py:160-162), wire_average_temperature (wire.py:339-347)
         object.__setattr__(self, "derived", {})
@@ -116,7 +119,9 @@ class BatchedEDMState:
     def pointers(self, with_obs: bool) -> _abi.StatePtrs:
         return _abi.StatePtrs(self.f64.data_ptr(), self.i32.data_ptr(), self.i8.data_ptr(), self.T.data_ptr(),
                               self.obs.data_ptr() if with_obs else None, self.stride, self.stats.data_ptr(),
-                              self.reward.data_ptr())
+                              self.reward.data_ptr(),
+                              self.crater_log.data_ptr() if self.crater_log is not None else None,
+                              self.crater_log.shape[0] if self.crater_log is not None else 0)
 
     def field_names(self):
         return tuple(_FIELDS)

@@ -753,6 +753,8 @@ __device__ __forceinline__ Coef scalar_prelude(const Hot& p, const ColdRef cold,
             vol = tb.crater_mean[m] + tb.crater_std[m] * z;
         }
         if (!(vol > 0)) vol = 0;
+        if (writer && cc->s.crater_log && cc->s.crater_log_capacity > 0)  // crater_volumes_um3.append (material.py:133)
+            cc->s.crater_log[((int64_t)s.sparks % cc->s.crater_log_capacity) * cc->s.stride + e] = vol;
         s.sparks += 1;
         if (writer && cc->s.stats) crater_stats_update(cc->s.stats + e, cc->s.stride, vol);
         double crater = vol / 1e9;

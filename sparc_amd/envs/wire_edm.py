@@ -107,6 +107,7 @@ class WireEDMEnv:
         reward: Optional[str] = None,
         reward_break_penalty: float = 10.0,
         stencil_dtype: str = "float32",
+        crater_log_capacity: int = 0,
         backend: Optional[Callable] = None,
     ):
         """Beyond the reference's keywords (wire_edm.py:22-34):
@@ -119,7 +120,9 @@ class WireEDMEnv:
         launch minus ``reward_break_penalty`` if the wire broke, written by the kernels (float32).
         ``stencil_dtype``: ``"float32"`` = the wire stencil exactly as the reference evaluates
         wire.py:58-123 without Numba (NumPy-2 scalar promotion: float32 op for op); ``"float64"`` =
-        as Numba types the same lines (float64 expressions rounded at each float32 store)."""
+        as Numba types the same lines (float64 expressions rounded at each float32 store).
+        ``crater_log_capacity``: keep the last that many sampled crater volumes of every environment
+        (`MaterialRemovalModule.crater_volumes_um3`, material.py:133) — see `get_crater_volumes`."""
         self.render_mode = render_mode
         if mechanics_control_mode not in ["position", "velocity"]:
             raise ValueError(f"mechanics_control_mode must be 'position' or 'velocity', got {mechanics_control_mode}")
@@ -182,7 +185,8 @@ class WireEDMEnv:
             reward_break_penalty=reward_break_penalty, stencil_mode=1 if stencil_dtype == "float64" else 0)
 
         # ---- state (caller-owned memory) + backend
-        self.state = BatchedEDMState(self.num_envs, self.n_segments, _abi.OBS_DIM, self.device)
+        self.state = BatchedEDMState(self.num_envs, self.n_segments, _abi.OBS_DIM, self.device,
+                                     crater_log_capacity=int(crater_log_capacity))
         from ..utils.logger import dielectric_flow_rate
 
         base_flow = float(self.dielectric_params.base_flow_rate)
@@ -481,6 +485,19 @@ class WireEDMEnv:
         return {"total_craters": n, "mean_volume_um3": mean, "std_volume_um3": torch.sqrt(var),
                 "min_volume_um3": torch.where(none, zero, st[STAT.CRATER_MIN]),
                 "max_volume_um3": torch.where(none, zero, st[STAT.CRATER_MAX])}
+
+    def get_crater_volumes(self, env_index: int) -> torch.Tensor:
+        """`MaterialRemovalModule.crater_volumes_um3` (material.py:133) of one environment since its reset, oldest
+        first, from the ring the kernels fill at every fresh spark (needs ``crater_log_capacity``; when more craters
+        were sampled than the ring holds, the newest ``capacity`` of them)."""
+        log = self.state.crater_log
+        if log is None:
+            raise RuntimeError("construct the environment with crater_log_capacity > 0 to keep the crater volumes")
+        n, cap = int(self.state.spark_count[env_index].item()), log.shape[0]
+        if n <= cap:
+            return log[:n, env_index].clone()
+        idx = torch.arange(n - cap, n, device=log.device) % cap
+        return log[idx, env_index]
 
     def get_crater_count(self) -> torch.Tensor:
         """`len(MaterialRemovalModule.crater_volumes_um3)` (material.py:133), per environment."""

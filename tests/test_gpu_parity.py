@@ -668,7 +668,7 @@ def test_crater_statistics_on_gpu_match_reference_fixture(golden_dir):
     fx = Fixture(golden_dir / "f10_crater_statistics_philox_env1.npz")
     total, mean, std, vmin, vmax = fx.data["crater_stats"].tolist()
     for variant, lanes in ((0, 0), (3, 16), (1, 0), (5, 0)):
-        env = WireEDMEnv(num_envs=64, device="cuda:0")
+        env = WireEDMEnv(num_envs=64, device="cuda:0", crater_log_capacity=160)
         env.set_kernel(variant, lanes)
         env.reset(seed=81)
         close_gap(env, 22.0, 10.0, 5000.0)
@@ -680,6 +680,10 @@ def test_crater_statistics_on_gpu_match_reference_fixture(golden_dir):
         assert got["min_volume_um3"] == vmin and got["max_volume_um3"] == vmax
         assert abs(got["mean_volume_um3"] - mean) <= 1e-12 * mean and abs(got["std_volume_um3"] - std) <= 1e-12 * std
         assert float(env.state.workpiece_position[1]) == float(fx.float_row("workpiece_position")[-1])
+        # the whole `crater_volumes_um3` list of the reference (material.py:133), from the kernel-side crater log
+        vols = env.get_crater_volumes(1).cpu().numpy()
+        assert vols.shape == fx.data["crater_volumes_um3"].shape
+        np.testing.assert_allclose(vols, fx.data["crater_volumes_um3"], rtol=1e-14, atol=0)
 
 
 def test_checkpoint_resume_on_gpu(tmp_path):

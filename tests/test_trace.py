@@ -235,8 +235,8 @@ def test_logger_and_voltage_controller_share_one_trace():
 
 
 # ------------------------------------------------------------------ running statistics (§8f-4)
-def crater_env(n, backend, device="cpu"):
-    env = WireEDMEnv(num_envs=n, device=device, backend=backend)
+def crater_env(n, backend, device="cpu", **kw):
+    env = WireEDMEnv(num_envs=n, device=device, backend=backend, **kw)
     env.reset(seed=81)
     env.state.workpiece_position = 22.0
     env.state.wire_position = 10.0
@@ -250,7 +250,8 @@ def test_crater_statistics_match_the_reference(golden_dir):
     count / min / max exact, mean and std to 1e-12 (np.mean / np.std sum pairwise, the kernel
     updates Welford's recurrence; both are float64)."""
     fx = Fixture(golden_dir / "f10_crater_statistics_philox_env1.npz")
-    env = crater_env(3, LibmOracleBackend)
+    env = crater_env(3, LibmOracleBackend, crater_log_capacity=256)
+    small = crater_env(3, LibmOracleBackend, crater_log_capacity=32)     # a ring shorter than the list
     act = env.make_action(0.05, 80.0, 13, 2.0, 20.0)
     assert (env.get_crater_statistics()["total_craters"] == 0).all()
     trace = env.bind_trace(["last_crater_volume", "spark_state", "spark_duration"], capacity=fx.n_steps, envs=(1, 1))
@@ -268,6 +269,13 @@ def test_crater_statistics_match_the_reference(golden_dir):
     fresh = (t["spark_state"][:, 0] == 1) & (t["spark_duration"][:, 0] == 0)
     vols_mm3 = t["last_crater_volume"][:, 0][fresh].numpy()
     assert np.array_equal(vols_mm3, fx.data["crater_volumes_um3"] / 1e9)
+    # ... and directly from the crater log the kernels keep (`crater_volumes_um3`, material.py:133)
+    assert np.array_equal(env.get_crater_volumes(1).numpy(), fx.data["crater_volumes_um3"])
+    for _ in range(12):
+        small.step_many(small.make_action(0.05, 80.0, 13, 2.0, 20.0), 1000)
+    assert np.array_equal(small.get_crater_volumes(1).numpy(), fx.data["crater_volumes_um3"][-32:])
+    with pytest.raises(RuntimeError):
+        crater_env(2, OracleBackend).get_crater_volumes(0)
     # environments without craters report zeros, like the reference's empty case
     idle = WireEDMEnv(num_envs=2, device="cpu", backend=OracleBackend)
     idle.reset(seed=1)
