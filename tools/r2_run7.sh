@@ -15,6 +15,6 @@ for r in csv.DictReader(open("$f")):
     if "wedm_step" in r["Name"]: print("$1 k$2 l$3", r["Name"], "calls", r["Calls"], "avg_us %.2f" % (float(r["AverageNs"])/1e3))
 PY
 }
-run config3 9 2
-run config4 9 8
-run config2 9 8
+run config3 6 2
+run config4 6 8
+run config2 6 8

@@ -11,7 +11,7 @@ wl = sys.argv[2] if len(sys.argv) > 2 else "config3"
 lanes = int(sys.argv[3]) if len(sys.argv) > 3 else 2
 wire = WireModuleParameters(segment_len=0.625) if wl == "config3" else WireModuleParameters()
 env = WireEDMEnv(num_envs=n, device="cuda:0", wire_params=wire)
-env.set_kernel(9, lanes)
+env.set_kernel(6, lanes)
 env.reset(seed=1234)
 act = env.make_action(0.1, 80.0, 5, 3.0, 80.0)
 nblk = (n * lanes + 255) // 256
@@ -26,7 +26,7 @@ env.step(act)
 torch.cuda.synchronize()
 print(env._backend.last_kernel())
 raw = buf.cpu().numpy().reshape(nblk * 4, 8).astype(np.float64)
-names = ["everything requested", "wire in LDS", "walk + epilogue done", "stores issued", "stores landed"]
+names = ["everything requested", "wire in LDS (barrier passed)", "walk + epilogue done", "stores issued", "stores landed"]
 idx = [0, 1, 4, 5, 6]
 prev = raw[:, 7]
 for i, nm in zip(idx, names):
