@@ -1645,6 +1645,15 @@ __global__ void wedm_debug_math_kernel(int32_t kind, const double* a, const doub
 }
 
 // =================================================================== C-ABI
+struct LaunchPlan {
+    bool valid = false;
+    const void* fn = nullptr;
+    int grid = 0;
+    size_t lds = 0;
+    const WalkTable* walk = nullptr;
+    char name[160] = {0};
+};
+
 struct wedm_ctx {
     wedm_params p;
     int32_t num_envs = 0, n_seg_max = 0;
@@ -1671,6 +1680,10 @@ struct wedm_ctx {
     int64_t trace_us = 0, trace_count = 0;
     std::string err;
     std::string last_kernel;
+    LaunchPlan plans[2][2];            // [single microsecond][trace point]: cached launch decisions
+    const LaunchPlan* last_plan = nullptr;
+    int32_t last_n_sub = 0;
+    void invalidate_plans() { for (auto& a : plans) for (auto& pl : a) pl.valid = false; }
 };
 
 static int32_t fail(wedm_ctx* ctx, int32_t code, const std::string& msg) {
@@ -1776,6 +1789,172 @@ static int32_t check_device(wedm_ctx* ctx, const char* who) {
 
 static int lanes_index(int L) { return L == 1 ? 0 : L == 2 ? 1 : L == 4 ? 2 : L == 8 ? 3 : L == 16 ? 4 : -1; }
 
+// What wedm_step launches for (single microsecond?, trace point?) under the handle's current settings: decided once
+// and cached (the decision walks a cost model over five lane counts; on the one-launch-per-microsecond path that and
+// a hipFuncSetAttribute per call were a measurable part of the host time per launch).
+static int32_t plan_launch(wedm_ctx* ctx, bool single, bool tr, LaunchPlan& out) {
+    const wedm_params& P = ctx->p;
+    // kernel 3 (one chunk per lane) and kernel 4 (two packed chunks per lane, table of 2L chunks).
+    // Auto-selection by a small cost model fitted to measurements (DESIGN.md §4):
+    //   cycles per step ~ rounds * (4500 + tiles_per_lane * 8 * cell_cost),
+    //   rounds = ceil(blocks / (256 CUs * resident blocks per CU)), resident = min(2 [VGPRs], LDS fit),
+    //   cell_cost = 90 per cell, a packed pair = 2 * 90 * 0.93.
+    const bool uniform = !ctx->p.per_env_geometry && ctx->walk_dev;
+    int lanes = ctx->lanes, planes = ctx->lanes;
+    {
+        double best3 = 1e300, best4 = 1e300;
+        int l3 = 0, l4 = 0;
+        const int Ls[5] = {1, 2, 4, 8, 16};
+        for (int i = 0; i < 5 && uniform; ++i) {
+            const int Lc = Ls[i];
+            const long blocks = (ctx->num_envs + (256 / Lc) - 1) / (256 / Lc);
+            if (ctx->walk_ok[i]) {  // kernel 3 with Lc lanes: table i
+                const size_t lds = ((size_t)ctx->walk_C[i] + 1) * 1024;
+                if (lds <= (size_t)ctx->lds_limit) {
+                    const long rb = std::min<long>(2, (long)(160 * 1024 / lds));
+                    const long rounds = (blocks + 256 * rb - 1) / (256 * rb);
+                    const double cost = rounds * (4500.0 + ((ctx->walk_C[i] + 7) / 8) * 8 * 90.0);
+                    if (cost < best3) { best3 = cost; l3 = Lc; }
+                }
+            }
+            if (Lc <= 8 && ctx->walk_ok[lanes_index(2 * Lc)]) {  // kernel 4 with Lc lanes: table of 2*Lc chunks
+                const int ti = lanes_index(2 * Lc);
+                const size_t lds = (2 * (size_t)ctx->walk_C[ti] + 2) * 1024;
+                if (lds <= (size_t)ctx->lds_limit) {
+                    const long rb = std::min<long>(2, (long)(160 * 1024 / lds));
+                    const long rounds = (blocks + 256 * rb - 1) / (256 * rb);
+                    const double cost = rounds * (4500.0 + ((ctx->walk_C[ti] + 7) / 8) * 8 * 2 * 90.0 * 0.93);
+                    if (cost < best4) { best4 = cost; l4 = Lc; }
+                }
+            }
+        }
+        if (!lanes) lanes = l3;
+        if (!planes) planes = l4;
+        ctx->auto_prefers_packed = best4 <= best3;
+    }
+    const int li = lanes_index(lanes);
+    const bool fused_ok = uniform && li >= 0 && ctx->walk_ok[li] &&
+                          ((size_t)ctx->walk_C[li] + 1) * 1024 <= (size_t)ctx->lds_limit;
+    const int pli = (planes >= 1 && planes <= 8) ? lanes_index(2 * planes) : -1;
+    const bool packed_ok = uniform && pli >= 0 && ctx->walk_ok[pli] &&
+                           (2 * (size_t)ctx->walk_C[pli] + 2) * 1024 <= (size_t)ctx->lds_limit;
+    // kernel 2 (any geometry): lanes per environment = the caller's choice, else the smallest L whose
+    // chunk fits in LDS, raised until the launch has ~2 waves per SIMD
+    int glanes = 0;
+    {
+        const int Ls[5] = {1, 2, 4, 8, 16};
+        for (int i = 0; i < 5; ++i) {
+            const size_t b = (size_t)((ctx->n_seg_max + Ls[i] - 1) / Ls[i]) * 1024;
+            if (b > (size_t)ctx->lds_limit) continue;
+            if (ctx->lanes) { if (Ls[i] == ctx->lanes) glanes = Ls[i]; continue; }
+            glanes = Ls[i];
+            const long waves = (long)((ctx->num_envs + (256 / Ls[i]) - 1) / (256 / Ls[i])) * 4;
+            if (waves >= 2048) break;
+        }
+    }
+    const bool lanes_ok = glanes > 0;
+    // kernel 6 (stream, single microseconds, uniform geometry): the caller's lane count, else the smallest L whose
+    // chunk has at most 64 cells (the registers a lane holds its chunk in; failing that at most 104)
+    int slanes = 0;
+    if (uniform && (uint64_t)ctx->n_seg_max * (uint64_t)ctx->s.stride * 4ull < (1ull << 32)) {
+        const int Ls[5] = {1, 2, 4, 8, 16};
+        for (int pass = 0; pass < 2 && !slanes; ++pass)
+            for (int i = 0; i < 5 && !slanes; ++i) {
+                if (!ctx->walk_ok[i] || ctx->walk_C[i] > (pass ? 104 : 64) ||
+                    ((size_t)ctx->walk_C[i] + 1) * 1024 > (size_t)ctx->lds_limit) continue;
+                if (ctx->lanes && Ls[i] != ctx->lanes) continue;
+                slanes = Ls[i];
+            }
+    }
+    const bool stream_ok = slanes > 0;
+    const bool stream_auto = stream_ok && ctx->walk_C[lanes_index(slanes)] <= 64 &&
+                             (long)((ctx->num_envs + (256 / slanes) - 1) / (256 / slanes)) * 4 <= 2048;
+    int variant = ctx->variant;
+    if (ctx->replay) {
+        if (variant != 0 && variant != 1)
+            return fail(ctx, WEDM_ERR_UNSUPPORTED, "wedm_step: injected variates (wedm_bind_rng_replay) run on kernel 1 only");
+        if (P.stencil_mode != 0)
+            return fail(ctx, WEDM_ERR_UNSUPPORTED, "wedm_step: injected variates and stencil_mode 1 cannot be combined");
+        variant = 1;
+    }
+    const bool f64 = P.stencil_mode != 0;
+    if (f64) {
+        // Numba's typing of the stencil exists in the predicated kernels only (any geometry): LDS-staged when
+        // a chunk fits, else in place in global memory
+        if (variant != 0 && variant != 1 && variant != 2)
+            return fail(ctx, WEDM_ERR_UNSUPPORTED, "wedm_step: stencil_mode 1 (float64 stencil expressions) runs on kernels 1 and 2 only");
+        if (variant == 0) variant = lanes_ok ? 2 : 1;
+    }
+    if (variant == 0) {
+        // single-microsecond launches: the stream kernel where one round of blocks covers the batch with chunks of
+        // at most 64 cells (measured: 27.5 vs 30.3 us at 65 536 x 128, 20.5 vs 24.9 us at 4 096 x 400), else the
+        // split global-memory kernel (32.7 vs 48.9 us at 32 768 x 400, where the stream kernel needs two rounds)
+        if (single) variant = (stream_ok && stream_auto) ? 6 : 5;
+        else if (packed_ok && (ctx->auto_prefers_packed || !fused_ok)) variant = 4;
+        else if (fused_ok) variant = 3;
+        else variant = lanes_ok ? 2 : 1;
+    }
+    if (variant == 3 && !fused_ok)
+        return fail(ctx, WEDM_ERR_UNSUPPORTED, "wedm_step: fused kernel needs uniform geometry and a chunk that fits in LDS");
+    if (variant == 4 && !packed_ok)
+        return fail(ctx, WEDM_ERR_UNSUPPORTED, "wedm_step: packed kernel needs uniform geometry, lanes in {1,2,4,8} and two chunks that fit in LDS");
+    if (variant == 2 && !lanes_ok)
+        return fail(ctx, WEDM_ERR_UNSUPPORTED, "wedm_step: no lane count puts a chunk of the wire in LDS");
+    if (variant == 6 && !stream_ok)
+        return fail(ctx, WEDM_ERR_UNSUPPORTED, "wedm_step: stream kernel needs uniform geometry and lanes in {1,2,4,8,16} with a chunk of at most 104 cells");
+
+    const void* fn = nullptr;
+    int grid = 0;
+    size_t fl = 0;
+    out.walk = nullptr;
+    if (variant == 1) {
+        grid = (ctx->num_envs + 255) / 256;
+        fn = ctx->replay ? (tr ? (const void*)wedm_step_global<true, false, true> : (const void*)wedm_step_global<false, false, true>)
+           : f64 ? (tr ? (const void*)wedm_step_global<true, true, false> : (const void*)wedm_step_global<false, true, false>)
+                 : (tr ? (const void*)wedm_step_global<true, false, false> : (const void*)wedm_step_global<false, false, false>);
+        std::snprintf(out.name, sizeof(out.name), "wedm_step_global%s<<<%d,256>>>", ctx->replay ? "[injected variates]" : f64 ? "[f64 stencil]" : "", grid);
+    } else if (variant == 5) {
+        grid = (ctx->num_envs + 63) / 64;
+        fn = tr ? (const void*)wedm_step_split<true> : (const void*)wedm_step_split<false>;
+        std::snprintf(out.name, sizeof(out.name), "wedm_step_split<<<%d,256>>>", grid);
+    } else if (variant == 6) {
+        const int sli = lanes_index(slanes);
+        grid = (ctx->num_envs + 256 / slanes - 1) / (256 / slanes);
+        fl = ((size_t)ctx->walk_C[sli] + 1) * 1024;
+        out.walk = ctx->walk_dev + sli;
+        fn = ctx->walk_C[sli] <= 64 ? (tr ? pick_stream<true, 64>(slanes) : pick_stream<false, 64>(slanes))
+                                    : (tr ? pick_stream<true, 104>(slanes) : pick_stream<false, 104>(slanes));
+        std::snprintf(out.name, sizeof(out.name), "wedm_step_stream<%d><<<%d,256,%zuB>>>", slanes, grid, fl);
+    } else if (variant == 2) {
+        grid = (ctx->num_envs + 256 / glanes - 1) / (256 / glanes);
+        fl = (size_t)((ctx->n_seg_max + glanes - 1) / glanes) * 1024;
+        fn = f64 ? (tr ? pick_lanes<true, true>(glanes) : pick_lanes<false, true>(glanes))
+                 : (tr ? pick_lanes<true, false>(glanes) : pick_lanes<false, false>(glanes));
+        std::snprintf(out.name, sizeof(out.name), "wedm_step_lanes<%d>%s<<<%d,256,%zuB>>>", glanes, f64 ? "[f64 stencil]" : "", grid, fl);
+    } else if (variant == 4) {
+        grid = (ctx->num_envs + 256 / planes - 1) / (256 / planes);
+        fl = (2 * (size_t)ctx->walk_C[pli] + 2) * 1024;
+        out.walk = ctx->walk_dev + pli;
+        fn = tr ? pick_packed<true>(planes) : pick_packed<false>(planes);
+        std::snprintf(out.name, sizeof(out.name), "wedm_step_packed<%d><<<%d,256,%zuB>>>", planes, grid, fl);
+    } else {
+        grid = (ctx->num_envs + 256 / lanes - 1) / (256 / lanes);
+        fl = ((size_t)ctx->walk_C[li] + 1) * 1024;
+        out.walk = ctx->walk_dev + li;
+        fn = tr ? pick_fused<true>(lanes) : pick_fused<false>(lanes);
+        std::snprintf(out.name, sizeof(out.name), "wedm_step_fused<%d><<<%d,256,%zuB>>>", lanes, grid, fl);
+    }
+    if (fl) {
+        hipError_t ea = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)fl);
+        if (ea != hipSuccess) return hip_fail(ctx, ea, "hipFuncSetAttribute(MaxDynamicSharedMemorySize)");
+    }
+    out.fn = fn;
+    out.grid = grid;
+    out.lds = fl;
+    out.valid = true;
+    return WEDM_OK;
+}
+
 static thread_local std::string g_create_error;
 
 extern "C" {
@@ -1784,7 +1963,11 @@ int32_t wedm_abi_version(void) { return WEDM_ABI_VERSION; }
 int64_t wedm_sizeof_params(void) { return (int64_t)sizeof(wedm_params); }
 
 const char* wedm_last_error(wedm_ctx* ctx) { return ctx ? ctx->err.c_str() : g_create_error.c_str(); }
-const char* wedm_last_kernel(wedm_ctx* ctx) { return ctx ? ctx->last_kernel.c_str() : ""; }
+const char* wedm_last_kernel(wedm_ctx* ctx) {
+    if (!ctx) return "";
+    if (ctx->last_plan) ctx->last_kernel = std::string(ctx->last_plan->name) + " n_sub=" + std::to_string(ctx->last_n_sub);
+    return ctx->last_kernel.c_str();
+}
 
 int32_t wedm_create(const wedm_params* params, int32_t num_envs, int32_t n_seg_max, wedm_ctx** out) {
     if (!params || !out || num_envs <= 0 || n_seg_max <= 0) {
@@ -1901,6 +2084,7 @@ int32_t wedm_bind_state(wedm_ctx* ctx, const wedm_state_ptrs* state) {
     if (ctx->p.obs_dim > 0 && !state->obs) return fail(ctx, WEDM_ERR_BAD_ARG, "wedm_bind_state: obs_dim > 0 but obs is null");
     ctx->s = *state;
     ctx->bound = true;
+    ctx->invalidate_plans();
     return WEDM_OK;
 }
 
@@ -1909,6 +2093,7 @@ int32_t wedm_bind_geometry(wedm_ctx* ctx, const wedm_geom_ptrs* geom) {
     if (!geom || !geom->f64 || !geom->i32) return fail(ctx, WEDM_ERR_BAD_ARG, "wedm_bind_geometry: null geometry block");
     ctx->g = *geom;
     ctx->geom_bound = true;
+    ctx->invalidate_plans();
     return WEDM_OK;
 }
 
@@ -1944,6 +2129,7 @@ int32_t wedm_bind_rng_replay(wedm_ctx* ctx, const double* table, int64_t n_steps
     if (table && n_steps < 1) return fail(ctx, WEDM_ERR_BAD_ARG, "wedm_bind_rng_replay: n_steps must be >= 1");
     ctx->replay = table;
     ctx->replay_steps = table ? n_steps : 0;
+    ctx->invalidate_plans();
     return WEDM_OK;
 }
 
@@ -1951,6 +2137,7 @@ int32_t wedm_set_kernel(wedm_ctx* ctx, int32_t variant) {
     if (!ctx) return WEDM_ERR_BAD_ARG;
     if (variant < 0 || variant > 6) return fail(ctx, WEDM_ERR_BAD_ARG, "wedm_set_kernel: variant must be 0..6");
     ctx->variant = variant;
+    ctx->invalidate_plans();
     return WEDM_OK;
 }
 
@@ -1969,6 +2156,7 @@ int32_t wedm_set_lanes(wedm_ctx* ctx, int32_t lanes) {
     if (lanes != 0 && lanes_index(lanes) < 0)
         return fail(ctx, WEDM_ERR_BAD_ARG, "wedm_set_lanes: lanes must be 0 (auto), 1, 2, 4, 8 or 16");
     ctx->lanes = lanes;
+    ctx->invalidate_plans();
     return WEDM_OK;
 }
 
@@ -2038,165 +2226,17 @@ int32_t wedm_step(wedm_ctx* ctx, int32_t n_substeps, const wedm_action_ptrs* act
         k.trace_slot = (int32_t)(ctx->trace_count % ctx->trace.capacity);
     }
 
-    // kernel 3 (one chunk per lane) and kernel 4 (two packed chunks per lane, table of 2L chunks).
-    // Auto-selection by a small cost model fitted to measurements (DESIGN.md §4):
-    //   cycles per step ~ rounds * (4500 + tiles_per_lane * 8 * cell_cost),
-    //   rounds = ceil(blocks / (256 CUs * resident blocks per CU)), resident = min(2 [VGPRs], LDS fit),
-    //   cell_cost = 90 per cell, a packed pair = 2 * 90 * 0.93.
-    const bool uniform = !ctx->p.per_env_geometry && ctx->walk_dev;
-    int lanes = ctx->lanes, planes = ctx->lanes;
-    {
-        double best3 = 1e300, best4 = 1e300;
-        int l3 = 0, l4 = 0;
-        const int Ls[5] = {1, 2, 4, 8, 16};
-        for (int i = 0; i < 5 && uniform; ++i) {
-            const int Lc = Ls[i];
-            const long blocks = (ctx->num_envs + (256 / Lc) - 1) / (256 / Lc);
-            if (ctx->walk_ok[i]) {  // kernel 3 with Lc lanes: table i
-                const size_t lds = ((size_t)ctx->walk_C[i] + 1) * 1024;
-                if (lds <= (size_t)ctx->lds_limit) {
-                    const long rb = std::min<long>(2, (long)(160 * 1024 / lds));
-                    const long rounds = (blocks + 256 * rb - 1) / (256 * rb);
-                    const double cost = rounds * (4500.0 + ((ctx->walk_C[i] + 7) / 8) * 8 * 90.0);
-                    if (cost < best3) { best3 = cost; l3 = Lc; }
-                }
-            }
-            if (Lc <= 8 && ctx->walk_ok[lanes_index(2 * Lc)]) {  // kernel 4 with Lc lanes: table of 2*Lc chunks
-                const int ti = lanes_index(2 * Lc);
-                const size_t lds = (2 * (size_t)ctx->walk_C[ti] + 2) * 1024;
-                if (lds <= (size_t)ctx->lds_limit) {
-                    const long rb = std::min<long>(2, (long)(160 * 1024 / lds));
-                    const long rounds = (blocks + 256 * rb - 1) / (256 * rb);
-                    const double cost = rounds * (4500.0 + ((ctx->walk_C[ti] + 7) / 8) * 8 * 2 * 90.0 * 0.93);
-                    if (cost < best4) { best4 = cost; l4 = Lc; }
-                }
-            }
-        }
-        if (!lanes) lanes = l3;
-        if (!planes) planes = l4;
-        ctx->auto_prefers_packed = best4 <= best3;
-    }
-    const int li = lanes_index(lanes);
-    const bool fused_ok = uniform && li >= 0 && ctx->walk_ok[li] &&
-                          ((size_t)ctx->walk_C[li] + 1) * 1024 <= (size_t)ctx->lds_limit;
-    const int pli = (planes >= 1 && planes <= 8) ? lanes_index(2 * planes) : -1;
-    const bool packed_ok = uniform && pli >= 0 && ctx->walk_ok[pli] &&
-                           (2 * (size_t)ctx->walk_C[pli] + 2) * 1024 <= (size_t)ctx->lds_limit;
-    // kernel 2 (any geometry): lanes per environment = the caller's choice, else the smallest L whose
-    // chunk fits in LDS, raised until the launch has ~2 waves per SIMD
-    int glanes = 0;
-    {
-        const int Ls[5] = {1, 2, 4, 8, 16};
-        for (int i = 0; i < 5; ++i) {
-            const size_t b = (size_t)((ctx->n_seg_max + Ls[i] - 1) / Ls[i]) * 1024;
-            if (b > (size_t)ctx->lds_limit) continue;
-            if (ctx->lanes) { if (Ls[i] == ctx->lanes) glanes = Ls[i]; continue; }
-            glanes = Ls[i];
-            const long waves = (long)((ctx->num_envs + (256 / Ls[i]) - 1) / (256 / Ls[i])) * 4;
-            if (waves >= 2048) break;
-        }
-    }
-    const bool lanes_ok = glanes > 0;
-    // kernel 6 (stream, single microseconds, uniform geometry): the caller's lane count, else the smallest L whose
-    // chunk has at most 64 cells (the registers a lane holds its chunk in; failing that at most 104)
-    int slanes = 0;
-    if (uniform && (uint64_t)ctx->n_seg_max * (uint64_t)ctx->s.stride * 4ull < (1ull << 32)) {
-        const int Ls[5] = {1, 2, 4, 8, 16};
-        for (int pass = 0; pass < 2 && !slanes; ++pass)
-            for (int i = 0; i < 5 && !slanes; ++i) {
-                if (!ctx->walk_ok[i] || ctx->walk_C[i] > (pass ? 104 : 64) ||
-                    ((size_t)ctx->walk_C[i] + 1) * 1024 > (size_t)ctx->lds_limit) continue;
-                if (ctx->lanes && Ls[i] != ctx->lanes) continue;
-                slanes = Ls[i];
-            }
-    }
-    const bool stream_ok = slanes > 0;
-    const bool stream_auto = stream_ok && ctx->walk_C[lanes_index(slanes)] <= 64 &&
-                             (long)((ctx->num_envs + (256 / slanes) - 1) / (256 / slanes)) * 4 <= 2048;
-    int variant = ctx->variant;
-    if (ctx->replay) {
-        if (variant != 0 && variant != 1)
-            return fail(ctx, WEDM_ERR_UNSUPPORTED, "wedm_step: injected variates (wedm_bind_rng_replay) run on kernel 1 only");
-        if (P.stencil_mode != 0)
-            return fail(ctx, WEDM_ERR_UNSUPPORTED, "wedm_step: injected variates and stencil_mode 1 cannot be combined");
-        variant = 1;
-    }
-    const bool f64 = P.stencil_mode != 0;
-    if (f64) {
-        // Numba's typing of the stencil exists in the predicated kernels only (any geometry): LDS-staged when
-        // a chunk fits, else in place in global memory
-        if (variant != 0 && variant != 1 && variant != 2)
-            return fail(ctx, WEDM_ERR_UNSUPPORTED, "wedm_step: stencil_mode 1 (float64 stencil expressions) runs on kernels 1 and 2 only");
-        if (variant == 0) variant = lanes_ok ? 2 : 1;
-    }
-    if (variant == 0) {
-        // single-microsecond launches: the stream kernel where one round of blocks covers the batch with chunks of
-        // at most 64 cells (measured: 27.5 vs 30.3 us at 65 536 x 128, 20.5 vs 24.9 us at 4 096 x 400), else the
-        // split global-memory kernel (32.7 vs 48.9 us at 32 768 x 400, where the stream kernel needs two rounds)
-        if (n_substeps <= 1) variant = (stream_ok && stream_auto) ? 6 : 5;
-        else if (packed_ok && (ctx->auto_prefers_packed || !fused_ok)) variant = 4;
-        else if (fused_ok) variant = 3;
-        else variant = lanes_ok ? 2 : 1;
-    }
-    if (variant == 3 && !fused_ok)
-        return fail(ctx, WEDM_ERR_UNSUPPORTED, "wedm_step: fused kernel needs uniform geometry and a chunk that fits in LDS");
-    if (variant == 4 && !packed_ok)
-        return fail(ctx, WEDM_ERR_UNSUPPORTED, "wedm_step: packed kernel needs uniform geometry, lanes in {1,2,4,8} and two chunks that fit in LDS");
-    if (variant == 2 && !lanes_ok)
-        return fail(ctx, WEDM_ERR_UNSUPPORTED, "wedm_step: no lane count puts a chunk of the wire in LDS");
-    if (variant == 6 && !stream_ok)
-        return fail(ctx, WEDM_ERR_UNSUPPORTED, "wedm_step: stream kernel needs uniform geometry and lanes in {1,2,4,8,16} with a chunk of at most 104 cells");
-
-    char name[160];
     const bool tr = ctx->trace_on && k.trace_next < n_substeps;  // a sample falls into this launch
-    const void* fn = nullptr;
-    int grid = 0;
-    size_t fl = 0;
-    if (variant == 1) {
-        grid = (ctx->num_envs + 255) / 256;
-        fn = ctx->replay ? (tr ? (const void*)wedm_step_global<true, false, true> : (const void*)wedm_step_global<false, false, true>)
-           : f64 ? (tr ? (const void*)wedm_step_global<true, true, false> : (const void*)wedm_step_global<false, true, false>)
-                 : (tr ? (const void*)wedm_step_global<true, false, false> : (const void*)wedm_step_global<false, false, false>);
-        std::snprintf(name, sizeof(name), "wedm_step_global%s<<<%d,256>>> n_sub=%d", ctx->replay ? "[injected variates]" : f64 ? "[f64 stencil]" : "", grid, n_substeps);
-    } else if (variant == 5) {
-        grid = (ctx->num_envs + 63) / 64;
-        fn = tr ? (const void*)wedm_step_split<true> : (const void*)wedm_step_split<false>;
-        std::snprintf(name, sizeof(name), "wedm_step_split<<<%d,256>>> n_sub=%d", grid, n_substeps);
-    } else if (variant == 6) {
-        const int sli = lanes_index(slanes);
-        grid = (ctx->num_envs + 256 / slanes - 1) / (256 / slanes);
-        fl = ((size_t)ctx->walk_C[sli] + 1) * 1024;
-        k.walk = ctx->walk_dev + sli;
-        fn = ctx->walk_C[sli] <= 64 ? (tr ? pick_stream<true, 64>(slanes) : pick_stream<false, 64>(slanes))
-                                    : (tr ? pick_stream<true, 104>(slanes) : pick_stream<false, 104>(slanes));
-        std::snprintf(name, sizeof(name), "wedm_step_stream<%d><<<%d,256,%zuB>>> n_sub=%d", slanes, grid, fl, n_substeps);
-    } else if (variant == 2) {
-        grid = (ctx->num_envs + 256 / glanes - 1) / (256 / glanes);
-        fl = (size_t)((ctx->n_seg_max + glanes - 1) / glanes) * 1024;
-        fn = f64 ? (tr ? pick_lanes<true, true>(glanes) : pick_lanes<false, true>(glanes))
-                 : (tr ? pick_lanes<true, false>(glanes) : pick_lanes<false, false>(glanes));
-        std::snprintf(name, sizeof(name), "wedm_step_lanes<%d>%s<<<%d,256,%zuB>>> n_sub=%d", glanes, f64 ? "[f64 stencil]" : "", grid, fl, n_substeps);
-    } else if (variant == 4) {
-        grid = (ctx->num_envs + 256 / planes - 1) / (256 / planes);
-        fl = (2 * (size_t)ctx->walk_C[pli] + 2) * 1024;
-        k.walk = ctx->walk_dev + pli;
-        fn = tr ? pick_packed<true>(planes) : pick_packed<false>(planes);
-        std::snprintf(name, sizeof(name), "wedm_step_packed<%d><<<%d,256,%zuB>>> n_sub=%d", planes, grid, fl, n_substeps);
-    } else {
-        grid = (ctx->num_envs + 256 / lanes - 1) / (256 / lanes);
-        fl = ((size_t)ctx->walk_C[li] + 1) * 1024;
-        k.walk = ctx->walk_dev + li;
-        fn = tr ? pick_fused<true>(lanes) : pick_fused<false>(lanes);
-        std::snprintf(name, sizeof(name), "wedm_step_fused<%d><<<%d,256,%zuB>>> n_sub=%d", lanes, grid, fl, n_substeps);
+    LaunchPlan& plan = ctx->plans[n_substeps <= 1 ? 1 : 0][tr ? 1 : 0];
+    if (!plan.valid) {
+        if (int32_t rc = plan_launch(ctx, n_substeps <= 1, tr, plan)) return rc;
     }
-    if (fl) {
-        hipError_t ea = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)fl);
-        if (ea != hipSuccess) return hip_fail(ctx, ea, "hipFuncSetAttribute(MaxDynamicSharedMemorySize)");
-    }
+    k.walk = plan.walk;
     void* kargs[] = {(void*)&k};
-    hipError_t el = hipLaunchKernel(fn, dim3(grid), dim3(256), kargs, fl, (hipStream_t)stream);
+    hipError_t el = hipLaunchKernel(plan.fn, dim3(plan.grid), dim3(256), kargs, plan.lds, (hipStream_t)stream);
     if (el != hipSuccess) return hip_fail(ctx, el, "wedm_step launch");
-    ctx->last_kernel = name;
+    ctx->last_plan = &plan;
+    ctx->last_n_sub = n_substeps;
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return hip_fail(ctx, e, "wedm_step launch");
     if (ctx->trace_on) {
