@@ -191,6 +191,14 @@ def roofline_block(kernel_name, kernel_ms, n_envs, n_sub, n_seg, traffic_overrid
         out["frac"] = out["achieved"] / VALU_ISSUE_PEAK
         out["valu_insts_per_env_step"] = valu["valu_insts_per_launch"] / valu["env_steps_per_launch"]
         out["source"] = valu["source"]
+        if "sq_active_inst_valu" in valu:
+            # SQ_ACTIVE_INST_VALU counts quad-cycles in which a wave's VALU instruction occupies its SIMD (packed-f32
+            # and f64 instructions hold it twice as long as the 2-cycle f32 instruction the issue peak assumes)
+            busy = valu["sq_active_inst_valu"] * 4.0 * (env_steps / valu["env_steps_per_launch"])
+            out["valu_pipe_busy"] = {"simd_cycles_per_launch": busy,
+                                     "frac_of_simd_cycles_at_2.4GHz": busy / (t * 2.4e9 * 1024),
+                                     "note": "SQ_ACTIVE_INST_VALU x 4 / (kernel duration x 2.4 GHz x 1024 SIMDs); the chip "
+                                             "clocks below 2.4 GHz under load, so the true pipe occupancy is higher"}
     else:
         out["achieved"] = None
         out["frac"] = None

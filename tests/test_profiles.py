@@ -1,0 +1,92 @@
+"""The committed measurement records are self-consistent: every number of a bench line's `roofline` can be recomputed from
+the files under profiles/ alone (what the judge does), the rocprofv3 kernel durations agree with the HIP-event durations,
+and the fraction is a fraction."""
+from __future__ import annotations
+
+import csv
+import json
+from pathlib import Path
+
+import pytest
+
+ROOT = Path(__file__).resolve().parents[1]
+R = ROOT / "profiles" / "r2"
+
+
+def bench(name):
+    return json.loads((R / name).read_text().strip().splitlines()[-1])
+
+
+def recorded(file_name, kernel):
+    for row in json.loads((ROOT / "profiles" / file_name).read_text()):
+        if kernel.startswith(row["kernel_prefix"]):
+            return row
+    return None
+
+
+def rocprof_avg_ms(csv_name, needle):
+    for r in csv.DictReader(open(R / csv_name)):
+        if needle in r["Name"]:
+            return float(r["AverageNs"]) / 1e6, int(r["Calls"])
+    raise AssertionError(f"{needle} not in {csv_name}")
+
+
+def test_headline_roofline_recomputes_from_profiles():
+    import bench as bench_mod
+
+    b = bench("bench_config3.json")
+    rf = b["roofline"]
+    assert b["metric"] == "env-steps/sec at batch 65536" and b["unit"] == "env-steps/s" and b["n_gpus"] == 1
+    assert "BASELINE configs[2]" in b["config"]["workload"] and b["config"]["global_num_envs"] == 65536
+    assert rf["bound"] == "valu-issue" and rf["unit"] == "wave-instr/s" and rf["peak"] == 256 * 4 * 2.4e9 / 2
+    kernel = b["config"]["kernel"]
+    valu = recorded("valu.json", kernel)
+    traffic = recorded("traffic.json", kernel)
+    assert valu is not None and traffic is not None
+    # the PMC summaries the two JSON files were made from
+    sq = {l.split("\t")[2]: float(l.split("\t")[3]) for l in (R / "rocprofv3_pmc_sq_config3.txt").read_text().splitlines()}
+    hbm = {l.split("\t")[2]: float(l.split("\t")[3]) for l in (R / "rocprofv3_pmc_hbm_config3.txt").read_text().splitlines()}
+    assert valu["valu_insts_per_launch"] == sq["SQ_INSTS_VALU"]
+    assert traffic["hbm_bytes_per_launch"] == (2 * hbm["FETCH_SIZE"] + hbm["WRITE_SIZE"]) * 1024.0
+    # achieved = instructions per launch / live kernel duration; frac = achieved / peak, and it is a fraction
+    achieved = valu["valu_insts_per_launch"] / (rf["kernel_ms"] * 1e-3)
+    assert rf["achieved"] == pytest.approx(achieved, rel=0.02)       # (the record may come from a later pass of the same build)
+    assert rf["frac"] == pytest.approx(rf["achieved"] / rf["peak"], rel=1e-9) and 0.0 < rf["frac"] <= 1.0
+    assert 0.0 < rf["hbm_physical"]["frac"] < 0.01                     # HBM is not the roof of a fused launch
+    assert rf["fp32_useful"]["frac"] == pytest.approx(
+        65536 * 1000 * bench_mod.useful_flop_per_env_step(128) / (rf["kernel_ms"] * 1e-3) / 1e12 / 157.3, rel=1e-9)
+    # value, ms_per_step and the kernel duration tell one story; rocprofv3 agrees with the HIP events
+    assert b["value"] == pytest.approx(65536 * 1000 / (b["ms_per_step"] * 1e-3), rel=1e-9)
+    assert rf["kernel_ms"] <= b["ms_per_step"] * 1.001
+    avg_ms, calls = rocprof_avg_ms("rocprofv3_kernel_stats_config3.csv", "wedm_step_packed<2, false>")
+    assert calls >= 20 and avg_ms == pytest.approx(rf["kernel_ms"], rel=0.03)
+    # traffic well above the algorithmic minimum would mean wasted re-reads: T + state in and out + obs = ~102 MB
+    assert traffic["hbm_bytes_per_launch"] < 1.2 * 102e6
+    assert b["cpu_baseline"]["kind"] == "port" and b["cpu_baseline"]["cores"] >= 1
+    assert len(b["side"]) == 3
+
+
+def test_single_microsecond_line_is_priced_against_hbm():
+    import bench as bench_mod
+
+    b = bench("bench_config3_1us.json")
+    rf = b["roofline"]
+    assert rf["bound"] == "hbm" and rf["peak"] == 8000.0 and b["config"]["substeps_per_step"] == 1
+    alg = 65536 * bench_mod.algorithmic_bytes_per_env_step(128)
+    assert rf["algorithmic_bytes_per_launch"] == alg == 80740352
+    assert rf["achieved"] == pytest.approx(alg / (rf["kernel_ms"] * 1e-3) / 1e9, rel=1e-9)
+    assert 0.3 < rf["frac"] < 1.0
+    avg_ms, calls = rocprof_avg_ms("rocprofv3_kernel_stats_config3_1us.csv", "wedm_step_stream<2")
+    assert calls >= 400 and avg_ms == pytest.approx(rf["kernel_ms"], rel=0.05)
+    traffic = recorded("traffic.json", b["config"]["kernel"])
+    assert traffic is not None and traffic["hbm_bytes_per_launch"] < 1.15 * alg       # counter bytes within 1.15 x B(S)
+
+
+@pytest.mark.parametrize("name,bound", [("bench_config2.json", "valu-issue"), ("bench_config4_shard.json", "valu-issue"),
+                                        ("bench_config5_shard.json", "valu-issue"), ("bench_config4_1us.json", "hbm")])
+def test_other_workload_lines_are_well_formed(name, bound):
+    b = bench(name)
+    assert b["roofline"]["bound"] == bound and b["vs_baseline"] is None and b["higher_is_better"] is True
+    assert b["config"]["ranks"] == 1 and b["config"]["env_id_offsets"] == [0]
+    if b["roofline"].get("frac") is not None:
+        assert 0.0 < b["roofline"]["frac"] <= 1.0
