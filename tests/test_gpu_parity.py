@@ -768,6 +768,8 @@ def test_randomized_configurations_all_kernels_bit_exact(case):
     if per_env:
         kw["workpiece_height"] = rng.uniform(8, 32, n)
         kw["wire_diameter"] = rng.choice([0.1, 0.15, 0.25], n)
+    if case >= 10 and case % 2:   # the cases with terminations: reset inside the launch + kernel-side reward + crater log
+        kw.update(autoreset=True, reward="progress", crater_log_capacity=8)
     gpu, cpu = make_pair(n, **kw)
     seed = int(rng.integers(1, 1 << 40))
     gaps, debris = rng.uniform(6, 30, n), rng.uniform(0, 0.01, n)
@@ -803,6 +805,10 @@ def test_randomized_configurations_all_kernels_bit_exact(case):
         diffs = block_diffs(gpu.state.clone_blocks(), cpu.state.clone_blocks(), n)
         assert not diffs, f"case {case}: kernel {gpu._backend.last_kernel()} after {k} us (n={n}, S={gpu.n_segments}):\n" + \
             "\n".join(diffs[:12])
+        if gpu.state.crater_log is not None:
+            G, Cc = gpu.state.crater_log[:, :n].cpu(), cpu.state.crater_log[:, :n]
+            filled = torch.arange(G.shape[0])[:, None] < gpu.state.spark_count.cpu()[None, :]   # slots written since the reset
+            assert torch.equal(torch.where(filled, G, 0), torch.where(filled, Cc, 0)), f"case {case}: crater log differs"
         ran += 1
     assert ran >= 2
 
