@@ -855,16 +855,26 @@ __device__ __forceinline__ Coef scalar_prelude(const Hot& p, const ColdRef cold,
 // fast path is taken only if EVERY live lane of the wave qualifies and none ignites; nothing is
 // written before that is known, so otherwise the general path runs on untouched state.
 // Returns true when the step was handled (the stencil coefficients are then {0, 0, off, none}).
-__device__ __forceinline__ bool quiet_prelude(const Hot& p, const Geom& g, uint32_t gid, Env& s, QuietTry& qt) {
+// DENSE (the instantiation for densely sparking batches, chosen per launch from the spark density of the previous ones):
+// the same straight line also carries a spark that ignited in an EARLIER microsecond and keeps burning or ends now
+// (ignition.py:270-287 with no short: duration + 1, voltage = spark voltage or 0, current = peak or 0, state 1 -> -2
+// when the ON time is over) and hands its plasma / Joule coefficients to the stencil (wire.py:284-301) — for such a
+// lane scalar_prelude() computes exactly these assignments.  Only an igniting lane (fresh spark: crater, debris, cache
+// refresh), a short, or a control-step latch still sends the wave through the general path.  Bit-identical; it costs
+// registers, so batches that spark rarely run the instantiation without it.
+template <bool DENSE>
+__device__ __forceinline__ bool quiet_prelude_t(const Hot& p, const ColdRef cold, const Geom& g, int64_t e, uint32_t gid,
+                                                Env& s, QuietTry& qt, Coef& cf) {
     qt.have_w = false;
     if (p.disable_ignition || p.has_random_short) return false;
     const bool live = !s.done;
     const double d0 = s.wp - s.x;                       // unclamped gap (>= hard_short_gap > 0.001 below)
     const bool idle = s.state == 0, rest = s.state == -2;
+    const bool spk = DENSE && s.state == 1;             // ignited in an earlier microsecond
     double crit = p.base_critical_density + p.gap_coefficient * d0;
     crit = crit < p.max_critical_density ? crit : p.max_critical_density;
     const double ex = -p.sigmoid_steepness * (s.rho - crit);
-    bool q = (s.tss < p.servo_interval) && (s.rnd_rem == 0) && (s.deb_rem == 0) && (idle || rest) &&
+    bool q = (s.tss < p.servo_interval) && (s.rnd_rem == 0) && (s.deb_rem == 0) && (idle || rest || spk) &&
              (d0 >= p.hard_short_gap) && (ex > 24.0);
     // dielectric (dielectric.py:87-139): this step's density and the cache test
     const double cavity = g.cavity_coeff * (d0 * 0.001);
@@ -888,19 +898,24 @@ __device__ __forceinline__ bool quiet_prelude(const Hot& p, const Geom& g, uint3
 #endif
     }
     if (__any(ign)) return false;
+    bool burning = false;
     if (live) {
         const double Vt = s.tvolt != 0.0 ? s.tvolt : p.default_target_voltage;
         const double on = s.on != 0.0 ? s.on : p.default_on_time;
         const double off = s.off != 0.0 ? s.off : p.default_off_time;
         const int32_t dur1 = s.dur + 1;
         const bool end_rest = rest && ((double)dur1 >= on + off);
+        const bool end_on = spk && ((double)dur1 >= on);
+        burning = spk && !end_on;
         s.ctrl = 0;
         s.is_short = 0;
-        s.V = idle ? Vt : (end_rest ? Vt : 0.0);
-        s.I = 0.0;
+        double V = idle ? Vt : (end_rest ? Vt : 0.0);
+        if (DENSE) V = spk ? (end_on ? 0.0 : Vt * p.spark_voltage_factor) : V;
+        s.V = V;
+        s.I = burning ? s.ipk : 0.0;
         s.y = end_rest ? __builtin_nan("") : s.y;
         s.dur = idle ? s.dur : (end_rest ? 0 : dur1);
-        s.state = end_rest ? 0 : s.state;
+        s.state = end_rest ? 0 : (end_on ? -2 : s.state);
         s.last_crater = 0.0;
         s.cavity = cavity;
         s.rho = rho;
@@ -909,7 +924,34 @@ __device__ __forceinline__ bool quiet_prelude(const Hot& p, const Geom& g, uint3
             s.debris = nv > 0.0 ? nv : 0.0;
         }
     }
+    if (DENSE && __any(burning)) {  // wire.py:284-301, 96-100 for the lanes that keep burning
+        if (burning && s.y == s.y) {
+            const wedm_params* c = opaque(cold->p);
+            const int zone_start = WEDM_COLD_GEOM_I32(cold, p, WEDM_GI_ZONE_START, zone_start);
+            const double seg = c->segment_len;
+            const int idx = seg != 0 ? zone_start + (int)py_floordiv(s.y, seg) : zone_start;
+            if (idx >= 0 && idx < g.n_seg) {
+                cf.pidx = idx;
+                cf.q64 = c->plasma_efficiency * s.V * s.I;
+                cf.q = (float)cf.q64;
+            }
+        }
+        if (burning) {
+            const double I2 = s.I * s.I;
+            cf.joule_on = I2 > 1e-6;
+            if (cf.joule_on) {
+                const double joule_geom = WEDM_COLD_GEOM_F64(cold, p, WEDM_G_JOULE_GEOM, joule_geom);
+                cf.jf64 = joule_geom * I2 * opaque(cold->p)->rho_elec;
+                cf.jf = (float)cf.jf64;
+            }
+        }
+    }
     return true;
+}
+
+__device__ __forceinline__ bool quiet_prelude(const Hot& p, const Geom& g, uint32_t gid, Env& s, QuietTry& qt) {
+    Coef unused{0.0f, 0.0f, 0, -1};
+    return quiet_prelude_t<false>(p, ColdRef{nullptr}, g, 0, gid, s, qt, unused);
 }
 
 __device__ __forceinline__ bool quiet_prelude(const Hot& p, const Geom& g, uint32_t gid, Env& s) {

@@ -41,6 +41,16 @@
 
 using namespace wedm;
 
+// Which kernels let their wave-uniform fast path also carry burning / ending sparks (quiet_prelude_t<true>), A/B-timed
+// on the MI355X (tools/r2_run13.sh, r2_run14.sh): the packed kernel gains everywhere (bench workload +1.3 %, 15 um gap
+// +4.1 %, closed loop +3.6 %), the unpacked fused and the predicated kernels lose 1-4 % on every workload (registers).
+#ifndef WEDM_PACKED_DENSE
+#define WEDM_PACKED_DENSE true
+#endif
+#ifndef WEDM_FUSED_DENSE
+#define WEDM_FUSED_DENSE false
+#endif
+
 // Wave-uniform description of one step's walk over a chunk of C cells (see build_walk()).
 // Cell j of chunk c is wire segment i = c*C + j.  The chunk is walked in ceil(C/8) tiles of 8
 // cells.  A NORMAL tile holds 8 interior cells (1 <= i <= n-2) with the same zone / contact
@@ -458,7 +468,7 @@ __global__ void __launch_bounds__(256, 2) wedm_step_lanes(const KArgs k) {
         if (__all(s.done) && !tracing) break;
         Coef cf{0.0f, 0.0f, 0, -1};
         QuietTry qt;
-        if (!quiet_prelude(hv, g, gid, s, qt) && !s.done) cf = scalar_prelude(hv, cold, g, e, gid, s, ps, c == 0, qt);
+        if (!quiet_prelude_t<WEDM_FUSED_DENSE>(hv, cold, g, e, gid, s, qt, cf) && !s.done) cf = scalar_prelude(hv, cold, g, e, gid, s, ps, c == 0, qt);
         const float halo_l = (c > 0) ? col[(C - 1) * 256 - 1] : spool;
         const float halo_r = (c < L - 1) ? col[1] : 0.0f;
         float tmax = spool, tm1 = halo_l, tc = col[0];
@@ -728,7 +738,7 @@ __global__ void __launch_bounds__(256, 2) wedm_step_fused(const KArgs k) {
         WEDM_STAMP(st0);
         Coef cf{0.0f, 0.0f, 0, -1};
         QuietTry qt;
-        if (!quiet_prelude(hv, g, gid, s, qt) && !s.done) cf = scalar_prelude(hv, cold, g, e, gid, s, ps, c == 0, qt);
+        if (!quiet_prelude_t<WEDM_FUSED_DENSE>(hv, cold, g, e, gid, s, qt, cf) && !s.done) cf = scalar_prelude(hv, cold, g, e, gid, s, ps, c == 0, qt);
         WEDM_STAMP(st1);
 
         // ---- halos: OLD neighbour values, read before any lane of this wave stores.  The right
@@ -1361,15 +1371,12 @@ __global__ void __launch_bounds__(256, 2) wedm_step_packed(const KArgs k) {
         if (__all(s.done) && !tracing) break;
         WEDM_STAMP(st0);
         Coef cf{0.0f, 0.0f, 0, -1};
-#ifdef WEDM_STAMPS
-        const bool was_quiet = quiet_prelude(hv, g, gid, s);
-        if (!was_quiet && !s.done) cf = scalar_prelude(hv, cold, g, e, gid, s, ps, c == 0);
-        WEDM_STAMP(st1);
-        if (was_quiet) { accN += st1 - st0; ++cntN; } else { accB += st1 - st0; ++cntB; }  // quiet / general prelude
-#else
         QuietTry qt;
-        if (!quiet_prelude(hv, g, gid, s, qt) && !s.done) cf = scalar_prelude(hv, cold, g, e, gid, s, ps, c == 0, qt);
+        const bool was_quiet = quiet_prelude_t<WEDM_PACKED_DENSE>(hv, cold, g, e, gid, s, qt, cf);
+        if (!was_quiet && !s.done) cf = scalar_prelude(hv, cold, g, e, gid, s, ps, c == 0, qt);
         WEDM_STAMP(st1);
+#ifdef WEDM_STAMPS
+        if (was_quiet) { accN += st1 - st0; ++cntN; } else { accB += st1 - st0; ++cntB; }  // quiet / general prelude
 #endif
 
         // ---- halos (OLD values, read before any store of this step)

@@ -1128,3 +1128,23 @@ def test_native_seed_reference_run_followed_on_the_gpu(golden_dir):
     env.bind_rng_replay(None)
     env.step_many(env.make_action(), 10)
     assert "wedm_step_packed" in env._backend.last_kernel() or "wedm_step_fused" in env._backend.last_kernel()
+
+
+def test_densely_sparking_batch_on_the_packed_kernel_matches_oracle():
+    """The packed kernel's wave-uniform fast path also carries burning / ending sparks (quiet_prelude_t<true>): a densely
+    sparking 128-segment batch with mixed current modes and ON times against the oracle, every byte."""
+    n = 2048
+    kw = dict(wire_params=WireModuleParameters(segment_len=0.625))
+    gpu, cpu = make_pair(n, **kw)
+    both((gpu, cpu), lambda e: (e.reset(seed=606), close_gap(e, 18.0, 10.0)))
+    rng = np.random.default_rng(1)
+    modes = rng.choice([5, 9, 13, 17], n).astype(np.int32)
+    on = rng.choice([1.0, 2.0, 3.5, 5.0], n)
+    gpu.set_kernel(4, 2)
+    for env in (gpu, cpu):
+        a = env.make_action(0.05, 80.0, modes, on, 15.0)
+        for k in (1000, 1000, 777):
+            env.step_many(a, k)
+    assert "wedm_step_packed<2>" in gpu._backend.last_kernel(), gpu._backend.last_kernel()
+    check(gpu, cpu, n)
+    assert int(gpu.state.spark_count.sum()) / n / 2.777 > 5.0          # densely sparking indeed
