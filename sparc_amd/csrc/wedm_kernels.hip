@@ -68,6 +68,14 @@ struct WalkTable {
                                       // bits 16-31: c*C + j < n (valid, j < C)
     uint32_t kind[WEDM_MAX_TILES];    // TILE_N / TILE_B / TILE_S
     uint32_t split[WEDM_MAX_TILES];   // TILE_B: first cell offset that uses the tile's second flag set (8: none)
+    // the same, gathered by the host the way the kernels keep it in registers (bit t = tile t): per chunk
+    // {zone of the tile's first cell, between the contacts (first cell), zone (last cell), contacts (last cell)},
+    // and wave-uniform tile kinds / split offsets (4 bits per tile).  One 16-byte load per lane instead of a
+    // loop of dependent table reads per launch (which cost the single-microsecond kernel ~2 us per launch).
+    uint32_t chunk_flags[16][4];
+    uint32_t kind_n_mask, kind_s_mask;
+    uint32_t split_pack[3];
+    uint32_t pad0;
 };
 // TILE_N: 8 interior cells, one flag set.  TILE_B: every cell takes the interior formula with at
 // most one flag change inside the tile; boundary cells (wire cell 0, the last cell, cells past
@@ -1024,22 +1032,12 @@ __global__ void __launch_bounds__(256, 2) wedm_step_stream(const KArgs k) {
     const float spool = k.hot.spool, tref = k.hot.tref, alpha = k.hot.alpha, tdiel = k.hot.tdiel;
     const int n_tiles = wt->n_tiles;
     // per-lane tile membership, gathered once (see wedm_step_fused)
-    uint32_t zone_lo = 0u, joule_lo = 0u, zone_hi = 0u, joule_hi = 0u, kind_n = 0u, kind_s = 0u;
-    uint32_t split_pack[3] = {0u, 0u, 0u};  // 4 bits per tile (WEDM_MAX_TILES <= 24)
-    for (int t = 0; t < n_tiles; ++t) {
-        const uint32_t lo = wt->zj[8 * t], hi = wt->zj[8 * t + 7], kd = wt->kind[t];
-        split_pack[t >> 3] |= (wt->split[t] & 15u) << ((t & 7) * 4);
-        zone_lo |= ((lo >> c) & 1u) << t;
-        joule_lo |= ((lo >> (16 + c)) & 1u) << t;
-        zone_hi |= ((hi >> c) & 1u) << t;
-        joule_hi |= ((hi >> (16 + c)) & 1u) << t;
-        kind_n |= (kd == TILE_N ? 1u : 0u) << t;
-        kind_s |= (kd == TILE_S ? 1u : 0u) << t;
-    }
-    kind_n = __builtin_amdgcn_readfirstlane(kind_n);
-    kind_s = __builtin_amdgcn_readfirstlane(kind_s);
+    const uint32_t zone_lo = wt->chunk_flags[c][0], joule_lo = wt->chunk_flags[c][1];
+    const uint32_t zone_hi = wt->chunk_flags[c][2], joule_hi = wt->chunk_flags[c][3];
+    const uint32_t kind_n = __builtin_amdgcn_readfirstlane(wt->kind_n_mask), kind_s = __builtin_amdgcn_readfirstlane(wt->kind_s_mask);
+    uint32_t split_pack[3];  // 4 bits per tile (WEDM_MAX_TILES <= 24)
 #pragma unroll
-    for (int q = 0; q < 3; ++q) split_pack[q] = __builtin_amdgcn_readfirstlane(split_pack[q]);
+    for (int q = 0; q < 3; ++q) split_pack[q] = __builtin_amdgcn_readfirstlane(wt->split_pack[q]);
     // the lane that owns the wire's last cell (Neumann boundary, wire.py:95)
     const bool owns_last = (n >= 2) && (n - 1 >= cbase) && (n - 1 < cbase + C);
 
@@ -1058,6 +1056,7 @@ __global__ void __launch_bounds__(256, 2) wedm_step_stream(const KArgs k) {
             quiet_only = false;
             if (!s.done) cf = scalar_prelude(hv, cold, g, e, gid, s, ps, c == 0, qt);
         }
+        WEDM_S2_STAMP(2);  // prelude done (first microsecond)
         // ---- halos: OLD neighbour values, read before any lane of this wave stores.  The right
         // halo goes into the chunk's extra LDS row C, so cell C-1 is walked like any other.
         const float halo_l = (c > 0) ? col[(C - 1) * 256 - 1] : spool;
@@ -1195,6 +1194,7 @@ __global__ void __launch_bounds__(256, 2) wedm_step_stream(const KArgs k) {
             float bufA[8];
             for (int t = 0; t < n_tiles; ++t) tile(t, bufA, bufA);
         }
+        WEDM_S2_STAMP(3);  // walk done
         // ---- patches (after every store of the walk): boundary condition, last cell, plasma cell
         patch0 = (owns_last && !s.done) ? n - 1 - cbase : -1;
         patch1 = owns_pl ? cf.pidx - cbase : -1;
@@ -1740,6 +1740,18 @@ static bool build_walk(const wedm_params& p, int L, WalkTable& t) {
         if (changes > 1) t.kind[tile] = TILE_S;
         else if (all_interior && changes == 0) t.kind[tile] = TILE_N;
         else t.kind[tile] = TILE_B;
+    }
+    for (int tile = 0; tile < t.n_tiles; ++tile) {
+        const uint32_t lo = t.zj[8 * tile], hi = t.zj[8 * tile + 7];
+        for (int c = 0; c < 16; ++c) {
+            t.chunk_flags[c][0] |= ((lo >> c) & 1u) << tile;
+            t.chunk_flags[c][1] |= ((lo >> (16 + c)) & 1u) << tile;
+            t.chunk_flags[c][2] |= ((hi >> c) & 1u) << tile;
+            t.chunk_flags[c][3] |= ((hi >> (16 + c)) & 1u) << tile;
+        }
+        t.kind_n_mask |= (t.kind[tile] == TILE_N ? 1u : 0u) << tile;
+        t.kind_s_mask |= (t.kind[tile] == TILE_S ? 1u : 0u) << tile;
+        t.split_pack[tile >> 3] |= (t.split[tile] & 15u) << ((tile & 7) * 4);
     }
     return true;
 }

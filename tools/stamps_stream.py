@@ -26,8 +26,8 @@ env.step(act)
 torch.cuda.synchronize()
 print(env._backend.last_kernel())
 raw = buf.cpu().numpy().reshape(nblk * 4, 8).astype(np.float64)
-names = ["everything requested", "wire in LDS (barrier passed)", "walk + epilogue done", "stores issued", "stores landed"]
-idx = [0, 1, 4, 5, 6]
+names = ["everything requested", "wire in LDS", "prelude done", "walk done", "patches + reduce + epilogue done", "stores issued", "stores landed"]
+idx = [0, 1, 2, 3, 4, 5, 6]
 prev = raw[:, 7]
 for i, nm in zip(idx, names):
     d = raw[:, i] - prev
