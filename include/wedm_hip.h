@@ -369,7 +369,9 @@ int64_t wedm_sizeof_params(void);
  * element-wise on device arrays, so tests can compare them bit for bit with the CPU.
  * kind: 0 exp, 1 log, 2 correctly-rounded cube, 3 sqrt, 4 Python floor-division
  * a // b, 5 a / b, 6 the four Philox step uniforms (u0 + 2 u1 + 4 u2 + 8 u3) at (time=a, env=b),
- * 7 Philox polar normal at (time=a, env=b).  Key 0x9abcdef012345678, episode 3.   */
+ * 7 Philox polar normal at (time=a, env=b), 8 the spark's cell offset int(a // b) as the kernels
+ * compute it (one division + a fused remainder where a >= 0 and b > 0).  Key 0x9abcdef012345678,
+ * episode 3.                                                                               */
 int32_t wedm_debug_math(int32_t kind, const double* a, const double* b, double* out, int32_t n, void* stream);
 
 #ifdef __cplusplus

@@ -108,6 +108,22 @@ __device__ __forceinline__ double py_floordiv(double vx, double wx) {
     return fd;
 }
 
+// int(y // seg) for the spark's cell (wire.py:290-294).  For y >= 0, seg > 0 CPython's float_divmod returns the exact
+// floor of the real quotient (fmod is exact, (y - mod) / seg is within half a unit of the integer it then rounds to),
+// and that integer is also what one division, a floor and ONE fused remainder give: r = fma(-n, seg, y) is the
+// correctly rounded y - n seg, so its sign and its comparison with seg are those of the exact remainder, which
+// corrects a floor(y / seg) that the division's rounding put one off.  ~20 instructions instead of ~105 (fmod is a
+// software loop); anything else (negative, NaN, huge) takes CPython's own sequence.
+__device__ __forceinline__ int spark_cell_offset(double y, double seg) {
+    const double q = y / seg;
+    const bool fast = y >= 0.0 && seg > 0.0 && q < 1.0e9;
+    double n = floor(q);
+    const double r = __builtin_fma(-n, seg, y);
+    n = r < 0.0 ? n - 1.0 : (r >= seg ? n + 1.0 : n);
+    if (!fast) n = py_floordiv(y, seg);
+    return (int)n;
+}
+
 // ------------------------------------------------------------------------- RNG
 // Philox4x32-10, counter {time, episode, global env id, stream}, key = reset seed.
 // Counter-based: a variate is a pure function of (seed, env, episode, time, slot),
@@ -827,7 +843,7 @@ __device__ __forceinline__ Coef scalar_prelude(const Hot& p, const ColdRef cold,
             const wedm_params* c = opaque(cold->p);
             const int zone_start = WEDM_COLD_GEOM_I32(cold, p, WEDM_GI_ZONE_START, zone_start);
             const double seg = c->segment_len;
-            int idx = seg != 0 ? zone_start + (int)py_floordiv(s.y, seg) : zone_start;
+            int idx = seg != 0 ? zone_start + spark_cell_offset(s.y, seg) : zone_start;
             if (idx >= 0 && idx < g.n_seg) {
                 cf.pidx = idx;
                 cf.q64 = c->plasma_efficiency * s.V * I;
@@ -929,7 +945,7 @@ __device__ __forceinline__ bool quiet_prelude_t(const Hot& p, const ColdRef cold
             const wedm_params* c = opaque(cold->p);
             const int zone_start = WEDM_COLD_GEOM_I32(cold, p, WEDM_GI_ZONE_START, zone_start);
             const double seg = c->segment_len;
-            const int idx = seg != 0 ? zone_start + (int)py_floordiv(s.y, seg) : zone_start;
+            const int idx = seg != 0 ? zone_start + spark_cell_offset(s.y, seg) : zone_start;
             if (idx >= 0 && idx < g.n_seg) {
                 cf.pidx = idx;
                 cf.q64 = c->plasma_efficiency * s.V * s.I;

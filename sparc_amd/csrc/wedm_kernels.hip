@@ -388,13 +388,20 @@ __global__ void __launch_bounds__(256) wedm_step_split(const KArgs k) {
 
 
 #ifdef WEDM_STAMPS
+// -DWEDM_STAMPS_REAL: the 100 MHz clock all XCDs share (10 ns per tick: start / end skew across the chip) instead of the
+// per-XCD shader clock (phase lengths inside a wave)
+#ifdef WEDM_STAMPS_REAL
+#define WEDM_S2_CLOCK "s_memrealtime"
+#else
+#define WEDM_S2_CLOCK "s_memtime"
+#endif
 #define WEDM_S2_STAMP_DECL unsigned long long sst[8] = {0, 0, 0, 0, 0, 0, 0, 0}; \
-    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(sst[7])::"memory")
+    asm volatile(WEDM_S2_CLOCK " %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(sst[7])::"memory")
 #define WEDM_S2_STAMP(i) do { __builtin_amdgcn_sched_barrier(0); \
-    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(sst[i])::"memory"); \
+    asm volatile(WEDM_S2_CLOCK " %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(sst[i])::"memory"); \
     __builtin_amdgcn_sched_barrier(0); } while (0)
 #define WEDM_S2_STAMP_VM(i) do { __builtin_amdgcn_sched_barrier(0); \
-    asm volatile("s_waitcnt vmcnt(0)\n\ts_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(sst[i])::"memory"); \
+    asm volatile("s_waitcnt vmcnt(0)\n\t" WEDM_S2_CLOCK " %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(sst[i])::"memory"); \
     __builtin_amdgcn_sched_barrier(0); } while (0)
 #define WEDM_S2_STAMP_OUT() do { if (k.dbg && (threadIdx.x & 63) == 0) { \
     unsigned long long* o = k.dbg + ((size_t)blockIdx.x * 4 + (threadIdx.x >> 6)) * 8; \
@@ -981,7 +988,21 @@ __global__ void __launch_bounds__(256, 2) wedm_step_stream(const KArgs k) {
     const int jn = (!live) ? 0 : ((C < n - cbase) ? C : n - cbase);  // cells of this chunk that exist (<= 0: none)
     WEDM_S2_STAMP_DECL;
 
-    // (1) the wire: the lane's whole chunk into registers, 32-bit byte offsets from the (wave-uniform) base of T
+    // (1) the state rows a microsecond reads: requested first, so that the first prelude runs while the wire is in flight
+    Env s;
+    Geom g;
+    Persist ps{0.0f, 0.0f, 0.0f, 0};
+    load_geom(k.hot, cold, live ? e : 0, g);
+    if (live) {
+        if (TRACE) load_env(cold, e, s);  // frozen environments are sampled too: every row
+        else load_env_inputs(cold, e, s, !k.hot.disable_ignition);
+    } else {
+        s.done = 1; s.unwind = 0.0; s.h_base = 0.0f; s.h_zone = 0.0f;
+    }
+    // per-lane tile membership, gathered by the host (build_walk): requested with the rest
+    const uint32_t zone_lo = wt->chunk_flags[c][0], joule_lo = wt->chunk_flags[c][1];
+    const uint32_t zone_hi = wt->chunk_flags[c][2], joule_hi = wt->chunk_flags[c][3];
+    // (2) the wire: the lane's whole chunk into registers, 32-bit byte offsets from the (wave-uniform) base of T
     // (the host checks that the block is below 4 GB): one v_add per row instead of a 64-bit multiply-add.
     // Rows past the chunk repeat its last row (a lane without cells reads row 0): every load is unconditional
     // and from a valid address, so the compiler can count them and waits for each row only where it is used.
@@ -998,17 +1019,6 @@ __global__ void __launch_bounds__(256, 2) wedm_step_stream(const KArgs k) {
             off += (j < jmax) ? rowb : 0u;
         }
     }
-    // (2) the state rows a microsecond reads
-    Env s;
-    Geom g;
-    Persist ps{0.0f, 0.0f, 0.0f, 0};
-    load_geom(k.hot, cold, live ? e : 0, g);
-    if (live) {
-        if (TRACE) load_env(cold, e, s);  // frozen environments are sampled too: every row
-        else load_env_inputs(cold, e, s, !k.hot.disable_ignition);
-    } else {
-        s.done = 1; s.unwind = 0.0; s.h_base = 0.0f; s.h_zone = 0.0f;
-    }
     WEDM_S2_STAMP(0);  // everything requested
     // next-step autoreset (all L lanes of the environment agree)
     const bool reinit = live && s.done && WEDM_AUTORESET(cold);
@@ -1020,20 +1030,11 @@ __global__ void __launch_bounds__(256, 2) wedm_step_stream(const KArgs k) {
         s.ipk = peak_current(cold, s.mode);
         init_persist(k.hot, cold, e, s, ps);
     }
-    // (3) the chunk into the lane's LDS column (each row is waited for where it is written: one round trip in all)
-#pragma unroll
-    for (int j = 0; j < CMAX; ++j)
-        if (j < C) col[j * 256] = reinit ? k.hot.spool : w[j];
-    if (c == 0) col[0] = k.hot.spool;  // wire cell 0 is held at the spool temperature (wire.py:83)
-    WEDM_S2_STAMP(1);  // wire in LDS
     pin_hot_in_vgprs(hv);
     const uint32_t gid = k.hot.env_id_offset + (uint32_t)e;
 
     const float spool = k.hot.spool, tref = k.hot.tref, alpha = k.hot.alpha, tdiel = k.hot.tdiel;
     const int n_tiles = wt->n_tiles;
-    // per-lane tile membership, gathered once (see wedm_step_fused)
-    const uint32_t zone_lo = wt->chunk_flags[c][0], joule_lo = wt->chunk_flags[c][1];
-    const uint32_t zone_hi = wt->chunk_flags[c][2], joule_hi = wt->chunk_flags[c][3];
     const uint32_t kind_n = __builtin_amdgcn_readfirstlane(wt->kind_n_mask), kind_s = __builtin_amdgcn_readfirstlane(wt->kind_s_mask);
     uint32_t split_pack[3];  // 4 bits per tile (WEDM_MAX_TILES <= 24)
 #pragma unroll
@@ -1044,19 +1045,22 @@ __global__ void __launch_bounds__(256, 2) wedm_step_stream(const KArgs k) {
     const bool tracing = WEDM_TRACING(k);
     int trace_next = k.trace_next, trace_slot = k.trace_slot;
     (void)trace_next; (void)trace_slot;
+    const bool no_ragged = L * C == n && k.num_envs % EPB == 0;  // every cell of every lane of the launch exists
+    const uint32_t offc = (uint32_t)(cbase * stride + (live ? e : 0)) * 4u;  // row cbase of this environment (stores)
     bool quiet_only = true;
     int patch0 = -1, patch1 = -1;  // cells patched after the last walk (chunk-local), -1: none
     uint32_t stored = 0u;  // tiles of the last microsecond that went to global memory from the walk itself (wave-uniform)
-    for (int it = 0; it < k.n_substeps; ++it) {
-        if (__all(s.done) && !tracing) break;
-        const bool last = it + 1 == k.n_substeps;
-        Coef cf{0.0f, 0.0f, 0, -1};
+    // one microsecond = prelude (state only) + the rest (wire walk, epilogue, trace point).  The launch's first
+    // prelude runs BEFORE the chunk is dropped into LDS: the wire's rows are still in flight then.
+    auto prelude = [&](Coef& cf) {
         QuietTry qt;
         if (!quiet_prelude(hv, g, gid, s, qt)) {
             quiet_only = false;
             if (!s.done) cf = scalar_prelude(hv, cold, g, e, gid, s, ps, c == 0, qt);
         }
-        WEDM_S2_STAMP(2);  // prelude done (first microsecond)
+    };
+    auto rest = [&](const int it, Coef& cf) {
+        const bool last = it + 1 == k.n_substeps;
         // ---- halos: OLD neighbour values, read before any lane of this wave stores.  The right
         // halo goes into the chunk's extra LDS row C, so cell C-1 is walked like any other.
         const float halo_l = (c > 0) ? col[(C - 1) * 256 - 1] : spool;
@@ -1146,6 +1150,7 @@ __global__ void __launch_bounds__(256, 2) wedm_step_stream(const KArgs k) {
                     const float jfe_hi = ((joule_hi >> t) & 1u) ? jf_lane : 0.0f;
                     const uint32_t im1 = (uint32_t)(cbase + j - 1);  // (i - 1) of the tile's first cell
                     const uint32_t span = (uint32_t)(n - 3);         // interior <=> (i - 1) <= n - 3 (unsigned)
+                    float tnv[8];
 #pragma unroll
                     for (int u = 0; u < 8; ++u) {
                         if (u < cnt) {
@@ -1153,11 +1158,29 @@ __global__ void __launch_bounds__(256, 2) wedm_step_stream(const KArgs k) {
                             const float jfe = u < split ? jfe_lo : jfe_hi;
                             float tn = interior_cell<true>(tm1, tc, cur[u], g.k, g.tuf, conv, tdiel, ps.adv, jfe, alpha, tref);
                             col[(j + u) * 256] = tn;
+                            tnv[u] = tn;
                             const bool inter = (n >= 3) && (im1 + (uint32_t)u <= span);
                             tmax = inter ? fmax_gt(tmax, tn) : tmax;
                             tm1 = tc;
                             tc = cur[u];
                         }
+                    }
+                    if (last) {
+                        // the launch's last microsecond: every cell of the tile that exists, except wire cell 0
+                        // (spool temperature, never rewritten), goes straight to global memory; the cells patched
+                        // after the walk are stored again behind these (same lane, same address: in order)
+                        char* const Tw = (char*)cold->s.T;
+                        uint32_t offt = offc + (uint32_t)j * rowb;
+                        if (no_ragged && cnt == 8) {  // every cell of every lane exists: 8 unconditional stores
+                            tnv[0] = (im1 == 0xffffffffu) ? spool : tnv[0];  // wire cell 0
+#pragma unroll
+                            for (int u = 0; u < 8; ++u) { *(float*)(Tw + offt) = tnv[u]; offt += rowb; }
+                        } else {
+#pragma unroll
+                            for (int u = 0; u < 8; ++u)
+                                if (u < cnt && im1 + (uint32_t)u < (uint32_t)(n - 1)) *(float*)(Tw + offt + (uint32_t)u * rowb) = tnv[u];
+                        }
+                        stored |= 1u << t;
                     }
                 } else {
 #pragma unroll 1
@@ -1215,6 +1238,25 @@ __global__ void __launch_bounds__(256, 2) wedm_step_stream(const KArgs k) {
         }
         WEDM_TRACE_POINT(k, it, e, s, c == 0,
                          for (int j = 0; j < C && cbase + j < n; ++j) tT[(int64_t)(cbase + j) * tcnt] = col[j * 256]);
+    };
+    const bool idle = __all(s.done) && !tracing;  // nothing to advance and nothing to sample
+    {
+        Coef cf{0.0f, 0.0f, 0, -1};
+        if (!idle) prelude(cf);
+        WEDM_S2_STAMP(2);  // prelude done (first microsecond)
+        // (3) the chunk into the lane's LDS column (each row is waited for where it is written: one round trip in all)
+#pragma unroll
+        for (int j = 0; j < CMAX; ++j)
+            if (j < C) col[j * 256] = reinit ? k.hot.spool : w[j];
+        if (c == 0) col[0] = k.hot.spool;  // wire cell 0 is held at the spool temperature (wire.py:83)
+        WEDM_S2_STAMP(1);  // wire in LDS
+        if (!idle) rest(0, cf);
+    }
+    for (int it = 1; it < k.n_substeps && !idle; ++it) {
+        if (__all(s.done) && !tracing) break;
+        Coef cf{0.0f, 0.0f, 0, -1};
+        prelude(cf);
+        rest(it, cf);
     }
 
     WEDM_S2_STAMP(4);  // walk + epilogue done
@@ -1223,7 +1265,6 @@ __global__ void __launch_bounds__(256, 2) wedm_step_stream(const KArgs k) {
     // flight, then 8 stores, fire and forget; the L lanes of an environment are in one wave: nothing to wait for
     if (!frozen0) {
         char* const Tw = (char*)cold->s.T;
-        const uint32_t offc = (uint32_t)(cbase * stride + (live ? e : 0)) * 4u;
         stored = __builtin_amdgcn_readfirstlane(stored);
 #pragma unroll
         for (int t = 0; t < (CMAX + 7) / 8; ++t) {
@@ -1646,6 +1687,7 @@ __global__ void wedm_debug_math_kernel(int32_t kind, const double* a, const doub
             break;
         }
         case 7: r = philox_std_normal(0x12345678u, 0x9abcdef0u, (uint32_t)x, 3u, (uint32_t)y); break;
+        case 8: r = (double)spark_cell_offset(x, y); break;
         default: break;
     }
     out[i] = r;
@@ -2267,7 +2309,7 @@ int32_t wedm_step(wedm_ctx* ctx, int32_t n_substeps, const wedm_action_ptrs* act
 }
 
 int32_t wedm_debug_math(int32_t kind, const double* a, const double* b, double* out, int32_t n, void* stream) {
-    if (!a || !out || n <= 0 || kind < 0 || kind > 7) return WEDM_ERR_BAD_ARG;
+    if (!a || !out || n <= 0 || kind < 0 || kind > 8) return WEDM_ERR_BAD_ARG;
     hipLaunchKernelGGL(wedm_debug_math_kernel, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)stream, kind, a, b,
                        out, n);
     return hipGetLastError() == hipSuccess ? WEDM_OK : WEDM_ERR_HIP;

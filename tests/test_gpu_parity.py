@@ -56,7 +56,7 @@ def test_native_library_is_the_one_running():
     assert "wedm_step_lanes" in env._backend.last_kernel()
 
 
-@pytest.mark.parametrize("kind", [0, 1, 2, 3, 4, 5, 6, 7])
+@pytest.mark.parametrize("kind", [0, 1, 2, 3, 4, 5, 6, 7, 8])
 def test_device_math_primitives_match_cpu_bit_for_bit(orc, kind):
     """exp/log/cube are IEEE-basic-op expression trees; sqrt, division and fmod-based
     floor division must be correctly rounded on the device; Philox must match."""
@@ -79,6 +79,17 @@ def test_device_math_primitives_match_cpu_bit_for_bit(orc, kind):
         b[:64] = 0.2
     elif kind == 5:
         a = rng.uniform(-1e3, 1e3, n); b = rng.uniform(1e-3, 1e3, n)
+    elif kind == 8:
+        # the spark's cell: y in [0, h] over segment lengths, plus the cases a rounded division gets wrong (products
+        # of an integer and the segment length nudged by one unit in the last place either way), negatives and NaN
+        b = rng.choice([0.1, 0.2, 0.25, 0.3, 0.5, 0.625, 1.0, 0.7, 1e-3, 3.3], n)
+        a = rng.uniform(0, 60, n)
+        m = rng.integers(0, 5000, n // 2).astype(np.float64) * b[: n // 2]
+        a[: n // 2] = np.nextafter(m, rng.choice([-np.inf, np.inf, 0.0], n // 2) * np.ones(n // 2))
+        a[n // 2: n // 2 + 64] = -rng.uniform(0, 40, 64)
+        a[n // 2 + 64] = np.nan
+        a[n // 2 + 65] = 0.0
+        a[n // 2 + 66] = 1e300
     else:
         a = rng.integers(0, 2**31, n).astype(np.float64); b = rng.integers(0, 2**31, n).astype(np.float64)
     ta, tb = torch.from_numpy(a).cuda(), torch.from_numpy(b).cuda()
@@ -100,6 +111,12 @@ def test_device_math_primitives_match_cpu_bit_for_bit(orc, kind):
         assert np.array_equal(want, np.array([x // y for x, y in zip(a.tolist(), b.tolist())]))
     elif kind == 5:
         want = a / b
+    elif kind == 8:
+        # int(y // seg) by CPython's own float floor division (NaN and 1e300 do not convert: the kernel's int
+        # conversion saturates there, and such a y never reaches it: the caller tests y == y and the range)
+        ok = np.isfinite(a) & (np.abs(a) < 1e12)
+        want = np.array([float(int(x // y)) if k else 0.0 for x, y, k in zip(a.tolist(), b.tolist(), ok)])
+        got = np.where(ok, got, 0.0)
     elif kind == 6:
         want = np.array([(lambda u: u[0] + 2.0 * u[1] + 4.0 * u[2] + 8.0 * u[3])(
             orc.step_uniforms(0x9abcdef012345678, int(y), 3, int(x))) for x, y in zip(a[:4096], b[:4096])])

@@ -26,8 +26,8 @@ env.step(act)
 torch.cuda.synchronize()
 print(env._backend.last_kernel())
 raw = buf.cpu().numpy().reshape(nblk * 4, 8).astype(np.float64)
-names = ["everything requested", "wire in LDS", "prelude done", "walk done", "patches + reduce + epilogue done", "stores issued", "stores landed"]
-idx = [0, 1, 2, 3, 4, 5, 6]
+names = ["everything requested", "first prelude done", "wire in LDS", "walk done", "patches + reduce + epilogue done", "stores issued", "stores landed"]
+idx = [0, 2, 1, 3, 4, 5, 6]
 prev = raw[:, 7]
 for i, nm in zip(idx, names):
     d = raw[:, i] - prev
@@ -35,3 +35,8 @@ for i, nm in zip(idx, names):
     prev = raw[:, i]
 life = raw[:, 6] - raw[:, 7]
 print(f"  wave lifetime: median {np.median(life):.0f} p90 {np.percentile(life, 90):.0f} max {life.max():.0f} cycles")
+# chip-wide skew: meaningful with a -DWEDM_STAMPS -DWEDM_STAMPS_REAL build only (one 100 MHz clock, 10 ns per tick)
+start, end = raw[:, 7], raw[:, 6]
+t0 = start.min()
+print("  wave starts after the first (p10/p50/p90/max):", np.percentile(start - t0, [10, 50, 90, 100]).round())
+print("  wave ends after the first start (p1/p10/p50/p90/p99/max):", np.percentile(end - t0, [1, 10, 50, 90, 99, 100]).round())
