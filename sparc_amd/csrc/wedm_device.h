@@ -641,8 +641,15 @@ __device__ __forceinline__ Coef scalar_prelude(const Hot& p, const ColdRef cold,
                                                uint32_t gid, Env& s, Persist& ps, bool writer,
                                                const QuietTry& qt = QuietTry{W4{0u, 0u, 0u, 0u}, false}) {
     double rv[WEDM_REPLAY_SLOTS] = {0.0, 0.0, 0.0, 0.0, 0.0};
+    // The cold parameter block and the pointer block, fetched ONCE per call (laundered: nothing read through them can
+    // be hoisted out of the microsecond loop).  Every rare branch below used to launder its own copy: two dependent
+    // scalar loads (kernel-argument segment, then the field) and a wait at each of ~15 sites of a fresh-spark step.
+    const ColdPtr cc0 = cold.get();
+    const wedm_params* const c0 = opaque(cc0->p);
+#define WEDM_GEOM_F64_C0(row, field) (p.per_env_geometry ? cc0->g.f64[(int64_t)(row) * cc0->s.stride + e] : c0->field)
+#define WEDM_GEOM_I32_C0(row, field) (p.per_env_geometry ? cc0->g.i32[(int64_t)(row) * cc0->s.stride + e] : c0->field)
     if (REPLAY) {
-        const ColdPtr c = cold.get();
+        const ColdPtr c = cc0;
         int64_t step = (int64_t)s.time / p.dt_us;
         if (step >= c->replay_steps) { s.err = 1; step = c->replay_steps - 1; }
         const double* rp = c->replay + step * (int64_t)WEDM_REPLAY_SLOTS * c->s.stride + e;
@@ -652,7 +659,7 @@ __device__ __forceinline__ Coef scalar_prelude(const Hot& p, const ColdRef cold,
     // ---- control-step latch (wire_edm.py:117-121,162-170)
     s.ctrl = s.tss >= p.servo_interval;
     if (s.ctrl) {
-        const ColdPtr c = cold.get();
+        const ColdPtr c = cc0;
         s.tdelta = c->a.servo[e];
         s.tvolt = c->a.target_voltage[e];
         s.mode = c->a.current_mode[e];
@@ -688,7 +695,7 @@ __device__ __forceinline__ Coef scalar_prelude(const Hot& p, const ColdRef cold,
         if (!timers && !hard && ex <= (REPLAY ? 500.0 : 24.0) && ex >= -500) p_d = 1.0 / (1.0 + portable_exp(ex));
         double p_r = 0.0;
         if (p.has_random_short) {  // ignition.py:221-230; max_probability == 0 by default
-            const wedm_params* c = opaque(cold->p);
+            const wedm_params* c = c0;
             if (gap >= c->random_short_max_gap) p_r = 0.0;
             else if (gap <= c->random_short_min_gap) p_r = c->random_short_max_probability;
             else
@@ -713,7 +720,7 @@ __device__ __forceinline__ Coef scalar_prelude(const Hot& p, const ColdRef cold,
             new_r = !timers && !new_d && ((REPLAY ? rv[WEDM_RS_RANDOM_ROLL] : u32_to_unit(w.y)) < p_r);
         }
         if (new_d || new_r) {  // rare: a short begins (durations are cold parameters)
-            const wedm_params* c = opaque(cold->p);
+            const wedm_params* c = c0;
             if (new_d) s.deb_rem = c->debris_short_duration;
             else s.rnd_rem = c->random_short_duration;
         }
@@ -746,7 +753,7 @@ __device__ __forceinline__ Coef scalar_prelude(const Hot& p, const ColdRef cold,
         s.V = V;
         s.I = burning ? Ipk : 0.0;
         if (ign) {  // rare: spark location, Generator.uniform(0, h)
-            const double h = WEDM_COLD_GEOM_F64(cold, p, WEDM_G_HEIGHT, workpiece_height);
+            const double h = WEDM_GEOM_F64_C0(WEDM_G_HEIGHT, workpiece_height);
             s.y = REPLAY ? rv[WEDM_RS_SPARK_Y] : 0.0 + (h - 0.0) * u32_to_unit(w.w);
         }
         s.y = (to_pulse || end_rest) ? __builtin_nan("") : s.y;
@@ -757,28 +764,40 @@ __device__ __forceinline__ Coef scalar_prelude(const Hot& p, const ColdRef cold,
 
     // ---- material removal (material.py:79-174)
     if (fresh) {
-        const ColdPtr cc = cold.get();
+        const ColdPtr cc = cc0;
         const Tables tb{cc->tb.mode_current, cc->tb.crater_mean, cc->tb.crater_std, cc->tb.crater_depth, cc->tb.crater_valid};
         int m = s.mode == 0 ? 1 : s.mode;  // None -> "I1" (material.py:104-105)
-        if (m < 1 || m > WEDM_MAX_MODE || !tb.crater_valid[m]) { s.err = 1; m = 1; }
+        const bool in_range = m >= 1 && m <= WEDM_MAX_MODE;
+        if (!in_range) m = 1;
+        // everything this branch reads from memory is requested here, before the crater normal (~230 instructions
+        // with no memory access) is computed: one latency instead of a chain of them
+        const int32_t valid = tb.crater_valid[m];
+        double mean = tb.crater_mean[m], sd = tb.crater_std[m], depth = tb.crater_depth[m];
+        const double kerf_base = WEDM_GEOM_F64_C0(WEDM_G_KERF_BASE, kerf_base);
+        const double h = WEDM_GEOM_F64_C0(WEDM_G_HEIGHT, workpiece_height);
+        double* const clog = cc->s.crater_log;
+        const int64_t clog_cap = cc->s.crater_log_capacity, sstride = cc->s.stride;
+        double* const stats = cc->s.stats;
+        if (!in_range || !valid) {  // unknown mode (the reference raises ValueError, material.py:108-113)
+            s.err = 1;
+            mean = tb.crater_mean[1]; sd = tb.crater_std[1]; depth = tb.crater_depth[1];
+        }
         double vol;
         if (REPLAY) {
             vol = rv[WEDM_RS_CRATER_UM3];
         } else {
             const double z = philox_std_normal(s.key0, s.key1, t, ep, gid);
-            vol = tb.crater_mean[m] + tb.crater_std[m] * z;
+            vol = mean + sd * z;
         }
         if (!(vol > 0)) vol = 0;
-        if (writer && cc->s.crater_log && cc->s.crater_log_capacity > 0)  // crater_volumes_um3.append (material.py:133)
-            cc->s.crater_log[((int64_t)s.sparks % cc->s.crater_log_capacity) * cc->s.stride + e] = vol;
+        if (writer && clog && clog_cap > 0)  // crater_volumes_um3.append (material.py:133)
+            clog[((int64_t)s.sparks % clog_cap) * sstride + e] = vol;
         s.sparks += 1;
-        if (writer && cc->s.stats) crater_stats_update(cc->s.stats + e, cc->s.stride, vol);
+        if (writer && stats) crater_stats_update(stats + e, sstride, vol);
         double crater = vol / 1e9;
         s.last_crater = crater;
         if (crater > 0) {
-            const double kerf_base = WEDM_COLD_GEOM_F64(cold, p, WEDM_G_KERF_BASE, kerf_base);
-            const double h = WEDM_COLD_GEOM_F64(cold, p, WEDM_G_HEIGHT, workpiece_height);
-            double kerf = kerf_base + tb.crater_depth[m] / 1000.0;
+            double kerf = kerf_base + depth / 1000.0;
             double dx = 0.0;
             if (kerf > 0 && h > 0) dx = crater / (kerf * h) * 1000.0;
             s.wp += dx;
@@ -801,7 +820,7 @@ __device__ __forceinline__ Coef scalar_prelude(const Hot& p, const ColdRef cold,
             s.rho = 0.0;
         }
         if (__builtin_fabs(gap_um - s.last_gap) > 0.01 || __builtin_fabs(s.rho - s.last_rho) > 0.001) {
-            const wedm_params* c = opaque(cold->p);
+            const wedm_params* c = c0;
             double cube = cube_cr(gap_um / c->reference_gap);
             double gap_factor = cube < 1.0 ? cube : 1.0;
             double kd = c->debris_obstruction_coeff * s.rho;
@@ -824,7 +843,7 @@ __device__ __forceinline__ Coef scalar_prelude(const Hot& p, const ColdRef cold,
     {
         const double I = s.I, I2 = I * I;
         if (__builtin_fabs(s.flow - s.wire_last_flow) > 0.01) {
-            const wedm_params* c = opaque(cold->p);
+            const wedm_params* c = c0;
             double ve = c->convection_velocity_factor * s.unwind;
             ve = ve > -0.9 ? ve : -0.9;
             double hb = c->base_convection * (1.0 + ve);
@@ -839,14 +858,15 @@ __device__ __forceinline__ Coef scalar_prelude(const Hot& p, const ColdRef cold,
         cf.pidx = -1;
         cf.q = 0.0f;
         cf.q64 = 0.0;
+        // the uniform cold constants of the plasma / Joule terms in one batch of scalar loads (one wait)
+        const double seg = c0->segment_len, eff = c0->plasma_efficiency, rho_elec = c0->rho_elec, jg_u = c0->joule_geom;
+        const int zs_u = c0->zone_start;
         if (s.state == 1 && s.y == s.y) {
-            const wedm_params* c = opaque(cold->p);
-            const int zone_start = WEDM_COLD_GEOM_I32(cold, p, WEDM_GI_ZONE_START, zone_start);
-            const double seg = c->segment_len;
+            const int zone_start = p.per_env_geometry ? cc0->g.i32[(int64_t)WEDM_GI_ZONE_START * cc0->s.stride + e] : zs_u;
             int idx = seg != 0 ? zone_start + spark_cell_offset(s.y, seg) : zone_start;
             if (idx >= 0 && idx < g.n_seg) {
                 cf.pidx = idx;
-                cf.q64 = c->plasma_efficiency * s.V * I;
+                cf.q64 = eff * s.V * I;
                 cf.q = (float)cf.q64;
             }
         }
@@ -854,12 +874,14 @@ __device__ __forceinline__ Coef scalar_prelude(const Hot& p, const ColdRef cold,
         cf.jf = 0.0f;
         cf.jf64 = 0.0;
         if (cf.joule_on) {
-            const double joule_geom = WEDM_COLD_GEOM_F64(cold, p, WEDM_G_JOULE_GEOM, joule_geom);
-            cf.jf64 = joule_geom * I2 * opaque(cold->p)->rho_elec;
+            const double joule_geom = p.per_env_geometry ? cc0->g.f64[(int64_t)WEDM_G_JOULE_GEOM * cc0->s.stride + e] : jg_u;
+            cf.jf64 = joule_geom * I2 * rho_elec;
             cf.jf = (float)cf.jf64;
         }
     }
     return cf;
+#undef WEDM_GEOM_F64_C0
+#undef WEDM_GEOM_I32_C0
 }
 
 // ------------------------------------------------- quiet-step fast path (wave-uniform)
@@ -941,14 +963,17 @@ __device__ __forceinline__ bool quiet_prelude_t(const Hot& p, const ColdRef cold
         }
     }
     if (DENSE && __any(burning)) {  // wire.py:284-301, 96-100 for the lanes that keep burning
+        // the five cold constants of this block in one batch of scalar loads (one wait instead of four chains of two)
+        const ColdPtr cc0 = cold.get();
+        const wedm_params* const c = opaque(cc0->p);
+        const double seg = c->segment_len, eff = c->plasma_efficiency, rho_elec = c->rho_elec;
+        const int zone_start = (p.per_env_geometry && burning) ? cc0->g.i32[(int64_t)WEDM_GI_ZONE_START * cc0->s.stride + e] : c->zone_start;
+        const double joule_geom = (p.per_env_geometry && burning) ? cc0->g.f64[(int64_t)WEDM_G_JOULE_GEOM * cc0->s.stride + e] : c->joule_geom;
         if (burning && s.y == s.y) {
-            const wedm_params* c = opaque(cold->p);
-            const int zone_start = WEDM_COLD_GEOM_I32(cold, p, WEDM_GI_ZONE_START, zone_start);
-            const double seg = c->segment_len;
             const int idx = seg != 0 ? zone_start + spark_cell_offset(s.y, seg) : zone_start;
             if (idx >= 0 && idx < g.n_seg) {
                 cf.pidx = idx;
-                cf.q64 = c->plasma_efficiency * s.V * s.I;
+                cf.q64 = eff * s.V * s.I;
                 cf.q = (float)cf.q64;
             }
         }
@@ -956,8 +981,7 @@ __device__ __forceinline__ bool quiet_prelude_t(const Hot& p, const ColdRef cold
             const double I2 = s.I * s.I;
             cf.joule_on = I2 > 1e-6;
             if (cf.joule_on) {
-                const double joule_geom = WEDM_COLD_GEOM_F64(cold, p, WEDM_G_JOULE_GEOM, joule_geom);
-                cf.jf64 = joule_geom * I2 * opaque(cold->p)->rho_elec;
+                cf.jf64 = joule_geom * I2 * rho_elec;
                 cf.jf = (float)cf.jf64;
             }
         }

@@ -32,3 +32,19 @@ gap = (env.state.workpiece_position - env.state.wire_position)
 print(f"{kind} controller, {wl}: {n * done / dt:.3e} env-steps/s over {done} us ({dt / intervals * 1e3:.2f} ms per control interval), "
       f"{(int(env.state.spark_count.sum()) - s0) / n / (done / 1000):.1f} sparks per env per ms, mean gap {float(gap.mean()):.2f} um, "
       f"kernel {env._backend.last_kernel()}")
+
+# where a control interval's time goes: the launch (HIP events on the launch stream) vs everything else
+ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(intervals)]
+action = ctl(env)
+torch.cuda.synchronize()
+t0 = time.perf_counter()
+for a, b in ev:
+    a.record()
+    env.step_many(action, 1000)
+    b.record()
+    action = ctl(env)
+torch.cuda.synchronize()
+dt = time.perf_counter() - t0
+kms = sum(a.elapsed_time(b) for a, b in ev) / intervals
+print(f"  per control interval: launch {kms:.3f} ms (HIP events), wall {dt / intervals * 1e3:.3f} ms -> "
+      f"controller + host {dt / intervals * 1e3 - kms:.3f} ms")
