@@ -646,8 +646,11 @@ __device__ __forceinline__ Coef scalar_prelude(const Hot& p, const ColdRef cold,
     // scalar loads (kernel-argument segment, then the field) and a wait at each of ~15 sites of a fresh-spark step.
     const ColdPtr cc0 = cold.get();
     const wedm_params* const c0 = opaque(cc0->p);
-#define WEDM_GEOM_F64_C0(row, field) (p.per_env_geometry ? cc0->g.f64[(int64_t)(row) * cc0->s.stride + e] : c0->field)
-#define WEDM_GEOM_I32_C0(row, field) (p.per_env_geometry ? cc0->g.i32[(int64_t)(row) * cc0->s.stride + e] : c0->field)
+    // the uniform constants of the rare branches, requested in one batch (scalar loads: one wait at the first use)
+    const double seg = c0->segment_len, eff = c0->plasma_efficiency, rho_elec = c0->rho_elec, jg_u = c0->joule_geom;
+    const double h_u = c0->workpiece_height, kerf_u = c0->kerf_base;
+    const double ref_gap = c0->reference_gap, obstruction = c0->debris_obstruction_coeff;
+    const int zs_u = c0->zone_start;
     if (REPLAY) {
         const ColdPtr c = cc0;
         int64_t step = (int64_t)s.time / p.dt_us;
@@ -753,7 +756,7 @@ __device__ __forceinline__ Coef scalar_prelude(const Hot& p, const ColdRef cold,
         s.V = V;
         s.I = burning ? Ipk : 0.0;
         if (ign) {  // rare: spark location, Generator.uniform(0, h)
-            const double h = WEDM_GEOM_F64_C0(WEDM_G_HEIGHT, workpiece_height);
+            const double h = p.per_env_geometry ? cc0->g.f64[(int64_t)WEDM_G_HEIGHT * cc0->s.stride + e] : h_u;
             s.y = REPLAY ? rv[WEDM_RS_SPARK_Y] : 0.0 + (h - 0.0) * u32_to_unit(w.w);
         }
         s.y = (to_pulse || end_rest) ? __builtin_nan("") : s.y;
@@ -773,8 +776,8 @@ __device__ __forceinline__ Coef scalar_prelude(const Hot& p, const ColdRef cold,
         // with no memory access) is computed: one latency instead of a chain of them
         const int32_t valid = tb.crater_valid[m];
         double mean = tb.crater_mean[m], sd = tb.crater_std[m], depth = tb.crater_depth[m];
-        const double kerf_base = WEDM_GEOM_F64_C0(WEDM_G_KERF_BASE, kerf_base);
-        const double h = WEDM_GEOM_F64_C0(WEDM_G_HEIGHT, workpiece_height);
+        const double kerf_base = p.per_env_geometry ? cc0->g.f64[(int64_t)WEDM_G_KERF_BASE * cc0->s.stride + e] : kerf_u;
+        const double h = p.per_env_geometry ? cc0->g.f64[(int64_t)WEDM_G_HEIGHT * cc0->s.stride + e] : h_u;
         double* const clog = cc->s.crater_log;
         const int64_t clog_cap = cc->s.crater_log_capacity, sstride = cc->s.stride;
         double* const stats = cc->s.stats;
@@ -820,13 +823,12 @@ __device__ __forceinline__ Coef scalar_prelude(const Hot& p, const ColdRef cold,
             s.rho = 0.0;
         }
         if (__builtin_fabs(gap_um - s.last_gap) > 0.01 || __builtin_fabs(s.rho - s.last_rho) > 0.001) {
-            const wedm_params* c = c0;
-            double cube = cube_cr(gap_um / c->reference_gap);
+            double cube = cube_cr(gap_um / ref_gap);
             double gap_factor = cube < 1.0 ? cube : 1.0;
-            double kd = c->debris_obstruction_coeff * s.rho;
+            double kd = obstruction * s.rho;
             double df;
             if (kd < 2.0) df = kd < 0.5 ? (1 - 0.5 * kd) / (1 + 0.5 * kd) : portable_exp(-kd);
-            else df = portable_exp(-c->debris_obstruction_coeff * s.rho);
+            else df = portable_exp(-obstruction * s.rho);
             s.flow = gap_factor * df;
             s.last_gap = gap_um;
             s.last_rho = s.rho;
@@ -858,9 +860,6 @@ __device__ __forceinline__ Coef scalar_prelude(const Hot& p, const ColdRef cold,
         cf.pidx = -1;
         cf.q = 0.0f;
         cf.q64 = 0.0;
-        // the uniform cold constants of the plasma / Joule terms in one batch of scalar loads (one wait)
-        const double seg = c0->segment_len, eff = c0->plasma_efficiency, rho_elec = c0->rho_elec, jg_u = c0->joule_geom;
-        const int zs_u = c0->zone_start;
         if (s.state == 1 && s.y == s.y) {
             const int zone_start = p.per_env_geometry ? cc0->g.i32[(int64_t)WEDM_GI_ZONE_START * cc0->s.stride + e] : zs_u;
             int idx = seg != 0 ? zone_start + spark_cell_offset(s.y, seg) : zone_start;
@@ -880,8 +879,6 @@ __device__ __forceinline__ Coef scalar_prelude(const Hot& p, const ColdRef cold,
         }
     }
     return cf;
-#undef WEDM_GEOM_F64_C0
-#undef WEDM_GEOM_I32_C0
 }
 
 // ------------------------------------------------- quiet-step fast path (wave-uniform)
