@@ -296,15 +296,30 @@ struct ColdRef {
 
 // Hide a pointer from loop-invariant code motion: loads through the result cannot be
 // hoisted out of the (rare) branch they sit in, so they cost SGPRs only there.
+typedef const wedm_params* ParamsPtr;
 template <class T>
 __device__ __forceinline__ const T* opaque(const T* p) {
     asm volatile("" : "+s"(p));
     return p;
 }
+// The same, but the result points into the CONSTANT address space (wedm_params is written by the host between
+// launches only), so a uniform load through it is an `s_load` (scalar cache, its own counter) instead of the
+// `flat_load` the laundered generic pointer gets.  For the few reads at kernel entry / exit: a flat load there is
+// queued behind the single-microsecond kernel's stream of wire rows and returns only after all of them.  NOT for the
+// rare branches of the microsecond loop: there the scalar results cost SGPRs and v_movs into the float64 VALU
+// operands, and measured 4-5 % slower on every fused workload than the vector loads.
+template <class T>
+__device__ __forceinline__ const WEDM_AS4 T* opaque_const(const T* p) {
+    asm volatile("" : "+s"(p));
+    return (const WEDM_AS4 T*)(unsigned long long)p;
+}
 
 // launch-level switches live in the device copy of wedm_params: read where they are used (kernel entry / exit)
 #define WEDM_AUTORESET(cold) (opaque((cold)->p)->autoreset != 0)
 #define WEDM_REWARD_ON(cold) (opaque((cold)->p)->reward_mode != 0 && (cold)->s.reward != nullptr)
+// (the single-microsecond stream kernel's flavour: scalar loads, see opaque_const)
+#define WEDM_AUTORESET_SCALAR(cold) (opaque_const((cold)->p)->autoreset != 0)
+#define WEDM_REWARD_ON_SCALAR(cold) (opaque_const((cold)->p)->reward_mode != 0 && (cold)->s.reward != nullptr)
 
 #define WEDM_ROW(ptr, row) ((ptr) + (int64_t)(row) * stride + e)
 
@@ -600,16 +615,31 @@ __device__ __forceinline__ void refresh_convection(const Hot& hot, const ColdRef
 }
 
 // once per launch: coefficients whose inputs no module changes (wire.py:304-312)
+// SCALAR_LOADS (the single-microsecond stream kernel): the uniform constants through the constant address space
+template <bool SCALAR_LOADS = false>
 __device__ __forceinline__ void init_persist(const Hot& hot, const ColdRef cold, int64_t e, const Env& s, Persist& ps) {
     double adv = 0.0;
     if (__builtin_fabs(s.unwind) > 1e-6) {
-        const double s_area = WEDM_COLD_GEOM_F64(cold, hot, WEDM_G_S_AREA, s_area);
-        adv = cold->p->rho_c * __builtin_fabs(s.unwind) * s_area;
+        if (SCALAR_LOADS) {
+            const auto pc = opaque_const(cold->p);
+            const double s_area = hot.per_env_geometry ? cold->g.f64[(int64_t)WEDM_G_S_AREA * cold->s.stride + e] : pc->s_area;
+            adv = pc->rho_c * __builtin_fabs(s.unwind) * s_area;
+        } else {
+            const double s_area = WEDM_COLD_GEOM_F64(cold, hot, WEDM_G_S_AREA, s_area);
+            adv = cold->p->rho_c * __builtin_fabs(s.unwind) * s_area;
+        }
     }
     ps.adv_on = __builtin_fabs(adv) > 1e-9;  // wire.py:115
     ps.adv = ps.adv_on ? (float)adv : 0.0f;
     ps.adv64 = ps.adv_on ? adv : 0.0;
-    refresh_convection(hot, cold, e, s, ps);
+    if (SCALAR_LOADS) {  // refresh_convection()
+        const float A = (float)(hot.per_env_geometry ? cold->g.f64[(int64_t)WEDM_G_A_SURF * cold->s.stride + e]
+                                                     : opaque_const(cold->p)->a_surf);
+        ps.conv_base = s.h_base * A;
+        ps.conv_zone = s.h_zone * A;
+    } else {
+        refresh_convection(hot, cold, e, s, ps);
+    }
 }
 
 // --------------------------------------------------- scalar prelude (modules 1-4a)
@@ -645,7 +675,7 @@ __device__ __forceinline__ Coef scalar_prelude(const Hot& p, const ColdRef cold,
     // be hoisted out of the microsecond loop).  Every rare branch below used to launder its own copy: two dependent
     // scalar loads (kernel-argument segment, then the field) and a wait at each of ~15 sites of a fresh-spark step.
     const ColdPtr cc0 = cold.get();
-    const wedm_params* const c0 = opaque(cc0->p);
+    const ParamsPtr c0 = opaque(cc0->p);
     // the uniform constants of the rare branches, requested in one batch (scalar loads: one wait at the first use)
     const double seg = c0->segment_len, eff = c0->plasma_efficiency, rho_elec = c0->rho_elec, jg_u = c0->joule_geom;
     const double h_u = c0->workpiece_height, kerf_u = c0->kerf_base;
@@ -698,7 +728,7 @@ __device__ __forceinline__ Coef scalar_prelude(const Hot& p, const ColdRef cold,
         if (!timers && !hard && ex <= (REPLAY ? 500.0 : 24.0) && ex >= -500) p_d = 1.0 / (1.0 + portable_exp(ex));
         double p_r = 0.0;
         if (p.has_random_short) {  // ignition.py:221-230; max_probability == 0 by default
-            const wedm_params* c = c0;
+            const ParamsPtr c = c0;
             if (gap >= c->random_short_max_gap) p_r = 0.0;
             else if (gap <= c->random_short_min_gap) p_r = c->random_short_max_probability;
             else
@@ -723,7 +753,7 @@ __device__ __forceinline__ Coef scalar_prelude(const Hot& p, const ColdRef cold,
             new_r = !timers && !new_d && ((REPLAY ? rv[WEDM_RS_RANDOM_ROLL] : u32_to_unit(w.y)) < p_r);
         }
         if (new_d || new_r) {  // rare: a short begins (durations are cold parameters)
-            const wedm_params* c = c0;
+            const ParamsPtr c = c0;
             if (new_d) s.deb_rem = c->debris_short_duration;
             else s.rnd_rem = c->random_short_duration;
         }
@@ -845,7 +875,7 @@ __device__ __forceinline__ Coef scalar_prelude(const Hot& p, const ColdRef cold,
     {
         const double I = s.I, I2 = I * I;
         if (__builtin_fabs(s.flow - s.wire_last_flow) > 0.01) {
-            const wedm_params* c = c0;
+            const ParamsPtr c = c0;
             double ve = c->convection_velocity_factor * s.unwind;
             ve = ve > -0.9 ? ve : -0.9;
             double hb = c->base_convection * (1.0 + ve);
@@ -962,7 +992,7 @@ __device__ __forceinline__ bool quiet_prelude_t(const Hot& p, const ColdRef cold
     if (DENSE && __any(burning)) {  // wire.py:284-301, 96-100 for the lanes that keep burning
         // the five cold constants of this block in one batch of scalar loads (one wait instead of four chains of two)
         const ColdPtr cc0 = cold.get();
-        const wedm_params* const c = opaque(cc0->p);
+        const ParamsPtr c = opaque(cc0->p);
         const double seg = c->segment_len, eff = c->plasma_efficiency, rho_elec = c->rho_elec;
         const int zone_start = (p.per_env_geometry && burning) ? cc0->g.i32[(int64_t)WEDM_GI_ZONE_START * cc0->s.stride + e] : c->zone_start;
         const double joule_geom = (p.per_env_geometry && burning) ? cc0->g.f64[(int64_t)WEDM_G_JOULE_GEOM * cc0->s.stride + e] : c->joule_geom;
@@ -1139,7 +1169,7 @@ __device__ __forceinline__ void control_step_outputs(const ColdRef cold, int64_t
 // store_env() never writes.  The caller sets the environment's wire to the spool temperature.
 __device__ __forceinline__ void reinit_env(const ColdRef cold, int64_t e, Env& s, bool writer) {
     const ColdPtr c = cold.get();
-    const wedm_params* p = opaque(c->p);
+    const ParamsPtr p = opaque(c->p);
     const int32_t episode = s.episode + 1;
     const uint32_t k0 = s.key0, k1 = s.key1;
     const float spool = (float)p->spool_T;

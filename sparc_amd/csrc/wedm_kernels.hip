@@ -988,6 +988,10 @@ __global__ void __launch_bounds__(256, 2) wedm_step_stream(const KArgs k) {
     const int jn = (!live) ? 0 : ((C < n - cbase) ? C : n - cbase);  // cells of this chunk that exist (<= 0: none)
     WEDM_S2_STAMP_DECL;
 
+    // (0) the peak-current table (ignition.py:98-113), entry `lane` in lane `lane`: the wave's first vector load, so that
+    // the lookup by the latched mode further down is a cross-lane read of a register that arrived long ago instead of a
+    // load queued behind the whole wire (vector loads return in order: the first prelude would wait for every row)
+    const double ipk_entry = cold->tb.mode_current[(tid & 63) <= WEDM_MAX_MODE ? (tid & 63) : WEDM_MAX_MODE];
     // (1) the state rows a microsecond reads: requested first, so that the first prelude runs while the wire is in flight
     Env s;
     Geom g;
@@ -1021,14 +1025,19 @@ __global__ void __launch_bounds__(256, 2) wedm_step_stream(const KArgs k) {
     }
     WEDM_S2_STAMP(0);  // everything requested
     // next-step autoreset (all L lanes of the environment agree)
-    const bool reinit = live && s.done && WEDM_AUTORESET(cold);
+    const bool reinit = live && s.done && WEDM_AUTORESET_SCALAR(cold);
     if (reinit) reinit_env(cold, e, s, c == 0);
     const bool frozen0 = s.done;
     double wp0 = 0.0;  // workpiece position at the start of the launch (reward)
-    if (WEDM_REWARD_ON(cold) && !frozen0) wp0 = s.wp;
-    if (!s.done) {
-        s.ipk = peak_current(cold, s.mode);
-        init_persist(k.hot, cold, e, s, ps);
+    if (WEDM_REWARD_ON_SCALAR(cold) && !frozen0) wp0 = s.wp;
+    {
+        const bool in_table = s.mode >= 1 && s.mode <= WEDM_MAX_MODE;
+        const double from_table = __shfl(ipk_entry, in_table ? s.mode : 0, 64);  // every lane takes part
+        if (!s.done) {
+            s.ipk = s.mode == 0 ? 60.0 : from_table;
+            if (s.mode != 0 && !in_table) s.ipk = peak_current(cold, s.mode);  // default_current (cold parameter)
+            init_persist<true>(k.hot, cold, e, s, ps);
+        }
     }
     pin_hot_in_vgprs(hv);
     const uint32_t gid = k.hot.env_id_offset + (uint32_t)e;
@@ -1282,7 +1291,7 @@ __global__ void __launch_bounds__(256, 2) wedm_step_stream(const KArgs k) {
         if (patch1 >= 0 && patch1 < jn && ((stored >> (patch1 >> 3)) & 1u)) *(float*)(Tw + offc + (uint32_t)patch1 * rowb) = col[patch1 * 256];
     }
     if (live && c == 0 && !frozen0) {
-        if (WEDM_REWARD_ON(cold)) {
+        if (WEDM_REWARD_ON_SCALAR(cold)) {
             const double pen = opaque(cold->p)->reward_break_penalty;
             cold->s.reward[e] = (float)(s.wp - wp0) - (float)pen * (s.broken ? 1.0f : 0.0f);
         }
