@@ -1442,10 +1442,14 @@ __global__ void __launch_bounds__(256, 2) wedm_step_packed(const KArgs k) {
 
         // full predicated formula for one owned cell, from OLD values (patched cells)
         auto patch_value = [&](int i, int own) -> float {
+            // (unconditional LDS reads from clamped rows, then selects: a conditional read made the compiler select
+            // between an LDS and a private address and fall back to flat loads; the rows after the last pair are the
+            // halo pair (b_first, halo_r), exactly what the last cell of A / B needs on its right)
             const int v = own - 1, r = i - (v ? baseB : baseA), row = 2 * r + v;
-            float tm = r > 0 ? col[(row - 2) * 256] : (v ? a_last : halo_l);
+            const float left = col[(r > 0 ? row - 2 : row) * 256];
+            float tm = r > 0 ? left : (v ? a_last : halo_l);
             if (i == 1) tm = spool;
-            const float tp = r < Cv - 1 ? col[(row + 2) * 256] : (v ? halo_r : b_first);
+            const float tp = col[(row + 2) * 256];
             return stencil_cell(i, n, tm, col[row * 256], tp, g, cf, ps, tref, alpha, tdiel);
         };
         const int own_pl = (!s.done && cf.pidx >= 1) ? owner(cf.pidx) : 0;
