@@ -957,11 +957,14 @@ __global__ void __launch_bounds__(256, 2) wedm_step_fused(const KArgs k) {
 // row.  This kernel has ONE memory round trip for everything it reads and no barrier:
 //   * L lanes of ONE wave share an environment, as in the fused kernels (scalar physics replicated, halos
 //     from the neighbour lane's column, DPP max reduction);
-//   * at its very first instructions every lane requests its whole chunk into registers (CMAX unconditional
-//     `global_load_dword`s from clamped addresses: a count the compiler can see, so no conservative waits)
-//     and then the state rows a microsecond reads; when both have landed the chunk is dropped into the lane's
+//   * at its very first instructions every lane requests the peak-current table (one entry per lane), the state
+//     rows a microsecond reads and then its whole chunk of the wire into registers (CMAX unconditional
+//     `global_load_dword`s from clamped addresses: a count the compiler can see, so no conservative waits);
+//     the launch's first prelude needs the state only and runs while the wire is still in flight (nothing it reads
+//     is queued behind the wire rows: vector loads return in order), then the chunk is dropped into the lane's
 //     LDS column and the tile walk of wedm_step_fused runs on it;
-//   * the write-back goes out 16 rows at a time (16 LDS reads, then 16 stores), fire and forget; only the state
+//   * in the launch's last microsecond the walk stores every regular and boundary tile straight to global memory;
+//     what is left (irregular tiles, patched cells) goes out after the loop, 8 rows at a time; only the state
 //     rows a microsecond can have changed are stored (store_env_after_*), and a wave whose steps were all quiet
 //     skips the rows the quiet prelude cannot change.
 // Every wave is its own pipeline, so the loads, arithmetic and stores of different waves overlap by themselves.

@@ -2,6 +2,7 @@
 """profiles/traffic.json and profiles/valu.json from the PMC summaries of tools/profile_round.sh.
 
     python tools/make_traffic_json.py profiles/r2
+    python tools/make_traffic_json.py gpurun_out/r2/summary profiles/r2   (second argument: where the summaries will be committed)
 
 HBM bytes per launch = 2 x FETCH_SIZE + WRITE_SIZE (KB -> bytes).  FETCH_SIZE is doubled as
 /opt/skills/guides/MI355X_MICROARCH.md prescribes for gfx950 (it tallies 128-B requests at 64 B);
@@ -14,6 +15,7 @@ import sys
 from pathlib import Path
 
 d = Path(sys.argv[1])
+label = sys.argv[2] if len(sys.argv) > 2 else str(d)
 traffic, valu = [], []
 CASES = (("config3", "bench_config3.json"), ("config4", "bench_config4_shard.json"), ("config2", "bench_config2.json"),
          ("config5", "bench_config5_shard.json"), ("config3_1us", "bench_config3_1us.json"))
@@ -42,7 +44,7 @@ for cfg, bench in CASES:
                 "FETCH_SIZE_KB": vals["FETCH_SIZE"], "WRITE_SIZE_KB": vals["WRITE_SIZE"],
                 "hbm_bytes_per_launch": (2 * vals["FETCH_SIZE"] + vals["WRITE_SIZE"]) * 1024.0,
                 "env_steps_per_launch": env_steps,
-                "source": f"{d}/rocprofv3_pmc_hbm_{cfg}.txt (separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of bench.py)",
+                "source": f"{label}/rocprofv3_pmc_hbm_{cfg}.txt (separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of bench.py)",
             })
     f = d / f"rocprofv3_pmc_sq_{cfg}.txt"
     if f.exists():
@@ -52,7 +54,7 @@ for cfg, bench in CASES:
                 "kernel_prefix": b["config"]["kernel"], "workload": b["config"]["workload"],
                 "valu_insts_per_launch": vals["SQ_INSTS_VALU"], "env_steps_per_launch": env_steps,
                 **{k.lower(): v for k, v in vals.items() if k != "SQ_INSTS_VALU"},
-                "source": f"{d}/rocprofv3_pmc_sq_{cfg}.txt (separate rocprofv3 --pmc SQ_* pass of bench.py)",
+                "source": f"{label}/rocprofv3_pmc_sq_{cfg}.txt (separate rocprofv3 --pmc SQ_* pass of bench.py)",
             })
 (Path("profiles") / "traffic.json").write_text(json.dumps(traffic, indent=1) + "\n")
 (Path("profiles") / "valu.json").write_text(json.dumps(valu, indent=1) + "\n")

@@ -10,22 +10,17 @@ S=$OUT/summary
 mkdir -p $S
 export TMPDIR=/tmp
 
-echo "[profile] bench lines"; date +%T
-python bench.py --steps 20 --warmup 2 > $S/bench_config3.json 2> $OUT/bench_config3.err
+bench_lines() {  # $1: extra flags of the headline run ("" = with the CPU baseline leg)
+python bench.py --steps 20 --warmup 2 $1 > $S/bench_config3.json 2> $OUT/bench_config3.err
 python bench.py --steps 10 --warmup 2 --workload config2 --no-cpu-baseline > $S/bench_config2.json 2>/dev/null
 python bench.py --steps 10 --warmup 2 --workload config4 --no-cpu-baseline > $S/bench_config4_shard.json 2>/dev/null
 python bench.py --steps 10 --warmup 2 --workload config5 --no-cpu-baseline > $S/bench_config5_shard.json 2>/dev/null
 python bench.py --steps 2000 --warmup 100 --substeps 1 --no-cpu-baseline --no-side > $S/bench_config3_1us.json 2>/dev/null
 python bench.py --steps 2000 --warmup 100 --substeps 1 --workload config4 --no-cpu-baseline > $S/bench_config4_1us.json 2>/dev/null
 python bench.py --steps 2000 --warmup 100 --substeps 1 --workload config2 --no-cpu-baseline > $S/bench_config2_1us.json 2>/dev/null
-WEDM_BENCH_FORCE_DIST=1 MASTER_ADDR=127.0.0.1 MASTER_PORT=29533 RANK=0 WORLD_SIZE=1 LOCAL_RANK=0 \
-    python bench.py --steps 10 --warmup 2 --no-cpu-baseline --no-side > $S/bench_config3_rccl_world1.json 2>/dev/null
-
-echo "[profile] rocprofv3 kernel trace"; date +%T
-rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/kt -o kt -- python3 bench.py --steps 20 --warmup 2 --no-cpu-baseline --no-side > $OUT/kt.log 2>&1
-cp $(find $OUT/kt -name "*kernel_stats.csv" | head -1) $S/rocprofv3_kernel_stats_config3.csv
-rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/kt1 -o kt -- python3 bench.py --steps 400 --warmup 50 --substeps 1 --no-cpu-baseline --no-side > $OUT/kt1.log 2>&1
-cp $(find $OUT/kt1 -name "*kernel_stats.csv" | head -1) $S/rocprofv3_kernel_stats_config3_1us.csv
+}
+echo "[profile] bench lines, first pass (kernel names and units per launch for the PMC tables)"; date +%T
+bench_lines "--no-cpu-baseline --no-side"
 
 echo "[profile] PMC passes (one counter group per run)"; date +%T
 pmc() {  # tag counters... -- bench args
@@ -45,5 +40,20 @@ pmc write_1us WRITE_SIZE -- --steps 40 --warmup 5 --substeps 1
 pmc sq_1us SQ_WAVES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_VALU SQ_INSTS_VALU SQ_INSTS_VMEM SQ_INSTS_LDS -- --steps 40 --warmup 5 --substeps 1
 python tools/pmc_summary.py $OUT/pmc_fetch_1us $OUT/pmc_write_1us > $S/rocprofv3_pmc_hbm_config3_1us.txt
 python tools/pmc_summary.py $OUT/pmc_sq_1us > $S/rocprofv3_pmc_sq_config3_1us.txt
+echo "[profile] recorded counter tables -> profiles/traffic.json, profiles/valu.json (bench.py reads them)"; date +%T
+python tools/make_traffic_json.py $S profiles/$R
+cp profiles/traffic.json profiles/valu.json $S/
+
+echo "[profile] bench lines, final pass (roofline objects use the counters just recorded)"; date +%T
+bench_lines ""
+WEDM_BENCH_FORCE_DIST=1 MASTER_ADDR=127.0.0.1 MASTER_PORT=29533 RANK=0 WORLD_SIZE=1 LOCAL_RANK=0 \
+    python bench.py --steps 10 --warmup 2 --no-cpu-baseline --no-side > $S/bench_config3_rccl_world1.json 2>/dev/null
+
+echo "[profile] rocprofv3 kernel trace"; date +%T
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/kt -o kt -- python3 bench.py --steps 20 --warmup 2 --no-cpu-baseline --no-side > $OUT/kt.log 2>&1
+cp $(find $OUT/kt -name "*kernel_stats.csv" | head -1) $S/rocprofv3_kernel_stats_config3.csv
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/kt1 -o kt -- python3 bench.py --steps 400 --warmup 50 --substeps 1 --no-cpu-baseline --no-side > $OUT/kt1.log 2>&1
+cp $(find $OUT/kt1 -name "*kernel_stats.csv" | head -1) $S/rocprofv3_kernel_stats_config3_1us.csv
+
 echo "[profile] done"; date +%T
 ls -la $S
