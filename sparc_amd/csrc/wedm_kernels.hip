@@ -75,6 +75,12 @@ struct WalkTable {
     uint32_t chunk_flags[16][4];
     uint32_t kind_n_mask, kind_s_mask;
     uint32_t split_pack[3];
+    // tiles that can ALSO take the regular (TILE_N) code: kind_ne_mask = full tiles with one flag set whose only
+    // non-interior cells are the wire's end cells (cell 0 = first cell of chunk 0's tile 0, cell n-1 = last cell of the
+    // last chunk's last tile: computed by the interior formula like the rest, kept out of the maximum, patched after
+    // the walk like every boundary cell); kind_nj_mask = the same where only the between-the-contacts flag changes inside
+    // the tile, which matters only in a microsecond in which some lane of the wave carries current.
+    uint32_t kind_ne_mask, kind_nj_mask;
     uint32_t pad0;
 };
 // TILE_N: 8 interior cells, one flag set.  TILE_B: every cell takes the interior formula with at
@@ -738,6 +744,8 @@ __global__ void __launch_bounds__(256, 2) wedm_step_fused(const KArgs k) {
     }
     kind_n = __builtin_amdgcn_readfirstlane(kind_n);
     kind_s = __builtin_amdgcn_readfirstlane(kind_s);
+    // tiles that take the regular code although they hold a wire end cell / a contact-flag change (see WalkTable)
+    const uint32_t kind_ne = __builtin_amdgcn_readfirstlane(wt->kind_ne_mask), kind_nj = __builtin_amdgcn_readfirstlane(wt->kind_nj_mask);
 #pragma unroll
     for (int q = 0; q < 3; ++q) split_pack[q] = __builtin_amdgcn_readfirstlane(split_pack[q]);
     if (c == 0) col[0] = spool;  // wire cell 0 is held at the spool temperature (wire.py:83)
@@ -766,6 +774,8 @@ __global__ void __launch_bounds__(256, 2) wedm_step_fused(const KArgs k) {
         // predicated path; results are identical, only slower
         const bool all_slow = __any(cf.q < 0.0f) || __any(s.done);
         const uint32_t slow_now = all_slow ? 0xffffffffu : kind_s;
+        // regular tiles of THIS microsecond: a contact-flag change inside a tile only matters while current flows
+        const uint32_t n_now = (kind_n | kind_ne | (__any(cf.joule_on && !s.done && cf.jf != 0.0f) ? 0u : kind_nj)) & ~(all_slow ? 0xffffffffu : 0u);
 
         // ---- patched cells: the plasma cell and the wire's last cell are computed with the
         // full predicated formula from OLD values now and written after the walk
@@ -818,9 +828,9 @@ __global__ void __launch_bounds__(256, 2) wedm_step_fused(const KArgs k) {
                 const float jfe_lo = ((joule_lo >> t) & 1u) ? jf_lane : 0.0f;
 #ifdef WEDM_STAMPS_TILES
                 WEDM_STAMP(tk0);
-                const int tkind = (((kind_n & ~slow_now) >> t) & 1u) ? 0 : (!((slow_now >> t) & 1u) ? 1 : 2);
+                const int tkind = ((n_now >> t) & 1u) ? 0 : (!((slow_now >> t) & 1u) ? 1 : 2);
 #endif
-                if (((kind_n & ~slow_now) >> t) & 1u) {
+                if ((n_now >> t) & 1u) {
                     float old[10], tn[8], cv[8], jv[8];
                     old[0] = tm1; old[1] = tc;
 #pragma unroll
@@ -830,11 +840,15 @@ __global__ void __launch_bounds__(256, 2) wedm_step_fused(const KArgs k) {
                         tile8_staged<float, true, false>(old, tn, g.k, g.tuf, cv, tdiel, ps.adv, jv, alpha, tref);
                     else
                         tile8_staged<float, false, false>(old, tn, g.k, g.tuf, cv, tdiel, ps.adv, jv, alpha, tref);
+                    // the wire's end cells, where a regular tile holds one (kind_ne / kind_nj): cell 0 stays at the spool
+                    // temperature; the last cell is kept out of the maximum here and patched after the walk
+                    tn[0] = (c == 0 && t == 0) ? spool : tn[0];
+                    const float last_v = (owns_last && t == n_tiles - 1) ? spool : tn[7];
 #pragma unroll
                     for (int u = 0; u < 8; ++u) col[(j + u) * 256] = tn[u];
                     float m0 = fmax_gt(tn[0], tn[1]), m1 = fmax_gt(tn[2], tn[3]);
                     m0 = fmax_gt(m0, fmax_gt(tn[4], tn[5]));
-                    m1 = fmax_gt(m1, fmax_gt(tn[6], tn[7]));
+                    m1 = fmax_gt(m1, fmax_gt(tn[6], last_v));
                     tmax = fmax_gt(tmax, fmax_gt(m0, m1));
                     tm1 = cur[6];
                     tc = cur[7];
@@ -1048,6 +1062,8 @@ __global__ void __launch_bounds__(256, 2) wedm_step_stream(const KArgs k) {
     const float spool = k.hot.spool, tref = k.hot.tref, alpha = k.hot.alpha, tdiel = k.hot.tdiel;
     const int n_tiles = wt->n_tiles;
     const uint32_t kind_n = __builtin_amdgcn_readfirstlane(wt->kind_n_mask), kind_s = __builtin_amdgcn_readfirstlane(wt->kind_s_mask);
+    // tiles that take the regular code although they hold a wire end cell / a contact-flag change (see WalkTable)
+    const uint32_t kind_ne = __builtin_amdgcn_readfirstlane(wt->kind_ne_mask), kind_nj = __builtin_amdgcn_readfirstlane(wt->kind_nj_mask);
     uint32_t split_pack[3];  // 4 bits per tile (WEDM_MAX_TILES <= 24)
 #pragma unroll
     for (int q = 0; q < 3; ++q) split_pack[q] = __builtin_amdgcn_readfirstlane(wt->split_pack[q]);
@@ -1083,6 +1099,8 @@ __global__ void __launch_bounds__(256, 2) wedm_step_stream(const KArgs k) {
         // predicated path; results are identical, only slower
         const bool all_slow = __any(cf.q < 0.0f) || __any(s.done);
         const uint32_t slow_now = all_slow ? 0xffffffffu : kind_s;
+        // regular tiles of THIS microsecond: a contact-flag change inside a tile only matters while current flows
+        const uint32_t n_now = (kind_n | kind_ne | (__any(cf.joule_on && !s.done && cf.jf != 0.0f) ? 0u : kind_nj)) & ~(all_slow ? 0xffffffffu : 0u);
 
         // ---- patched cells: the plasma cell and the wire's last cell are computed with the
         // full predicated formula from OLD values now and written after the walk
@@ -1128,7 +1146,7 @@ __global__ void __launch_bounds__(256, 2) wedm_step_stream(const KArgs k) {
                 load8(std::true_type{}, cur, j);  // (an unclamped variant for full tiles pays in the packed kernel only)
                 const float conv_lo = ((zone_lo >> t) & 1u) ? ps.conv_zone : ps.conv_base;
                 const float jfe_lo = ((joule_lo >> t) & 1u) ? jf_lane : 0.0f;
-                if (((kind_n & ~slow_now) >> t) & 1u) {
+                if ((n_now >> t) & 1u) {
                     float old[10], tn[8], cv[8], jv[8];
                     old[0] = tm1; old[1] = tc;
 #pragma unroll
@@ -1138,6 +1156,10 @@ __global__ void __launch_bounds__(256, 2) wedm_step_stream(const KArgs k) {
                         tile8_staged<float, true, false>(old, tn, g.k, g.tuf, cv, tdiel, ps.adv, jv, alpha, tref);
                     else
                         tile8_staged<float, false, false>(old, tn, g.k, g.tuf, cv, tdiel, ps.adv, jv, alpha, tref);
+                    // the wire's end cells, where a regular tile holds one (kind_ne / kind_nj): cell 0 stays at the spool
+                    // temperature; the last cell is kept out of the maximum here and patched after the walk
+                    tn[0] = (c == 0 && t == 0) ? spool : tn[0];
+                    const float last_v = (owns_last && t == n_tiles - 1) ? spool : tn[7];
 #pragma unroll
                     for (int u = 0; u < 8; ++u) col[(j + u) * 256] = tn[u];
                     if (last) {  // the launch's last microsecond: the tile also goes straight to global memory
@@ -1149,7 +1171,7 @@ __global__ void __launch_bounds__(256, 2) wedm_step_stream(const KArgs k) {
                     }
                     float m0 = fmax_gt(tn[0], tn[1]), m1 = fmax_gt(tn[2], tn[3]);
                     m0 = fmax_gt(m0, fmax_gt(tn[4], tn[5]));
-                    m1 = fmax_gt(m1, fmax_gt(tn[6], tn[7]));
+                    m1 = fmax_gt(m1, fmax_gt(tn[6], last_v));
                     tmax = fmax_gt(tmax, fmax_gt(m0, m1));
                     tm1 = cur[6];
                     tc = cur[7];
@@ -1404,6 +1426,8 @@ __global__ void __launch_bounds__(256, 2) wedm_step_packed(const KArgs k) {
     }
     kind_n = __builtin_amdgcn_readfirstlane(kind_n);
     kind_s = __builtin_amdgcn_readfirstlane(kind_s);
+    // tiles that take the regular code although they hold a wire end cell / a contact-flag change (see WalkTable)
+    const uint32_t kind_ne = __builtin_amdgcn_readfirstlane(wt->kind_ne_mask), kind_nj = __builtin_amdgcn_readfirstlane(wt->kind_nj_mask);
 #pragma unroll
     for (int q = 0; q < 3; ++q) split_pack[q] = __builtin_amdgcn_readfirstlane(split_pack[q]);
     if (c == 0) col[0] = spool;  // wire cell 0 (row 0 of lane 0's chunk A) is held at the spool temperature
@@ -1442,6 +1466,8 @@ __global__ void __launch_bounds__(256, 2) wedm_step_packed(const KArgs k) {
 
         const bool all_slow = __any(cf.q < 0.0f) || __any(s.done);
         const uint32_t slow_now = all_slow ? 0xffffffffu : kind_s;
+        // regular tiles of THIS microsecond: a contact-flag change inside a tile only matters while current flows
+        const uint32_t n_now = (kind_n | kind_ne | (__any(cf.joule_on && !s.done && cf.jf != 0.0f) ? 0u : kind_nj)) & ~(all_slow ? 0xffffffffu : 0u);
 
         // full predicated formula for one owned cell, from OLD values (patched cells)
         auto patch_value = [&](int i, int own) -> float {
@@ -1501,7 +1527,7 @@ __global__ void __launch_bounds__(256, 2) wedm_step_packed(const KArgs k) {
                 else load8(std::true_type{}, cur, r0);
                 const f2 conv_lo = {((zlA >> t) & 1u) ? cz : cb, ((zlB >> t) & 1u) ? cz : cb};
                 const f2 jfe_lo = {((jlA >> t) & 1u) ? jf_lane : 0.0f, ((jlB >> t) & 1u) ? jf_lane : 0.0f};
-                if (((kind_n & ~slow_now) >> t) & 1u) {
+                if ((n_now >> t) & 1u) {
                     f2 old[10], tn[8], cv[8], jv[8];
                     old[0] = tm1; old[1] = tc;
 #pragma unroll
@@ -1511,14 +1537,21 @@ __global__ void __launch_bounds__(256, 2) wedm_step_packed(const KArgs k) {
                         tile8_staged<f2, true, false>(old, tn, g.k, g.tuf, cv, tdiel, ps.adv, jv, alpha, tref);
                     else
                         tile8_staged<f2, false, false>(old, tn, g.k, g.tuf, cv, tdiel, ps.adv, jv, alpha, tref);
+                    // the wire's end cells, where a regular tile holds one (kind_ne / kind_nj): cell 0 is the first cell
+                    // of lane 0's chunk A and stays at the spool temperature; the last cell is the last cell of the last
+                    // lane's chunk B: out of the maximum here, patched after the walk
+                    tn[0].x = (c == 0 && t == 0) ? spool : tn[0].x;
+                    const float last_y = (own_last == 2 && t == n_tiles - 1) ? spool : tn[7].y;
                     float m0 = fmax_gt(tn[0].x, tn[0].y), m1 = fmax_gt(tn[1].x, tn[1].y);
 #pragma unroll
                     for (int u = 0; u < 8; ++u) store2(r0 + u, tn[u]);
 #pragma unroll
-                    for (int u = 2; u < 8; u += 2) {
+                    for (int u = 2; u < 6; u += 2) {
                         m0 = fmax_gt(m0, fmax_gt(tn[u].x, tn[u].y));
                         m1 = fmax_gt(m1, fmax_gt(tn[u + 1].x, tn[u + 1].y));
                     }
+                    m0 = fmax_gt(m0, fmax_gt(tn[6].x, tn[6].y));
+                    m1 = fmax_gt(m1, fmax_gt(tn[7].x, last_y));
                     tmax = fmax_gt(tmax, fmax_gt(m0, m1));
                     tm1 = cur[6];
                     tc = cur[7];
@@ -1792,6 +1825,24 @@ static bool build_walk(const wedm_params& p, int L, WalkTable& t) {
             if ((t.iv[j] & 0xffffu) != all) all_interior = false;
             if (j > j0 && t.zj[j] != t.zj[j - 1]) { ++changes; split = j - j0; }
         }
+        // regular apart from the wire's two end cells / apart from the contact flag?
+        bool ends_only = (j1 - j0 == 8);
+        int zone_changes = 0;
+        for (int j = j0; j < j1; ++j) {
+            uint16_t ends = 0;
+            for (int c = 0; c < L; ++c) {
+                const int i = c * C + j;
+                if (i == 0 || i == n - 1) ends |= (uint16_t)(1u << c);
+            }
+            if ((t.iv[j] >> 16) != all) ends_only = false;                          // a cell past the wire's end
+            if ((uint16_t)((t.iv[j] & 0xffffu) | ends) != all) ends_only = false;   // non-interior and not an end cell
+            if (j > j0 && (t.zj[j] & 0xffffu) != (t.zj[j - 1] & 0xffffu)) ++zone_changes;
+        }
+        // (an end cell inside a full tile sits at its first / last position: cell 0 is j = 0 of chunk 0, and cell n-1
+        // can only be followed by cells past the wire's end, which a tile with ends_only does not have)
+        if (n < 2) ends_only = false;
+        if (ends_only && !all_interior && changes == 0) t.kind_ne_mask |= 1u << tile;
+        if (ends_only && zone_changes == 0 && changes > 0) t.kind_nj_mask |= 1u << tile;
         // cells past the chunk keep the last real cell's flags so that zj[8t+7] is the tile's "hi" set
         for (int j = j1; j < j0 + 8; ++j) t.zj[j] = t.zj[j1 - 1];
         t.split[tile] = (uint32_t)split;
