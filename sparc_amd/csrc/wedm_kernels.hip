@@ -672,7 +672,8 @@ __device__ __forceinline__ void tile8_staged(const V (&old)[10], V (&tn)[8], flo
         tile_staged<V, JOULE, PERCELL, W>(old, tn, o, k, tuf, conv, tdiel, adv, jfe, alpha, tref);
 }
 
-template <int L, bool TRACE>
+// FROZEN_OK: see wedm_step_packed
+template <int L, bool TRACE, bool FROZEN_OK = false>
 __global__ void __launch_bounds__(256, 2) wedm_step_fused(const KArgs k) {
     const ColdRef cold = kernarg_cold();
     Hot hv = k.hot;
@@ -770,9 +771,10 @@ __global__ void __launch_bounds__(256, 2) wedm_step_fused(const KArgs k) {
         const float halo_r = (c < L - 1) ? col[1] : 0.0f;
         col[C * 256] = halo_r;
 
-        // a wave with a frozen environment (or a negative plasma heat) walks every cell on the
+        // a wave with a negative plasma heat (or, without FROZEN_OK, with a frozen environment) walks every cell on the
         // predicated path; results are identical, only slower
-        const bool all_slow = __any(cf.q < 0.0f) || __any(s.done);
+        const bool frozen_wave = FROZEN_OK && __any(s.done);
+        const bool all_slow = __any(cf.q < 0.0f) || (!FROZEN_OK && __any(s.done));
         const uint32_t slow_now = all_slow ? 0xffffffffu : kind_s;
         // regular tiles of THIS microsecond: a contact-flag change inside a tile only matters while current flows
         const uint32_t n_now = (kind_n | kind_ne | (__any(cf.joule_on && !s.done && cf.jf != 0.0f) ? 0u : kind_nj)) & ~(all_slow ? 0xffffffffu : 0u);
@@ -820,7 +822,8 @@ __global__ void __launch_bounds__(256, 2) wedm_step_fused(const KArgs k) {
                     dst[u] = col[row * 256];
                 }
             };
-            auto tile = [&](int t, float (&cur)[8], float (&nxt)[8]) {
+            auto tile = [&](auto frozen, int t, float (&cur)[8], float (&nxt)[8]) {
+                constexpr bool FROZEN = decltype(frozen)::value;  // the copy for a wave with frozen lanes: they do not store
                 const int j = 8 * t;
                 (void)nxt;
                 load8(std::true_type{}, cur, j);  // (an unclamped variant for full tiles pays in the packed kernel only)
@@ -844,8 +847,10 @@ __global__ void __launch_bounds__(256, 2) wedm_step_fused(const KArgs k) {
                     // temperature; the last cell is kept out of the maximum here and patched after the walk
                     tn[0] = (c == 0 && t == 0) ? spool : tn[0];
                     const float last_v = (owns_last && t == n_tiles - 1) ? spool : tn[7];
+                    if (!FROZEN || !s.done) {
 #pragma unroll
-                    for (int u = 0; u < 8; ++u) col[(j + u) * 256] = tn[u];
+                        for (int u = 0; u < 8; ++u) col[(j + u) * 256] = tn[u];
+                    }
                     float m0 = fmax_gt(tn[0], tn[1]), m1 = fmax_gt(tn[2], tn[3]);
                     m0 = fmax_gt(m0, fmax_gt(tn[4], tn[5]));
                     m1 = fmax_gt(m1, fmax_gt(tn[6], last_v));
@@ -867,7 +872,7 @@ __global__ void __launch_bounds__(256, 2) wedm_step_fused(const KArgs k) {
                             const float conv = u < split ? conv_lo : conv_hi;
                             const float jfe = u < split ? jfe_lo : jfe_hi;
                             float tn = interior_cell<true>(tm1, tc, cur[u], g.k, g.tuf, conv, tdiel, ps.adv, jfe, alpha, tref);
-                            col[(j + u) * 256] = tn;
+                            if (!FROZEN || !s.done) col[(j + u) * 256] = tn;
                             const bool inter = (n >= 3) && (im1 + (uint32_t)u <= span);
                             tmax = inter ? fmax_gt(tmax, tn) : tmax;
                             tm1 = tc;
@@ -911,7 +916,11 @@ __global__ void __launch_bounds__(256, 2) wedm_step_fused(const KArgs k) {
 #endif
             };
             float bufA[8];
-            for (int t = 0; t < n_tiles; ++t) tile(t, bufA, bufA);
+            if (!FROZEN_OK || !frozen_wave) {
+                for (int t = 0; t < n_tiles; ++t) tile(std::false_type{}, t, bufA, bufA);
+            } else {
+                for (int t = 0; t < n_tiles; ++t) tile(std::true_type{}, t, bufA, bufA);
+            }
         }
         WEDM_STAMP(st2);
         // ---- patches (after every store of the walk): boundary condition, last cell, plasma cell
@@ -1352,7 +1361,12 @@ __device__ __forceinline__ f2 interior2(f2 tm1, f2 tc, f2 tp1, float k, float tu
     return tc + d * tuf;
 }
 
-template <int L, bool TRACE>
+// FROZEN_OK: the instantiation for handles with in-launch autoreset, i.e. batches in which environments terminate at
+// different times and wait, frozen, for the next launch.  Without it a wave with a frozen lane walks every cell on the
+// predicated path (~4 x slower: 3.65e9 instead of 1.36e10 env-steps/s on a batch that resets 17 % of its environments per
+// launch); with it such a wave takes a second copy of the tile code in which the frozen lanes do not store.  A separate
+// instantiation, because the mere presence of that copy costs the other waves 2 % (6 % when folded into one copy).
+template <int L, bool TRACE, bool FROZEN_OK = false>
 __global__ void __launch_bounds__(256, 2) wedm_step_packed(const KArgs k) {
     const ColdRef cold = kernarg_cold();
     Hot hv = k.hot;
@@ -1464,7 +1478,10 @@ __global__ void __launch_bounds__(256, 2) wedm_step_packed(const KArgs k) {
         col[R * 256] = b_first;
         col[(R + 1) * 256] = halo_r;
 
-        const bool all_slow = __any(cf.q < 0.0f) || __any(s.done);
+        // a wave with a negative plasma heat (or, without FROZEN_OK, with a frozen environment) walks every cell on the
+        // predicated path; results are identical, only slower
+        const bool frozen_wave = FROZEN_OK && __any(s.done);
+        const bool all_slow = __any(cf.q < 0.0f) || (!FROZEN_OK && __any(s.done));
         const uint32_t slow_now = all_slow ? 0xffffffffu : kind_s;
         // regular tiles of THIS microsecond: a contact-flag change inside a tile only matters while current flows
         const uint32_t n_now = (kind_n | kind_ne | (__any(cf.joule_on && !s.done && cf.jf != 0.0f) ? 0u : kind_nj)) & ~(all_slow ? 0xffffffffu : 0u);
@@ -1516,7 +1533,8 @@ __global__ void __launch_bounds__(256, 2) wedm_step_packed(const KArgs k) {
                 col[(2 * r) * 256] = v.x;
                 col[(2 * r + 1) * 256] = v.y;
             };
-            auto tile = [&](int t, f2 (&cur)[8], f2 (&nxt)[8]) {
+            auto tile = [&](auto frozen, int t, f2 (&cur)[8], f2 (&nxt)[8]) {
+                constexpr bool FROZEN = decltype(frozen)::value;  // the copy for a wave with frozen lanes: they do not store
                 const int r0 = 8 * t;
                 // One buffer only: the tile's eight "next" pairs are loaded at the tile's start.  A
                 // second (prefetch) buffer cost 16 VGPRs, pushed the kernel into scratch spills
@@ -1543,8 +1561,10 @@ __global__ void __launch_bounds__(256, 2) wedm_step_packed(const KArgs k) {
                     tn[0].x = (c == 0 && t == 0) ? spool : tn[0].x;
                     const float last_y = (own_last == 2 && t == n_tiles - 1) ? spool : tn[7].y;
                     float m0 = fmax_gt(tn[0].x, tn[0].y), m1 = fmax_gt(tn[1].x, tn[1].y);
+                    if (!FROZEN || !s.done) {
 #pragma unroll
-                    for (int u = 0; u < 8; ++u) store2(r0 + u, tn[u]);
+                        for (int u = 0; u < 8; ++u) store2(r0 + u, tn[u]);
+                    }
 #pragma unroll
                     for (int u = 2; u < 6; u += 2) {
                         m0 = fmax_gt(m0, fmax_gt(tn[u].x, tn[u].y));
@@ -1577,7 +1597,7 @@ __global__ void __launch_bounds__(256, 2) wedm_step_packed(const KArgs k) {
 #pragma unroll
                     for (int u = 0; u < 8; ++u) {
                         if (u < cnt) {
-                            store2(r0 + u, tn[u]);
+                            if (!FROZEN || !s.done) store2(r0 + u, tn[u]);
                             const bool inA = (n >= 3) && (imA + (uint32_t)u <= span);
                             const bool inB = (n >= 3) && (imB + (uint32_t)u <= span);
                             tmax = inA ? fmax_gt(tmax, tn[u].x) : tmax;
@@ -1625,7 +1645,11 @@ __global__ void __launch_bounds__(256, 2) wedm_step_packed(const KArgs k) {
                 }
             };
             f2 bufA[8];
-            for (int t = 0; t < n_tiles; ++t) tile(t, bufA, bufA);
+            if (!FROZEN_OK || !frozen_wave) {
+                for (int t = 0; t < n_tiles; ++t) tile(std::false_type{}, t, bufA, bufA);
+            } else {
+                for (int t = 0; t < n_tiles; ++t) tile(std::true_type{}, t, bufA, bufA);
+            }
         }
         WEDM_STAMP(st2);
         // ---- patches (after every store of the walk): boundary condition, last cell, plasma cell
@@ -1874,13 +1898,13 @@ template <bool TR, bool F64> static const void* pick_lanes(int L) {
         default: return (const void*)wedm_step_lanes<16, TR, F64>;
     }
 }
-template <bool TR> static const void* pick_fused(int L) {
+template <bool TR, bool FZ> static const void* pick_fused(int L) {
     switch (L) {
-        case 1: return (const void*)wedm_step_fused<1, TR>;
-        case 2: return (const void*)wedm_step_fused<2, TR>;
-        case 4: return (const void*)wedm_step_fused<4, TR>;
-        case 8: return (const void*)wedm_step_fused<8, TR>;
-        default: return (const void*)wedm_step_fused<16, TR>;
+        case 1: return (const void*)wedm_step_fused<1, TR, FZ>;
+        case 2: return (const void*)wedm_step_fused<2, TR, FZ>;
+        case 4: return (const void*)wedm_step_fused<4, TR, FZ>;
+        case 8: return (const void*)wedm_step_fused<8, TR, FZ>;
+        default: return (const void*)wedm_step_fused<16, TR, FZ>;
     }
 }
 // rows a lane of the stream kernel holds in registers: 64 (128 segments over 2 lanes, 400 over 8) or 104 (400 over 4)
@@ -1893,12 +1917,12 @@ template <bool TR, int CMAX> static const void* pick_stream(int L) {
         default: return (const void*)wedm_step_stream<16, TR, CMAX>;
     }
 }
-template <bool TR> static const void* pick_packed(int L) {
+template <bool TR, bool FZ> static const void* pick_packed(int L) {
     switch (L) {
-        case 1: return (const void*)wedm_step_packed<1, TR>;
-        case 2: return (const void*)wedm_step_packed<2, TR>;
-        case 4: return (const void*)wedm_step_packed<4, TR>;
-        default: return (const void*)wedm_step_packed<8, TR>;
+        case 1: return (const void*)wedm_step_packed<1, TR, FZ>;
+        case 2: return (const void*)wedm_step_packed<2, TR, FZ>;
+        case 4: return (const void*)wedm_step_packed<4, TR, FZ>;
+        default: return (const void*)wedm_step_packed<8, TR, FZ>;
     }
 }
 
@@ -2063,13 +2087,16 @@ static int32_t plan_launch(wedm_ctx* ctx, bool single, bool tr, LaunchPlan& out)
         grid = (ctx->num_envs + 256 / planes - 1) / (256 / planes);
         fl = (2 * (size_t)ctx->walk_C[pli] + 2) * 1024;
         out.walk = ctx->walk_dev + pli;
-        fn = tr ? pick_packed<true>(planes) : pick_packed<false>(planes);
+        // handles with in-launch autoreset expect terminations: the instantiation that tolerates frozen lanes
+        fn = P.autoreset ? (tr ? pick_packed<true, true>(planes) : pick_packed<false, true>(planes))
+                         : (tr ? pick_packed<true, false>(planes) : pick_packed<false, false>(planes));
         std::snprintf(out.name, sizeof(out.name), "wedm_step_packed<%d><<<%d,256,%zuB>>>", planes, grid, fl);
     } else {
         grid = (ctx->num_envs + 256 / lanes - 1) / (256 / lanes);
         fl = ((size_t)ctx->walk_C[li] + 1) * 1024;
         out.walk = ctx->walk_dev + li;
-        fn = tr ? pick_fused<true>(lanes) : pick_fused<false>(lanes);
+        fn = P.autoreset ? (tr ? pick_fused<true, true>(lanes) : pick_fused<false, true>(lanes))
+                         : (tr ? pick_fused<true, false>(lanes) : pick_fused<false, false>(lanes));
         std::snprintf(out.name, sizeof(out.name), "wedm_step_fused<%d><<<%d,256,%zuB>>>", lanes, grid, fl);
     }
     if (fl) {
