@@ -225,11 +225,12 @@ def time_launches(env, act, n_sub, steps, warmup):
 
 
 def side_measurements(n_local, wire, S, device):
-    """Three side measurements of the same build at the bench batch (single GPU only):
+    """Four side measurements of the same build at the bench batch (single GPU only):
       * the reference's own cadence, one launch per microsecond (wedm_step(n_substeps=1));
       * a densely sparking start (15 um gap: ~5.6 sparks per environment per ms instead of ~0.7);
       * the closed loop of experiments/run_simulation.py with ITS PI voltage controller evaluated on the device
-        from the kernel-side running voltage sum (steady state after a 100 ms approach)."""
+        from the kernel-side running voltage sum (steady state after a 100 ms approach);
+      * a batch with in-launch autoreset whose environments keep terminating at different times."""
     import torch
 
     from sparc_amd import VoltageController, WireEDMEnv, run_controlled
@@ -269,6 +270,28 @@ def side_measurements(n_local, wire, S, device):
                 "ms_per_control_interval": dt / 10 * 1e3, "mean_gap_um": gap,
                 "sparks_per_env_per_ms": (int(env.state.spark_count.sum().item()) - s0) / n_local / 10.0,
                 "timing": "wall clock around 10 control intervals incl. the controller's torch ops"})
+    env.close()
+    # a training-style batch: in-launch autoreset and a cutting target a few sparks ahead, so that in steady state a sixth
+    # of the environments terminates in every launch and waits, frozen, for the next launch's re-initialisation
+    from sparc_amd import EnvironmentConfig
+
+    env = WireEDMEnv(num_envs=n_local, device=device, wire_params=wire, autoreset=True, reward="progress",
+                     config=EnvironmentConfig(target_cutting_distance=50.002))
+    env.reset(seed=7)
+    act = env.make_action(0.1, 80.0, 5, 3.0, 80.0)
+    for _ in range(20):
+        env.step_many(act, 1000)
+    torch.cuda.synchronize()
+    e0 = int(env.state.episode.sum().item())
+    t0 = time.perf_counter()
+    for _ in range(20):
+        env.step_many(act, 1000)
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    out.append({"name": "autoreset batch: environments terminate at different times (cutting target 0.002 um ahead)",
+                "value": n_local * 20 * 1000 / dt, "unit": "env-steps/s", "kernel": env._backend.last_kernel(),
+                "resets_per_env_per_launch": (int(env.state.episode.sum().item()) - e0) / n_local / 20.0,
+                "timing": "wall clock around 20 launches of 1000 us"})
     env.close()
     return out
 
