@@ -81,7 +81,10 @@ struct WalkTable {
     // the walk like every boundary cell); kind_nj_mask = the same where only the between-the-contacts flag changes inside
     // the tile, which matters only in a microsecond in which some lane of the wave carries current.
     uint32_t kind_ne_mask, kind_nj_mask;
-    uint32_t pad0;
+    // kind_n1_mask: full tiles, end cells apart all interior, with exactly ONE flag change (bit 31: at least one of them
+    // changes the ZONE flag, i.e. is a boundary tile in every microsecond): the N1 instantiation of wedm_step_fused runs
+    // them stage-major with per-cell coefficients, without a boundary tile's predicated stores and maxima
+    uint32_t kind_n1_mask;
 };
 // TILE_N: 8 interior cells, one flag set.  TILE_B: every cell takes the interior formula with at
 // most one flag change inside the tile; boundary cells (wire cell 0, the last cell, cells past
@@ -672,8 +675,10 @@ __device__ __forceinline__ void tile8_staged(const V (&old)[10], V (&tn)[8], flo
         tile_staged<V, JOULE, PERCELL, W>(old, tn, o, k, tuf, conv, tdiel, adv, jfe, alpha, tref);
 }
 
-// FROZEN_OK: see wedm_step_packed
-template <int L, bool TRACE, bool FROZEN_OK = false>
+// FROZEN_OK: see wedm_step_packed.  N1: the instantiation for tile tables with a one-change tile that is a boundary tile in
+// every microsecond (4 096 x 400 over 16 lanes: the end of the workpiece zone falls inside tile 2 of 4): +4.7 % there; the
+// extra code costs tables without such a tile 1-1.5 %, so they run the instantiation without it.
+template <int L, bool TRACE, bool FROZEN_OK = false, bool N1 = false>
 __global__ void __launch_bounds__(256, 2) wedm_step_fused(const KArgs k) {
     const ColdRef cold = kernarg_cold();
     Hot hv = k.hot;
@@ -747,6 +752,7 @@ __global__ void __launch_bounds__(256, 2) wedm_step_fused(const KArgs k) {
     kind_s = __builtin_amdgcn_readfirstlane(kind_s);
     // tiles that take the regular code although they hold a wire end cell / a contact-flag change (see WalkTable)
     const uint32_t kind_ne = __builtin_amdgcn_readfirstlane(wt->kind_ne_mask), kind_nj = __builtin_amdgcn_readfirstlane(wt->kind_nj_mask);
+    const uint32_t kind_n1 = N1 ? (__builtin_amdgcn_readfirstlane(wt->kind_n1_mask) & 0x7fffffffu) : 0u;
 #pragma unroll
     for (int q = 0; q < 3; ++q) split_pack[q] = __builtin_amdgcn_readfirstlane(split_pack[q]);
     if (c == 0) col[0] = spool;  // wire cell 0 is held at the spool temperature (wire.py:83)
@@ -845,6 +851,34 @@ __global__ void __launch_bounds__(256, 2) wedm_step_fused(const KArgs k) {
                         tile8_staged<float, false, false>(old, tn, g.k, g.tuf, cv, tdiel, ps.adv, jv, alpha, tref);
                     // the wire's end cells, where a regular tile holds one (kind_ne / kind_nj): cell 0 stays at the spool
                     // temperature; the last cell is kept out of the maximum here and patched after the walk
+                    tn[0] = (c == 0 && t == 0) ? spool : tn[0];
+                    const float last_v = (owns_last && t == n_tiles - 1) ? spool : tn[7];
+                    if (!FROZEN || !s.done) {
+#pragma unroll
+                        for (int u = 0; u < 8; ++u) col[(j + u) * 256] = tn[u];
+                    }
+                    float m0 = fmax_gt(tn[0], tn[1]), m1 = fmax_gt(tn[2], tn[3]);
+                    m0 = fmax_gt(m0, fmax_gt(tn[4], tn[5]));
+                    m1 = fmax_gt(m1, fmax_gt(tn[6], last_v));
+                    tmax = fmax_gt(tmax, fmax_gt(m0, m1));
+                    tm1 = cur[6];
+                    tc = cur[7];
+                } else if (N1 && (((kind_n1 & ~slow_now) >> t) & 1u)) {
+                    // one flag change at `split`, nothing else irregular (end cells apart): stage-major with per-cell
+                    // coefficients, stores and maximum as in a regular tile
+                    const int split = (int)((split_pack[t >> 3] >> ((t & 7) * 4)) & 15u);
+                    const float conv_hi = ((zone_hi >> t) & 1u) ? ps.conv_zone : ps.conv_base;
+                    const float jfe_hi = ((joule_hi >> t) & 1u) ? jf_lane : 0.0f;
+                    float old[10], tn[8], cv[8], jv[8];
+                    old[0] = tm1; old[1] = tc;
+#pragma unroll
+                    for (int u = 0; u < 8; ++u) {
+                        old[u + 2] = cur[u];
+                        cv[u] = u < split ? conv_lo : conv_hi;
+                        jv[u] = u < split ? jfe_lo : jfe_hi;
+                    }
+                    if (joule_wave) tile8_staged<float, true, true>(old, tn, g.k, g.tuf, cv, tdiel, ps.adv, jv, alpha, tref);
+                    else tile8_staged<float, false, true>(old, tn, g.k, g.tuf, cv, tdiel, ps.adv, jv, alpha, tref);
                     tn[0] = (c == 0 && t == 0) ? spool : tn[0];
                     const float last_v = (owns_last && t == n_tiles - 1) ? spool : tn[7];
                     if (!FROZEN || !s.done) {
@@ -1794,6 +1828,7 @@ struct wedm_ctx {
     WalkTable* walk_dev = nullptr;     // [5] tables for L = 1, 2, 4, 8, 16
     bool walk_ok[5] = {false, false, false, false, false};
     int32_t walk_C[5] = {0, 0, 0, 0, 0};
+    uint32_t walk_n1z = 0;             // bit i: table i has a one-change tile with a zone change (see WalkTable::kind_n1_mask)
     // signal trace (wedm_bind_trace): descriptor, microseconds stepped and samples written since the bind
     const double* replay = nullptr;    // wedm_bind_rng_replay
     int64_t replay_steps = 0;
@@ -1867,6 +1902,7 @@ static bool build_walk(const wedm_params& p, int L, WalkTable& t) {
         if (n < 2) ends_only = false;
         if (ends_only && !all_interior && changes == 0) t.kind_ne_mask |= 1u << tile;
         if (ends_only && zone_changes == 0 && changes > 0) t.kind_nj_mask |= 1u << tile;
+        if (ends_only && changes == 1) t.kind_n1_mask |= (1u << tile) | (zone_changes == 1 ? 0x80000000u : 0u);
         // cells past the chunk keep the last real cell's flags so that zj[8t+7] is the tile's "hi" set
         for (int j = j1; j < j0 + 8; ++j) t.zj[j] = t.zj[j1 - 1];
         t.split[tile] = (uint32_t)split;
@@ -1898,14 +1934,17 @@ template <bool TR, bool F64> static const void* pick_lanes(int L) {
         default: return (const void*)wedm_step_lanes<16, TR, F64>;
     }
 }
-template <bool TR, bool FZ> static const void* pick_fused(int L) {
+template <bool TR, bool FZ, bool N1> static const void* pick_fused(int L) {
     switch (L) {
-        case 1: return (const void*)wedm_step_fused<1, TR, FZ>;
-        case 2: return (const void*)wedm_step_fused<2, TR, FZ>;
-        case 4: return (const void*)wedm_step_fused<4, TR, FZ>;
-        case 8: return (const void*)wedm_step_fused<8, TR, FZ>;
-        default: return (const void*)wedm_step_fused<16, TR, FZ>;
+        case 1: return (const void*)wedm_step_fused<1, TR, FZ, N1>;
+        case 2: return (const void*)wedm_step_fused<2, TR, FZ, N1>;
+        case 4: return (const void*)wedm_step_fused<4, TR, FZ, N1>;
+        case 8: return (const void*)wedm_step_fused<8, TR, FZ, N1>;
+        default: return (const void*)wedm_step_fused<16, TR, FZ, N1>;
     }
+}
+template <bool TR, bool FZ> static const void* pick_fused(int L, bool n1) {
+    return n1 ? pick_fused<TR, FZ, true>(L) : pick_fused<TR, FZ, false>(L);
 }
 // rows a lane of the stream kernel holds in registers: 64 (128 segments over 2 lanes, 400 over 8) or 104 (400 over 4)
 template <bool TR, int CMAX> static const void* pick_stream(int L) {
@@ -2095,8 +2134,9 @@ static int32_t plan_launch(wedm_ctx* ctx, bool single, bool tr, LaunchPlan& out)
         grid = (ctx->num_envs + 256 / lanes - 1) / (256 / lanes);
         fl = ((size_t)ctx->walk_C[li] + 1) * 1024;
         out.walk = ctx->walk_dev + li;
-        fn = P.autoreset ? (tr ? pick_fused<true, true>(lanes) : pick_fused<false, true>(lanes))
-                         : (tr ? pick_fused<true, false>(lanes) : pick_fused<false, false>(lanes));
+        const bool n1 = (ctx->walk_n1z >> li) & 1u;  // the table has a one-change tile that is a boundary tile in every microsecond
+        fn = P.autoreset ? (tr ? pick_fused<true, true>(lanes, n1) : pick_fused<false, true>(lanes, n1))
+                         : (tr ? pick_fused<true, false>(lanes, n1) : pick_fused<false, false>(lanes, n1));
         std::snprintf(out.name, sizeof(out.name), "wedm_step_fused<%d><<<%d,256,%zuB>>>", lanes, grid, fl);
     }
     if (fl) {
@@ -2207,6 +2247,7 @@ int32_t wedm_create(const wedm_params* params, int32_t num_envs, int32_t n_seg_m
         for (int i = 0; i < 5; ++i) {
             ctx->walk_ok[i] = build_walk(*params, Ls[i], host_tabs[i]);
             ctx->walk_C[i] = host_tabs[i].C;
+            if (ctx->walk_ok[i] && (host_tabs[i].kind_n1_mask & 0x80000000u)) ctx->walk_n1z |= 1u << i;
         }
         if ((e = hipMalloc((void**)&ctx->walk_dev, sizeof(host_tabs))) != hipSuccess ||
             (e = hipMemcpy(ctx->walk_dev, host_tabs, sizeof(host_tabs), hipMemcpyHostToDevice)) != hipSuccess) {
