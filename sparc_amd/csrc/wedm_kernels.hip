@@ -837,7 +837,9 @@ __global__ void __launch_bounds__(256, 2) wedm_step_fused(const KArgs k) {
                 const float jfe_lo = ((joule_lo >> t) & 1u) ? jf_lane : 0.0f;
 #ifdef WEDM_STAMPS_TILES
                 WEDM_STAMP(tk0);
-                const int tkind = ((n_now >> t) & 1u) ? 0 : (!((slow_now >> t) & 1u) ? 1 : 2);
+                // (diagnostic buckets: regular tiles, boundary tiles, and -- in the third -- one-change tiles of the N1
+                // instantiation together with the predicated fallback)
+                const int tkind = ((n_now >> t) & 1u) ? 0 : ((N1 && (((kind_n1 & ~slow_now) >> t) & 1u)) ? 2 : (!((slow_now >> t) & 1u) ? 1 : 2));
 #endif
                 if ((n_now >> t) & 1u) {
                     float old[10], tn[8], cv[8], jv[8];
