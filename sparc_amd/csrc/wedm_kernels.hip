@@ -758,6 +758,18 @@ __global__ void __launch_bounds__(256, 2) wedm_step_fused(const KArgs k) {
     if (c == 0) col[0] = spool;  // wire cell 0 is held at the spool temperature (wire.py:83)
     // the lane that owns the wire's last cell (Neumann boundary, wire.py:95)
     const bool owns_last = (n >= 2) && (n - 1 >= cbase) && (n - 1 < cbase + C);
+    // A chunk whose length is 1 or 2 cells over a multiple of 8 (400 segments: 25 cells over 16 lanes, 50 over 8) would
+    // spend a whole tile on that tail, and a tile costs its dependent chain whatever its width (stamped: 811-843 cycles
+    // for the 1- / 2-cell tile against 799-809 for a full regular one).  The tail cells are instead computed like the
+    // patched cells: by the interior formula from OLD values before the walk (their chains overlap those of the plasma /
+    // last cell), written after it; the walk covers the full tiles only.  Bits per tail cell q: zone, contacts,
+    // interior, valid (this lane's chunk).
+    const int tail = (C > 8 && (C & 7) >= 1 && (C & 7) <= 2) ? (C & 7) : 0;
+    uint32_t tail_bits = 0u;
+    for (int q = 0; q < tail; ++q) {
+        const uint32_t zj = wt->zj[C - tail + q], iv = wt->iv[C - tail + q];
+        tail_bits |= (((zj >> c) & 1u) | (((zj >> (16 + c)) & 1u) << 1) | (((iv >> c) & 1u) << 2) | (((iv >> (16 + c)) & 1u) << 3)) << (4 * q);
+    }
 
     WEDM_STAMP_DECL;
     const bool tracing = WEDM_TRACING(k);
@@ -805,6 +817,23 @@ __global__ void __launch_bounds__(256, 2) wedm_step_fused(const KArgs k) {
             if (n - 1 == 1) tm = spool;
             tlast = stencil_cell(n - 1, n, tm, col[jl * 256], 0.0f, g, cf, ps, tref, alpha, tdiel);
         }
+
+        // ---- tail cells (see `tail`): new values from OLD ones, now; not on the predicated path, whose last tile covers them
+        const bool use_tail = tail != 0 && !all_slow;
+        float tt0 = 0.0f, tt1 = 0.0f;
+        if (use_tail) {
+            const float jfl = (cf.joule_on && !s.done) ? cf.jf : 0.0f;
+            const int j0 = C - tail;
+            const float a0 = col[(j0 - 1) * 256], b0 = col[j0 * 256], c0 = col[(j0 + 1) * 256];  // row C holds the right halo
+            tt0 = interior_cell<true>(a0, b0, c0, g.k, g.tuf, (tail_bits & 1u) ? ps.conv_zone : ps.conv_base, tdiel, ps.adv,
+                                      (tail_bits & 2u) ? jfl : 0.0f, alpha, tref);
+            if (tail == 2) {
+                const float c1 = col[(j0 + 2) * 256];
+                tt1 = interior_cell<true>(b0, c0, c1, g.k, g.tuf, (tail_bits & 16u) ? ps.conv_zone : ps.conv_base, tdiel, ps.adv,
+                                          (tail_bits & 32u) ? jfl : 0.0f, alpha, tref);
+            }
+        }
+        const int n_walk = use_tail ? n_tiles - 1 : n_tiles;
 
         float tmax = spool;
         float tm1 = halo_l;
@@ -953,13 +982,19 @@ __global__ void __launch_bounds__(256, 2) wedm_step_fused(const KArgs k) {
             };
             float bufA[8];
             if (!FROZEN_OK || !frozen_wave) {
-                for (int t = 0; t < n_tiles; ++t) tile(std::false_type{}, t, bufA, bufA);
+                for (int t = 0; t < n_walk; ++t) tile(std::false_type{}, t, bufA, bufA);
             } else {
-                for (int t = 0; t < n_tiles; ++t) tile(std::true_type{}, t, bufA, bufA);
+                for (int t = 0; t < n_walk; ++t) tile(std::true_type{}, t, bufA, bufA);
             }
         }
         WEDM_STAMP(st2);
-        // ---- patches (after every store of the walk): boundary condition, last cell, plasma cell
+        // ---- patches (after every store of the walk): tail cells, then boundary condition, last cell, plasma cell
+        if (use_tail && !s.done) {
+            // (valid: the cell exists; interior: it counts for the maximum and is not the wire's last cell, which the
+            // patch below writes)
+            if (tail_bits & 4u) { col[(C - tail) * 256] = tt0; tmax = fmax_gt(tmax, tt0); }
+            if (tail == 2 && (tail_bits & 64u)) { col[(C - 1) * 256] = tt1; tmax = fmax_gt(tmax, tt1); }
+        }
         if (c == 0 && !s.done) col[0] = spool;
         if (owns_last && !s.done) {
             col[(n - 1 - cbase) * 256] = tlast;
