@@ -1437,7 +1437,9 @@ __device__ __forceinline__ f2 interior2(f2 tm1, f2 tc, f2 tp1, float k, float tu
 // predicated path (~4 x slower: 3.65e9 instead of 1.36e10 env-steps/s on a batch that resets 17 % of its environments per
 // launch); with it such a wave takes a second copy of the tile code in which the frozen lanes do not store.  A separate
 // instantiation, because the mere presence of that copy costs the other waves 2 % (6 % when folded into one copy).
-template <int L, bool TRACE, bool FROZEN_OK = false>
+// EXTRA: the instantiation for tile tables that need them: one-change tiles on the stage-major code (see wedm_step_fused's
+// N1) and a chunk's 1- or 2-cell tail computed with the patched cells (virtual chunks of 25 cells: 400 segments over 8 lanes).
+template <int L, bool TRACE, bool FROZEN_OK = false, bool EXTRA = false>
 __global__ void __launch_bounds__(256, 2) wedm_step_packed(const KArgs k) {
     const ColdRef cold = kernarg_cold();
     Hot hv = k.hot;
@@ -1513,6 +1515,7 @@ __global__ void __launch_bounds__(256, 2) wedm_step_packed(const KArgs k) {
     kind_s = __builtin_amdgcn_readfirstlane(kind_s);
     // tiles that take the regular code although they hold a wire end cell / a contact-flag change (see WalkTable)
     const uint32_t kind_ne = __builtin_amdgcn_readfirstlane(wt->kind_ne_mask), kind_nj = __builtin_amdgcn_readfirstlane(wt->kind_nj_mask);
+    const uint32_t kind_n1 = EXTRA ? (__builtin_amdgcn_readfirstlane(wt->kind_n1_mask) & 0x7fffffffu) : 0u;
 #pragma unroll
     for (int q = 0; q < 3; ++q) split_pack[q] = __builtin_amdgcn_readfirstlane(split_pack[q]);
     if (c == 0) col[0] = spool;  // wire cell 0 (row 0 of lane 0's chunk A) is held at the spool temperature
@@ -1524,6 +1527,18 @@ __global__ void __launch_bounds__(256, 2) wedm_step_packed(const KArgs k) {
         return 0;
     };
     const int own_last = (n >= 2) ? owner(n - 1) : 0;
+    // tail cells of the two virtual chunks (see wedm_step_fused): bits per tail cell q and chunk v at 4 (2 q + v):
+    // zone, contacts, interior, valid
+    const int tail = (EXTRA && Cv > 8 && (Cv & 7) >= 1 && (Cv & 7) <= 2) ? (Cv & 7) : 0;
+    uint32_t tail_bits = 0u;
+    for (int q = 0; q < tail; ++q) {
+        const uint32_t zj = wt->zj[Cv - tail + q], iv = wt->iv[Cv - tail + q];
+#pragma unroll
+        for (int v = 0; v < 2; ++v) {
+            const int vc = 2 * c + v;
+            tail_bits |= (((zj >> vc) & 1u) | (((zj >> (16 + vc)) & 1u) << 1) | (((iv >> vc) & 1u) << 2) | (((iv >> (16 + vc)) & 1u) << 3)) << (4 * (2 * q + v));
+        }
+    }
 
     WEDM_STAMP_DECL;
     const bool tracing = WEDM_TRACING(k);
@@ -1575,6 +1590,28 @@ __global__ void __launch_bounds__(256, 2) wedm_step_packed(const KArgs k) {
             if (own_pl) tpl = patch_value(cf.pidx, own_pl);
         }
         if (own_last && !s.done) tlast = patch_value(n - 1, own_last);
+
+        // ---- tail cells: new values from OLD ones, now (not on the predicated path, whose last tile covers them)
+        const bool use_tail = EXTRA && tail != 0 && !all_slow;
+        float tt[4] = {0.0f, 0.0f, 0.0f, 0.0f};  // [2 q + v]
+        if (use_tail) {
+            const float jfl = (cf.joule_on && !s.done) ? cf.jf : 0.0f;
+#pragma unroll
+            for (int q = 0; q < 2; ++q) {
+                if (q < tail) {
+                    const int r = Cv - tail + q;
+#pragma unroll
+                    for (int v = 0; v < 2; ++v) {
+                        const uint32_t b = tail_bits >> (4 * (2 * q + v));
+                        // rows 2 Cv and 2 Cv + 1 hold the halo pair: the right neighbour of a chunk's last cell
+                        tt[2 * q + v] = interior_cell<true>(col[(2 * (r - 1) + v) * 256], col[(2 * r + v) * 256], col[(2 * (r + 1) + v) * 256],
+                                                            g.k, g.tuf, (b & 1u) ? ps.conv_zone : ps.conv_base, tdiel, ps.adv,
+                                                            (b & 2u) ? jfl : 0.0f, alpha, tref);
+                    }
+                }
+            }
+        }
+        const int n_walk = use_tail ? n_tiles - 1 : n_tiles;
 
         float tmax = spool;
         f2 tm1 = {halo_l, a_last};
@@ -1636,6 +1673,39 @@ __global__ void __launch_bounds__(256, 2) wedm_step_packed(const KArgs k) {
 #pragma unroll
                         for (int u = 0; u < 8; ++u) store2(r0 + u, tn[u]);
                     }
+#pragma unroll
+                    for (int u = 2; u < 6; u += 2) {
+                        m0 = fmax_gt(m0, fmax_gt(tn[u].x, tn[u].y));
+                        m1 = fmax_gt(m1, fmax_gt(tn[u + 1].x, tn[u + 1].y));
+                    }
+                    m0 = fmax_gt(m0, fmax_gt(tn[6].x, tn[6].y));
+                    m1 = fmax_gt(m1, fmax_gt(tn[7].x, last_y));
+                    tmax = fmax_gt(tmax, fmax_gt(m0, m1));
+                    tm1 = cur[6];
+                    tc = cur[7];
+                } else if (EXTRA && (((kind_n1 & ~slow_now) >> t) & 1u)) {
+                    // one flag change at `split`, nothing else irregular (end cells apart): per-cell coefficients, stores
+                    // and maximum as in a regular tile
+                    const int split = (int)((split_pack[t >> 3] >> ((t & 7) * 4)) & 15u);
+                    const f2 conv_hi = {((zhA >> t) & 1u) ? cz : cb, ((zhB >> t) & 1u) ? cz : cb};
+                    const f2 jfe_hi = {((jhA >> t) & 1u) ? jf_lane : 0.0f, ((jhB >> t) & 1u) ? jf_lane : 0.0f};
+                    f2 old[10], tn[8], cv[8], jv[8];
+                    old[0] = tm1; old[1] = tc;
+#pragma unroll
+                    for (int u = 0; u < 8; ++u) {
+                        old[u + 2] = cur[u];
+                        cv[u] = u < split ? conv_lo : conv_hi;
+                        jv[u] = u < split ? jfe_lo : jfe_hi;
+                    }
+                    if (joule_wave) tile8_staged<f2, true, true>(old, tn, g.k, g.tuf, cv, tdiel, ps.adv, jv, alpha, tref);
+                    else tile8_staged<f2, false, true>(old, tn, g.k, g.tuf, cv, tdiel, ps.adv, jv, alpha, tref);
+                    tn[0].x = (c == 0 && t == 0) ? spool : tn[0].x;
+                    const float last_y = (own_last == 2 && t == n_tiles - 1) ? spool : tn[7].y;
+                    if (!FROZEN || !s.done) {
+#pragma unroll
+                        for (int u = 0; u < 8; ++u) store2(r0 + u, tn[u]);
+                    }
+                    float m0 = fmax_gt(tn[0].x, tn[0].y), m1 = fmax_gt(tn[1].x, tn[1].y);
 #pragma unroll
                     for (int u = 2; u < 6; u += 2) {
                         m0 = fmax_gt(m0, fmax_gt(tn[u].x, tn[u].y));
@@ -1717,13 +1787,27 @@ __global__ void __launch_bounds__(256, 2) wedm_step_packed(const KArgs k) {
             };
             f2 bufA[8];
             if (!FROZEN_OK || !frozen_wave) {
-                for (int t = 0; t < n_tiles; ++t) tile(std::false_type{}, t, bufA, bufA);
+                for (int t = 0; t < n_walk; ++t) tile(std::false_type{}, t, bufA, bufA);
             } else {
-                for (int t = 0; t < n_tiles; ++t) tile(std::true_type{}, t, bufA, bufA);
+                for (int t = 0; t < n_walk; ++t) tile(std::true_type{}, t, bufA, bufA);
             }
         }
         WEDM_STAMP(st2);
-        // ---- patches (after every store of the walk): boundary condition, last cell, plasma cell
+        // ---- patches (after every store of the walk): tail cells, then boundary condition, last cell, plasma cell
+        if (use_tail && !s.done) {
+#pragma unroll
+            for (int q = 0; q < 2; ++q) {
+                if (q < tail) {
+#pragma unroll
+                    for (int v = 0; v < 2; ++v) {
+                        if ((tail_bits >> (4 * (2 * q + v))) & 4u) {  // interior: exists, counts, and is not the wire's last cell
+                            col[(2 * (Cv - tail + q) + v) * 256] = tt[2 * q + v];
+                            tmax = fmax_gt(tmax, tt[2 * q + v]);
+                        }
+                    }
+                }
+            }
+        }
         if (c == 0 && !s.done) col[0] = spool;
         if (own_last && !s.done) {
             const int v = own_last - 1;
@@ -1993,13 +2077,16 @@ template <bool TR, int CMAX> static const void* pick_stream(int L) {
         default: return (const void*)wedm_step_stream<16, TR, CMAX>;
     }
 }
-template <bool TR, bool FZ> static const void* pick_packed(int L) {
+template <bool TR, bool FZ, bool EX> static const void* pick_packed(int L) {
     switch (L) {
-        case 1: return (const void*)wedm_step_packed<1, TR, FZ>;
-        case 2: return (const void*)wedm_step_packed<2, TR, FZ>;
-        case 4: return (const void*)wedm_step_packed<4, TR, FZ>;
-        default: return (const void*)wedm_step_packed<8, TR, FZ>;
+        case 1: return (const void*)wedm_step_packed<1, TR, FZ, EX>;
+        case 2: return (const void*)wedm_step_packed<2, TR, FZ, EX>;
+        case 4: return (const void*)wedm_step_packed<4, TR, FZ, EX>;
+        default: return (const void*)wedm_step_packed<8, TR, FZ, EX>;
     }
+}
+template <bool TR, bool FZ> static const void* pick_packed(int L, bool extra) {
+    return extra ? pick_packed<TR, FZ, true>(L) : pick_packed<TR, FZ, false>(L);
 }
 
 // A handle belongs to the device that was current in wedm_create: its parameter / table / walk buffers
@@ -2024,11 +2111,17 @@ static int32_t plan_launch(wedm_ctx* ctx, bool single, bool tr, LaunchPlan& out)
     const wedm_params& P = ctx->p;
     // kernel 3 (one chunk per lane) and kernel 4 (two packed chunks per lane, table of 2L chunks).
     // Auto-selection by a small cost model fitted to measurements:
-    //   cycles per step ~ rounds * (4500 + tiles_per_lane * 8 * cell_cost),
+    //   cycles per step ~ rounds * (4500 + tiles_per_lane * 8 * cell_cost),  tiles_per_lane: see eff_tiles below,
     //   rounds = ceil(blocks / (256 CUs * resident blocks per CU)), resident = min(2 [VGPRs], LDS fit),
     //   cell_cost = 90 per cell, a packed pair = 2 * 90 * 0.93.
     const bool uniform = !ctx->p.per_env_geometry && ctx->walk_dev;
     int lanes = ctx->lanes, planes = ctx->lanes;
+    // tiles a chunk of C cells costs: its full tiles, a whole tile for a partial one, a quarter for a 1- / 2-cell tail
+    // (computed with the patched cells) -- 32 768 x 400: fused<8> 3.60e9, packed<8> 3.75e9 measured
+    auto eff_tiles = [](int C) -> double {
+        const int rest = C & 7;
+        return (double)(C / 8) + (rest == 0 ? 0.0 : (C > 8 && rest <= 2) ? 0.25 : 1.0);
+    };
     {
         double best3 = 1e300, best4 = 1e300;
         int l3 = 0, l4 = 0;
@@ -2041,7 +2134,7 @@ static int32_t plan_launch(wedm_ctx* ctx, bool single, bool tr, LaunchPlan& out)
                 if (lds <= (size_t)ctx->lds_limit) {
                     const long rb = std::min<long>(2, (long)(160 * 1024 / lds));
                     const long rounds = (blocks + 256 * rb - 1) / (256 * rb);
-                    const double cost = rounds * (4500.0 + ((ctx->walk_C[i] + 7) / 8) * 8 * 90.0);
+                    const double cost = rounds * (4500.0 + eff_tiles(ctx->walk_C[i]) * 8 * 90.0);
                     if (cost < best3) { best3 = cost; l3 = Lc; }
                 }
             }
@@ -2051,7 +2144,7 @@ static int32_t plan_launch(wedm_ctx* ctx, bool single, bool tr, LaunchPlan& out)
                 if (lds <= (size_t)ctx->lds_limit) {
                     const long rb = std::min<long>(2, (long)(160 * 1024 / lds));
                     const long rounds = (blocks + 256 * rb - 1) / (256 * rb);
-                    const double cost = rounds * (4500.0 + ((ctx->walk_C[ti] + 7) / 8) * 8 * 2 * 90.0 * 0.93);
+                    const double cost = rounds * (4500.0 + eff_tiles(ctx->walk_C[ti]) * 8 * 2 * 90.0 * 0.93);
                     if (cost < best4) { best4 = cost; l4 = Lc; }
                 }
             }
@@ -2164,8 +2257,10 @@ static int32_t plan_launch(wedm_ctx* ctx, bool single, bool tr, LaunchPlan& out)
         fl = (2 * (size_t)ctx->walk_C[pli] + 2) * 1024;
         out.walk = ctx->walk_dev + pli;
         // handles with in-launch autoreset expect terminations: the instantiation that tolerates frozen lanes
-        fn = P.autoreset ? (tr ? pick_packed<true, true>(planes) : pick_packed<false, true>(planes))
-                         : (tr ? pick_packed<true, false>(planes) : pick_packed<false, false>(planes));
+        // tables with a one-change boundary tile or a 1- / 2-cell tail: the instantiation that handles them
+        const bool extra = ((ctx->walk_n1z >> pli) & 1u) || ((ctx->walk_C[pli] > 8) && (ctx->walk_C[pli] & 7) >= 1 && (ctx->walk_C[pli] & 7) <= 2);
+        fn = P.autoreset ? (tr ? pick_packed<true, true>(planes, extra) : pick_packed<false, true>(planes, extra))
+                         : (tr ? pick_packed<true, false>(planes, extra) : pick_packed<false, false>(planes, extra));
         std::snprintf(out.name, sizeof(out.name), "wedm_step_packed<%d><<<%d,256,%zuB>>>", planes, grid, fl);
     } else {
         grid = (ctx->num_envs + 256 / lanes - 1) / (256 / lanes);

@@ -908,7 +908,7 @@ def test_config4_shard_of_rank_7_matches_oracle():
         act = env.make_action(0.1, 80.0, 5, 3.0, 80.0)
         env.step_many(act, 1000)
         env.step_many(act, 1000)
-    assert "wedm_step_fused<8>" in gpu._backend.last_kernel(), gpu._backend.last_kernel()
+    assert "wedm_step_packed<8>" in gpu._backend.last_kernel(), gpu._backend.last_kernel()
     check(gpu, cpu, n)
     for env in (gpu, cpu):
         act = env.make_action(0.1, 80.0, 5, 3.0, 80.0)
