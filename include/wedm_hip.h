@@ -374,6 +374,12 @@ int64_t wedm_sizeof_params(void);
  * episode 3.                                                                               */
 int32_t wedm_debug_math(int32_t kind, const double* a, const double* b, double* out, int32_t n, void* stream);
 
+/* TEST HOOK: fills the LDS of every compute unit of the current device with `value`.  The step kernels stage only the
+ * cells of a wire that exist; rows of their LDS image past a wire's end are never written, and a result that depended
+ * on one would go unnoticed as long as the previous kernel happened to leave plausible temperatures there.  The GPU
+ * tests poison the LDS (1e30) before every test.                                                                  */
+int32_t wedm_debug_poison_lds(float value, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -72,6 +72,8 @@ def load() -> C.CDLL:
     L.wedm_last_kernel.restype = C.c_char_p
     L.wedm_debug_math.argtypes = [C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p]
     L.wedm_debug_math.restype = C.c_int32
+    L.wedm_debug_poison_lds.argtypes = [C.c_float, C.c_void_p]
+    L.wedm_debug_poison_lds.restype = C.c_int32
     _lib = L
     return L
 
@@ -79,7 +81,7 @@ def load() -> C.CDLL:
 EXPORTS = (
     "wedm_abi_version", "wedm_create", "wedm_destroy", "wedm_bind_state", "wedm_bind_geometry",
     "wedm_reset", "wedm_step", "wedm_bind_trace", "wedm_bind_rng_replay", "wedm_trace_samples", "wedm_set_kernel", "wedm_set_lanes", "wedm_last_kernel", "wedm_last_error",
-    "wedm_sizeof_params", "wedm_debug_math",
+    "wedm_sizeof_params", "wedm_debug_math", "wedm_debug_poison_lds",
 )
 
 

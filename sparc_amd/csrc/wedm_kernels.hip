@@ -422,6 +422,84 @@ __global__ void __launch_bounds__(256) wedm_step_split(const KArgs k) {
 #define WEDM_S2_STAMP_OUT() do { } while (0)
 #endif
 
+typedef float f2 __attribute__((ext_vector_type(2)));
+
+// Eight cells (V = float) or eight packed cell pairs (V = float2) evaluated STAGE-MAJOR: every stage applies one operation
+// of interior2() to all eight pairs, and a scheduling barrier separates the stages, so dependent
+// packed ops are always >= 8 instructions apart.  Left to itself the scheduler emits the eight
+// chains one after the other (each op waiting on the previous, s_nop in between).  Operation
+// order and rounding are exactly those of interior2().  old[u], old[u+1], old[u+2] are the OLD
+// (tm1, tc, tp1) of pair u.  conv/jfe: one coefficient pair per cell (PERCELL) or per tile.
+#define WEDM_STAGE_FENCE() __builtin_amdgcn_sched_barrier(0)
+// W pairs starting at pair `o` of the tile (W = 4: two half-tiles keep the temporaries, and
+// with them the scratch spills of the caller's state, small; 4-way ILP already covers the
+// packed-op latency).
+template <class V, bool JOULE, bool PERCELL, int W>
+__device__ __forceinline__ void tile_staged(const V (&old)[10], V (&tn)[8], const int o, float k, float tuf,
+                                            const V (&conv)[8], float tdiel, float adv, const V (&jfe)[8],
+                                            float alpha, float tref) {
+    V a[W], e[W], f[W], r[W];
+#pragma unroll
+    for (int u = 0; u < W; ++u) {
+        a[u] = sub_twice(old[o + u], old[o + u + 1]);  // T[i-1] - 2*T[i] (exact product, one rounding)
+        e[u] = old[o + u + 1] - tdiel;           // T[i] - T_dielectric
+        f[u] = old[o + u] - old[o + u + 1];      // T[i-1] - T[i]
+        if (JOULE) r[u] = old[o + u + 1] - tref;
+    }
+    WEDM_STAGE_FENCE();
+#pragma unroll
+    for (int u = 0; u < W; ++u) {
+        e[u] = (PERCELL ? conv[o + u] : conv[0]) * e[u];
+        f[u] = adv * f[u];
+        if (JOULE) r[u] = alpha * r[u];
+    }
+    WEDM_STAGE_FENCE();
+#pragma unroll
+    for (int u = 0; u < W; ++u) {
+        a[u] = a[u] + old[o + u + 2];
+        if (JOULE) r[u] = 1.0f + r[u];
+    }
+    WEDM_STAGE_FENCE();
+#pragma unroll
+    for (int u = 0; u < W; ++u) {
+        a[u] = k * a[u];
+        if (JOULE) r[u] = (PERCELL ? jfe[o + u] : jfe[0]) * r[u];
+    }
+    WEDM_STAGE_FENCE();
+    if (JOULE) {
+#pragma unroll
+        for (int u = 0; u < W; ++u) a[u] = a[u] + r[u];
+        WEDM_STAGE_FENCE();
+    }
+#pragma unroll
+    for (int u = 0; u < W; ++u) a[u] = a[u] - e[u];
+    WEDM_STAGE_FENCE();
+#pragma unroll
+    for (int u = 0; u < W; ++u) a[u] = a[u] + f[u];
+    WEDM_STAGE_FENCE();
+#pragma unroll
+    for (int u = 0; u < W; ++u) a[u] = a[u] * tuf;
+    WEDM_STAGE_FENCE();
+#pragma unroll
+    for (int u = 0; u < W; ++u) tn[o + u] = old[o + u + 1] + a[u];
+    WEDM_STAGE_FENCE();
+}
+
+#ifndef WEDM_STAGE_W
+#define WEDM_STAGE_W 4
+#endif
+#ifndef WEDM_STAGE_W_PACKED
+#define WEDM_STAGE_W_PACKED 2  // as fast as 4 (the other wave of the SIMD fills the gaps) and 16 VGPRs cheaper
+#endif
+template <class V, bool JOULE, bool PERCELL>
+__device__ __forceinline__ void tile8_staged(const V (&old)[10], V (&tn)[8], float k, float tuf, const V (&conv)[8],
+                                             float tdiel, float adv, const V (&jfe)[8], float alpha, float tref) {
+    constexpr int W = sizeof(V) == 8 ? WEDM_STAGE_W_PACKED : WEDM_STAGE_W;
+#pragma unroll
+    for (int o = 0; o < 8; o += W)
+        tile_staged<V, JOULE, PERCELL, W>(old, tn, o, k, tuf, conv, tdiel, adv, jfe, alpha, tref);
+}
+
 // Any geometry (uniform or one row per environment), L lanes per environment, every cell on the
 // predicated formula with the lane's own n_seg / zone / contact indices.  LDS layout and halo
 // exchange as in the fused kernels; the chunk length is uniform, C = ceil(n_seg_max / L), so an
@@ -496,6 +574,74 @@ __global__ void __launch_bounds__(256, 2) wedm_step_lanes(const KArgs k) {
         const float halo_l = (c > 0) ? col[(C - 1) * 256 - 1] : spool;
         const float halo_r = (c < L - 1) ? col[1] : 0.0f;
         float tmax = spool, tm1 = halo_l, tc = col[0];
+#ifndef WEDM_LANES_PREDICATED_ONLY
+        // Fast walk (float32 stencil, no negative plasma heat in the wave): every cell of the chunk takes the interior
+        // formula, stage-major, eight at a time, with ITS OWN coefficients (two range tests against this lane's zone and
+        // contact indices per cell); the cells the interior formula is wrong for -- wire cell 0, the last cell, the plasma
+        // cell -- are computed by the predicated formula from OLD values before the walk and written after it, and
+        // together with the cells past this environment's wire they are kept out of the maximum.  Same results as the
+        // predicated walk below (the uniform-geometry kernels rely on the same equivalence), ~23 instead of ~40
+        // instructions per cell.
+        if (!F64 && !__any(cf.q < 0.0f)) {
+            const bool keep = !s.done;
+            const bool owns_pl = keep && cf.pidx >= 1 && cf.pidx >= cbase && cf.pidx < cbase + C && cf.pidx < n;
+            const bool owns_last = keep && n >= 2 && (n - 1 >= cbase) && (n - 1 < cbase + C);
+            float tpl = 0.0f, tlast = 0.0f;
+            if (__any(owns_pl)) {
+                if (owns_pl) {
+                    const int jp = cf.pidx - cbase;
+                    float tm = jp > 0 ? col[(jp - 1) * 256] : halo_l;
+                    if (cf.pidx == 1) tm = spool;
+                    const float tp = jp < C - 1 ? col[(jp + 1) * 256] : halo_r;
+                    tpl = stencil_cell(cf.pidx, n, tm, col[jp * 256], tp, g, cf, ps, tref, alpha, tdiel);
+                }
+            }
+            if (owns_last) {
+                const int jl = n - 1 - cbase;
+                float tm = jl > 0 ? col[(jl - 1) * 256] : halo_l;
+                if (n - 1 == 1) tm = spool;
+                tlast = stencil_cell(n - 1, n, tm, col[jl * 256], 0.0f, g, cf, ps, tref, alpha, tdiel);
+            }
+            const float jf_lane = (cf.joule_on && keep) ? cf.jf : 0.0f;
+            const bool joule_wave = __any(jf_lane != 0.0f);
+            const uint32_t zs = (uint32_t)g.az_start, zw = g.az_end > g.az_start ? (uint32_t)(g.az_end - g.az_start) : 0u;
+            const uint32_t cbot = (uint32_t)g.cb, cw = g.ct >= g.cb ? (uint32_t)(g.ct - g.cb + 1) : 0u;
+            const uint32_t span = n >= 3 ? (uint32_t)(n - 3) : 0u;
+            for (int j0 = 0; j0 < C; j0 += 8) {
+                float old[10], tn[8], cv[8], jv[8];
+                old[0] = tm1; old[1] = tc;
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    const int row = j0 + 1 + u;
+                    old[u + 2] = row < C ? col[row * 256] : halo_r;
+                    const uint32_t i = (uint32_t)(cbase + j0 + u);
+                    cv[u] = (i - zs < zw) ? ps.conv_zone : ps.conv_base;   // az_start <= i < az_end
+                    jv[u] = (i - cbot < cw) ? jf_lane : 0.0f;               // contact_bottom <= i <= contact_top
+                }
+                if (joule_wave) tile8_staged<float, true, true>(old, tn, g.k, g.tuf, cv, tdiel, ps.adv, jv, alpha, tref);
+                else tile8_staged<float, false, true>(old, tn, g.k, g.tuf, cv, tdiel, ps.adv, jv, alpha, tref);
+                if (keep) {
+                    // (rows past this environment's wire keep their value: the write-back copies all n_seg_max rows)
+#pragma unroll
+                    for (int u = 0; u < 8; ++u)
+                        if (j0 + u < C) col[(j0 + u) * 256] = (cbase + j0 + u < n) ? tn[u] : old[u + 1];
+                }
+                float mx[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    const uint32_t im1 = (uint32_t)(cbase + j0 + u) - 1u;  // interior: 1 <= i <= n - 2
+                    mx[u] = (n >= 3 && j0 + u < C && im1 <= span) ? tn[u] : spool;
+                }
+                tmax = fmax_gt(tmax, fmax_gt(fmax_gt(fmax_gt(mx[0], mx[1]), fmax_gt(mx[2], mx[3])),
+                                             fmax_gt(fmax_gt(mx[4], mx[5]), fmax_gt(mx[6], mx[7]))));
+                tm1 = old[8];
+                tc = old[9];
+            }
+            if (c == 0 && keep) col[0] = spool;
+            if (owns_last) { col[(n - 1 - cbase) * 256] = tlast; tmax = fmax_gt(tmax, tlast); }
+            if (owns_pl) { col[(cf.pidx - cbase) * 256] = tpl; tmax = fmax_gt(tmax, tpl); }
+        } else
+#endif
         for (int j0 = 0; j0 < C; j0 += 8) {
             float nx[8];
 #pragma unroll
@@ -597,84 +743,6 @@ __device__ __forceinline__ float interior_cell(float tm1, float tc, float tp1, f
     return tc + d * tuf;
 }
 
-typedef float f2 __attribute__((ext_vector_type(2)));
-
-// Eight cells (V = float) or eight packed cell pairs (V = float2) evaluated STAGE-MAJOR: every stage applies one operation
-// of interior2() to all eight pairs, and a scheduling barrier separates the stages, so dependent
-// packed ops are always >= 8 instructions apart.  Left to itself the scheduler emits the eight
-// chains one after the other (each op waiting on the previous, s_nop in between).  Operation
-// order and rounding are exactly those of interior2().  old[u], old[u+1], old[u+2] are the OLD
-// (tm1, tc, tp1) of pair u.  conv/jfe: one coefficient pair per cell (PERCELL) or per tile.
-#define WEDM_STAGE_FENCE() __builtin_amdgcn_sched_barrier(0)
-// W pairs starting at pair `o` of the tile (W = 4: two half-tiles keep the temporaries, and
-// with them the scratch spills of the caller's state, small; 4-way ILP already covers the
-// packed-op latency).
-template <class V, bool JOULE, bool PERCELL, int W>
-__device__ __forceinline__ void tile_staged(const V (&old)[10], V (&tn)[8], const int o, float k, float tuf,
-                                            const V (&conv)[8], float tdiel, float adv, const V (&jfe)[8],
-                                            float alpha, float tref) {
-    V a[W], e[W], f[W], r[W];
-#pragma unroll
-    for (int u = 0; u < W; ++u) {
-        a[u] = sub_twice(old[o + u], old[o + u + 1]);  // T[i-1] - 2*T[i] (exact product, one rounding)
-        e[u] = old[o + u + 1] - tdiel;           // T[i] - T_dielectric
-        f[u] = old[o + u] - old[o + u + 1];      // T[i-1] - T[i]
-        if (JOULE) r[u] = old[o + u + 1] - tref;
-    }
-    WEDM_STAGE_FENCE();
-#pragma unroll
-    for (int u = 0; u < W; ++u) {
-        e[u] = (PERCELL ? conv[o + u] : conv[0]) * e[u];
-        f[u] = adv * f[u];
-        if (JOULE) r[u] = alpha * r[u];
-    }
-    WEDM_STAGE_FENCE();
-#pragma unroll
-    for (int u = 0; u < W; ++u) {
-        a[u] = a[u] + old[o + u + 2];
-        if (JOULE) r[u] = 1.0f + r[u];
-    }
-    WEDM_STAGE_FENCE();
-#pragma unroll
-    for (int u = 0; u < W; ++u) {
-        a[u] = k * a[u];
-        if (JOULE) r[u] = (PERCELL ? jfe[o + u] : jfe[0]) * r[u];
-    }
-    WEDM_STAGE_FENCE();
-    if (JOULE) {
-#pragma unroll
-        for (int u = 0; u < W; ++u) a[u] = a[u] + r[u];
-        WEDM_STAGE_FENCE();
-    }
-#pragma unroll
-    for (int u = 0; u < W; ++u) a[u] = a[u] - e[u];
-    WEDM_STAGE_FENCE();
-#pragma unroll
-    for (int u = 0; u < W; ++u) a[u] = a[u] + f[u];
-    WEDM_STAGE_FENCE();
-#pragma unroll
-    for (int u = 0; u < W; ++u) a[u] = a[u] * tuf;
-    WEDM_STAGE_FENCE();
-#pragma unroll
-    for (int u = 0; u < W; ++u) tn[o + u] = old[o + u + 1] + a[u];
-    WEDM_STAGE_FENCE();
-}
-
-#ifndef WEDM_STAGE_W
-#define WEDM_STAGE_W 4
-#endif
-#ifndef WEDM_STAGE_W_PACKED
-#define WEDM_STAGE_W_PACKED 2  // as fast as 4 (the other wave of the SIMD fills the gaps) and 16 VGPRs cheaper
-#endif
-template <class V, bool JOULE, bool PERCELL>
-__device__ __forceinline__ void tile8_staged(const V (&old)[10], V (&tn)[8], float k, float tuf, const V (&conv)[8],
-                                             float tdiel, float adv, const V (&jfe)[8], float alpha, float tref) {
-    constexpr int W = sizeof(V) == 8 ? WEDM_STAGE_W_PACKED : WEDM_STAGE_W;
-#pragma unroll
-    for (int o = 0; o < 8; o += W)
-        tile_staged<V, JOULE, PERCELL, W>(old, tn, o, k, tuf, conv, tdiel, adv, jfe, alpha, tref);
-}
-
 // FROZEN_OK: see wedm_step_packed.  N1: the instantiation for tile tables with a one-change tile that is a boundary tile in
 // every microsecond (4 096 x 400 over 16 lanes: the end of the workpiece zone falls inside tile 2 of 4): +4.7 % there; the
 // extra code costs tables without such a tile 1-1.5 %, so they run the instantiation without it.
@@ -758,6 +826,7 @@ __global__ void __launch_bounds__(256, 2) wedm_step_fused(const KArgs k) {
     if (c == 0) col[0] = spool;  // wire cell 0 is held at the spool temperature (wire.py:83)
     // the lane that owns the wire's last cell (Neumann boundary, wire.py:95)
     const bool owns_last = (n >= 2) && (n - 1 >= cbase) && (n - 1 < cbase + C);
+    const int t_last = (n - 1 - cbase) >> 3;  // the tile of that cell in the owning lane (its last position, where the tile is regular)
     // A chunk whose length is 1 or 2 cells over a multiple of 8 (400 segments: 25 cells over 16 lanes, 50 over 8) would
     // spend a whole tile on that tail, and a tile costs its dependent chain whatever its width (stamped: 811-843 cycles
     // for the 1- / 2-cell tile against 799-809 for a full regular one).  The tail cells are instead computed like the
@@ -883,7 +952,7 @@ __global__ void __launch_bounds__(256, 2) wedm_step_fused(const KArgs k) {
                     // the wire's end cells, where a regular tile holds one (kind_ne / kind_nj): cell 0 stays at the spool
                     // temperature; the last cell is kept out of the maximum here and patched after the walk
                     tn[0] = (c == 0 && t == 0) ? spool : tn[0];
-                    const float last_v = (owns_last && t == n_tiles - 1) ? spool : tn[7];
+                    const float last_v = (owns_last && t == t_last) ? spool : tn[7];
                     if (!FROZEN || !s.done) {
 #pragma unroll
                         for (int u = 0; u < 8; ++u) col[(j + u) * 256] = tn[u];
@@ -911,7 +980,7 @@ __global__ void __launch_bounds__(256, 2) wedm_step_fused(const KArgs k) {
                     if (joule_wave) tile8_staged<float, true, true>(old, tn, g.k, g.tuf, cv, tdiel, ps.adv, jv, alpha, tref);
                     else tile8_staged<float, false, true>(old, tn, g.k, g.tuf, cv, tdiel, ps.adv, jv, alpha, tref);
                     tn[0] = (c == 0 && t == 0) ? spool : tn[0];
-                    const float last_v = (owns_last && t == n_tiles - 1) ? spool : tn[7];
+                    const float last_v = (owns_last && t == t_last) ? spool : tn[7];
                     if (!FROZEN || !s.done) {
 #pragma unroll
                         for (int u = 0; u < 8; ++u) col[(j + u) * 256] = tn[u];
@@ -1149,6 +1218,7 @@ __global__ void __launch_bounds__(256, 2) wedm_step_stream(const KArgs k) {
     for (int q = 0; q < 3; ++q) split_pack[q] = __builtin_amdgcn_readfirstlane(wt->split_pack[q]);
     // the lane that owns the wire's last cell (Neumann boundary, wire.py:95)
     const bool owns_last = (n >= 2) && (n - 1 >= cbase) && (n - 1 < cbase + C);
+    const int t_last = (n - 1 - cbase) >> 3;  // the tile of that cell in the owning lane (its last position, where the tile is regular)
 
     const bool tracing = WEDM_TRACING(k);
     int trace_next = k.trace_next, trace_slot = k.trace_slot;
@@ -1239,7 +1309,7 @@ __global__ void __launch_bounds__(256, 2) wedm_step_stream(const KArgs k) {
                     // the wire's end cells, where a regular tile holds one (kind_ne / kind_nj): cell 0 stays at the spool
                     // temperature; the last cell is kept out of the maximum here and patched after the walk
                     tn[0] = (c == 0 && t == 0) ? spool : tn[0];
-                    const float last_v = (owns_last && t == n_tiles - 1) ? spool : tn[7];
+                    const float last_v = (owns_last && t == t_last) ? spool : tn[7];
 #pragma unroll
                     for (int u = 0; u < 8; ++u) col[(j + u) * 256] = tn[u];
                     if (last) {  // the launch's last microsecond: the tile also goes straight to global memory
@@ -1527,6 +1597,10 @@ __global__ void __launch_bounds__(256, 2) wedm_step_packed(const KArgs k) {
         return 0;
     };
     const int own_last = (n >= 2) ? owner(n - 1) : 0;
+    // the tile of that cell: a regular tile holds it only as the last cell of chunk B (chunk A's would be followed by
+    // cells past the wire's end in the same tile), and not necessarily in the chunk's LAST tile (a further, partial tile
+    // of cells past the end may follow)
+    const int t_last = (n - 1 - baseB) >> 3;
     // tail cells of the two virtual chunks (see wedm_step_fused): bits per tail cell q and chunk v at 4 (2 q + v):
     // zone, contacts, interior, valid
     const int tail = (EXTRA && Cv > 8 && (Cv & 7) >= 1 && (Cv & 7) <= 2) ? (Cv & 7) : 0;
@@ -1667,7 +1741,7 @@ __global__ void __launch_bounds__(256, 2) wedm_step_packed(const KArgs k) {
                     // of lane 0's chunk A and stays at the spool temperature; the last cell is the last cell of the last
                     // lane's chunk B: out of the maximum here, patched after the walk
                     tn[0].x = (c == 0 && t == 0) ? spool : tn[0].x;
-                    const float last_y = (own_last == 2 && t == n_tiles - 1) ? spool : tn[7].y;
+                    const float last_y = (own_last == 2 && t == t_last) ? spool : tn[7].y;
                     float m0 = fmax_gt(tn[0].x, tn[0].y), m1 = fmax_gt(tn[1].x, tn[1].y);
                     if (!FROZEN || !s.done) {
 #pragma unroll
@@ -1700,7 +1774,7 @@ __global__ void __launch_bounds__(256, 2) wedm_step_packed(const KArgs k) {
                     if (joule_wave) tile8_staged<f2, true, true>(old, tn, g.k, g.tuf, cv, tdiel, ps.adv, jv, alpha, tref);
                     else tile8_staged<f2, false, true>(old, tn, g.k, g.tuf, cv, tdiel, ps.adv, jv, alpha, tref);
                     tn[0].x = (c == 0 && t == 0) ? spool : tn[0].x;
-                    const float last_y = (own_last == 2 && t == n_tiles - 1) ? spool : tn[7].y;
+                    const float last_y = (own_last == 2 && t == t_last) ? spool : tn[7].y;
                     if (!FROZEN || !s.done) {
 #pragma unroll
                         for (int u = 0; u < 8; ++u) store2(r0 + u, tn[u]);
@@ -1919,6 +1993,15 @@ __global__ void wedm_debug_math_kernel(int32_t kind, const double* a, const doub
         default: break;
     }
     out[i] = r;
+}
+
+// Fills every CU's LDS with `value` (test hook; see wedm_debug_poison_lds): rows of the LDS image that a kernel never
+// stages (cells past a wire's end) then hold a conspicuous value instead of whatever the previous kernel left there.
+__global__ void __launch_bounds__(256) wedm_debug_poison_lds_kernel(float value, int32_t n_floats) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    for (int i = threadIdx.x; i < n_floats; i += 256) lds[i] = value;
+    __syncthreads();
+    if (lds[(threadIdx.x * 97) % n_floats] != value) __builtin_trap();  // keeps the stores observable
 }
 
 // =================================================================== C-ABI
@@ -2579,6 +2662,19 @@ int32_t wedm_debug_math(int32_t kind, const double* a, const double* b, double* 
     if (!a || !out || n <= 0 || kind < 0 || kind > 8) return WEDM_ERR_BAD_ARG;
     hipLaunchKernelGGL(wedm_debug_math_kernel, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)stream, kind, a, b,
                        out, n);
+    return hipGetLastError() == hipSuccess ? WEDM_OK : WEDM_ERR_HIP;
+}
+
+int32_t wedm_debug_poison_lds(float value, void* stream) {
+    int dev = 0, lds = 0, cus = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return WEDM_ERR_HIP;
+    (void)hipDeviceGetAttribute(&lds, hipDeviceAttributeMaxSharedMemoryPerBlock, dev);
+    (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+    if (lds <= 0 || cus <= 0) return WEDM_ERR_HIP;
+    if (hipFuncSetAttribute((const void*)wedm_debug_poison_lds_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess)
+        return WEDM_ERR_HIP;
+    // one block per CU holds the whole LDS; a few rounds so that every CU gets one whatever the dispatch order
+    hipLaunchKernelGGL(wedm_debug_poison_lds_kernel, dim3(4 * cus), dim3(256), (size_t)lds, (hipStream_t)stream, value, lds / 4);
     return hipGetLastError() == hipSuccess ? WEDM_OK : WEDM_ERR_HIP;
 }
 

@@ -43,3 +43,20 @@ def orc():
 @pytest.fixture(scope="session")
 def golden_dir():
     return ROOT / "tests" / "golden"
+
+
+@pytest.fixture(autouse=True)
+def _poisoned_lds(request):
+    """GPU tests start with every compute unit's LDS full of 1e30 (`wedm_debug_poison_lds`): the step kernels never
+    write the rows of their LDS image that lie past a wire's end, and a result that leaned on one would otherwise depend
+    on what the previous test's kernels left there (it did once: a regular tile let the interior-formula value of a
+    last cell, computed from such a row, into the maximum temperature — caught only when the test order changed)."""
+    if "gpu" in request.keywords:
+        import torch
+
+        if torch.cuda.is_available():
+            from sparc_amd import _lib
+
+            assert _lib.load().wedm_debug_poison_lds(1e30, None) == 0
+            torch.cuda.synchronize()
+    yield
