@@ -58,7 +58,7 @@ def test_headline_roofline_recomputes_from_profiles():
     # value, ms_per_step and the kernel duration tell one story; rocprofv3 agrees with the HIP events
     assert b["value"] == pytest.approx(65536 * 1000 / (b["ms_per_step"] * 1e-3), rel=1e-9)
     assert rf["kernel_ms"] <= b["ms_per_step"] * 1.001
-    avg_ms, calls = rocprof_avg_ms("rocprofv3_kernel_stats_config3.csv", "wedm_step_packed<2, false, false>")
+    avg_ms, calls = rocprof_avg_ms("rocprofv3_kernel_stats_config3.csv", "wedm_step_packed<2, false, false, false>")
     assert calls >= 20 and avg_ms == pytest.approx(rf["kernel_ms"], rel=0.03)
     # traffic well above the algorithmic minimum would mean wasted re-reads: T + state in and out + obs = ~102 MB
     assert traffic["hbm_bytes_per_launch"] < 1.2 * 102e6
