@@ -191,7 +191,7 @@ def test_config3_grid_128_segments(variant, lanes):
     check(gpu, cpu, n)
 
 
-@pytest.mark.parametrize("variant,lanes", [(3, 4), (3, 8), (3, 16), (4, 4), (4, 8)])
+@pytest.mark.parametrize("variant,lanes", [(3, 4), (3, 8), (3, 16), (4, 4), (4, 8), (6, 4), (6, 8), (2, 8)])
 def test_fused_kernel_with_ragged_chunks_and_heavy_sparking(variant, lanes):
     """361 segments (not divisible by any lane count), thin wire + I17: Joule heating,
     plasma cells at chunk edges, wire breaks and frozen environments inside live waves."""
@@ -208,9 +208,32 @@ def test_fused_kernel_with_ragged_chunks_and_heavy_sparking(variant, lanes):
         env.state.wire_unwinding_velocity[::7] = 0.0   # mixed advection inside a wave
         env.step_many(a, 700)
     check(gpu, cpu, n)
-    want = {3: f"wedm_step_fused<{lanes}>", 4: f"wedm_step_packed<{lanes}>"}[variant]
+    want = {3: f"wedm_step_fused<{lanes}>", 4: f"wedm_step_packed<{lanes}>", 6: f"wedm_step_stream<{lanes}>",
+            2: f"wedm_step_lanes<{lanes}>"}[variant]
     assert want in gpu._backend.last_kernel()
     assert bool(gpu.state.is_wire_broken.any()) and not bool(gpu.state.is_wire_broken.all())
+
+
+@pytest.mark.parametrize("variant,lanes", [(4, 2), (3, 4), (6, 4), (2, 4), (1, 0)])
+def test_last_cell_closing_a_full_tile_that_a_partial_tile_follows(variant, lanes):
+    """169 segments in chunks of 43 cells: the wire's last cell (168 = 129 + 39) closes the fifth full tile of the last
+    chunk, and a sixth tile of three cells past the wire's end follows.  The regular-tile code must keep that cell out
+    of the maximum although it is not in the chunk's last tile (it once did not: the value computed from a never-staged
+    LDS row broke wires at t = 3 us whenever the previous kernel had left something implausible there; the GPU tests
+    poison the LDS for that reason)."""
+    n = 160
+    kw = dict(config=EnvironmentConfig(workpiece_height=24.5, target_cutting_distance=5000.0),
+              wire_params=WireModuleParameters(segment_len=0.5))
+    gpu, cpu = make_pair(n, **kw)
+    assert gpu.n_segments == 169
+    gpu.set_kernel(variant, lanes)
+    both((gpu, cpu), lambda e: (e.reset(seed=23), close_gap(e, 24.0, 10.0)))
+    for env in (gpu, cpu):
+        a = env.make_action(0.1, 80.0, 9, 3.0, 40.0)
+        env.step_many(a, 1)
+        env.step_many(a, 1500)
+    check(gpu, cpu, n)
+    assert int(gpu.state.spark_count.sum()) > 100 and not bool(gpu.state.is_wire_broken.any())
 
 
 def test_per_environment_geometry_config5():
