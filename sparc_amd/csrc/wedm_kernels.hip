@@ -1,26 +1,28 @@
 // wedm_kernels.hip — gfx950 kernels + the C-ABI of include/wedm_hip.h.
 //
-// Kernels
-//   wedm_step_global : one lane per environment, wire temperature walked in place in
-//                      global memory (layout T[seg][env] -> every row access is a
-//                      256-B coalesced wave transaction).  One HBM/L2 pass per
-//                      microsecond; used for n_substeps == 1 (the reference's step()).
-//   wedm_step_lanes<L>: any geometry (one (h, d) pair per environment: BASELINE config 5).
-//                      L lanes per environment, wire chunks in LDS, every cell on the
-//                      predicated formula with the lane's own indices.
-//   wedm_step_fused<L>: the throughput kernel for uniform geometry.  L lanes share one
-//                      environment: the wire is cut into L chunks, chunk c of environment
-//                      el lives in LDS column (el*L + c) as [cell j][256 lanes] (lane-linear
-//                      -> conflict-free), halos are read from the neighbour lane's column
-//                      before any store of the step (wave lock-step, no barrier).  The
-//                      scalar physics runs redundantly in the L lanes (bit-identical
-//                      inputs -> bit-identical results).  The wire walk follows a
-//                      host-built, wave-uniform SEGMENT TABLE: between two breakpoints
-//                      (contact / zone / boundary indices mapped into chunk space) every
-//                      lane applies the same formula, so the inner loop is 13 float32
-//                      VALU ops + 1 ds_read + 1 ds_write per cell with no per-cell
-//                      predicate; the plasma cell is patched outside the loop.
+// Kernels (DESIGN.md section 4 has the table with what binds each of them)
+//   wedm_step_global : one lane per environment, wire temperature walked in place in global memory (layout
+//                      T[seg][env] -> every row access is a 256-B coalesced wave transaction); the float64-stencil and
+//                      variate-injection modes, and wires no LDS kernel fits.
+//   wedm_step_split  : single microseconds where the stream kernel does not fit: the wire cut over the four waves of
+//                      a block, in place in global memory.
+//   wedm_step_stream<L>: single microseconds (the reference's step() cadence), uniform geometry: the whole chunk of a
+//                      lane requested up front into registers, one tile walk in LDS, no barrier.
+//   wedm_step_lanes<L>: any geometry (one (h, d) pair per environment: BASELINE config 5).  L lanes per environment,
+//                      wire chunks in LDS; interior formula stage-major with per-cell coefficients from the lane's own
+//                      indices, boundary / plasma cells patched (the per-cell predicated walk remains as fallback).
+//   wedm_step_fused<L>: uniform geometry.  L lanes share one environment: the wire is cut into L chunks, chunk c of
+//                      environment el lives in LDS column (el*L + c) as [cell j][256 lanes] (lane-linear ->
+//                      conflict-free), halos are read from the neighbour lane's column before any store of the step
+//                      (wave lock-step, no barrier).  The scalar physics runs redundantly in the L lanes (bit-identical
+//                      inputs -> bit-identical results).  The walk follows a host-built, wave-uniform TILE TABLE
+//                      (build_walk): regular tiles of 8 cells run stage-major without a per-cell predicate; boundary,
+//                      plasma and tail cells are patched from values computed before the walk.
+//   wedm_step_packed<L>: the same with two chunks per lane advanced together in float2 registers (the headline kernel).
 //   wedm_reset_kernel: WireEDMEnv.reset for a masked subset.
+// The packed / fused kernels exist in several instantiations (signal trace point, FROZEN_OK for autoreset handles,
+// N1 / EXTRA for tile tables with one-change tiles or short tails): code that costs the other launches 1-2 % by its
+// mere presence lives in its own instantiation, chosen per handle in plan_launch().
 //
 // Build: hipcc --offload-arch=gfx950 -O3 -ffp-contract=off -fno-fast-math (see
 // __graft_entry__.build()).  -ffp-contract=off is part of the numerics contract.
@@ -53,9 +55,8 @@ using namespace wedm;
 
 // Wave-uniform description of one step's walk over a chunk of C cells (see build_walk()).
 // Cell j of chunk c is wire segment i = c*C + j.  The chunk is walked in ceil(C/8) tiles of 8
-// cells.  A NORMAL tile holds 8 interior cells (1 <= i <= n-2) with the same zone / contact
-// membership in every chunk; anything else (boundary cells, a breakpoint inside the tile, the
-// padded tail) is a SPECIAL tile that looks its flags up per cell.
+// cells, each of a kind that is the same for every chunk (TILE_N / TILE_B / TILE_S and the masks
+// below that let further tiles take the regular code).
 #define WEDM_MAX_C 160  // 160 KB LDS / (256 lanes * 4 B)
 #define WEDM_MAX_TILES (WEDM_MAX_C / 8 + 1)
 struct WalkTable {
