@@ -401,7 +401,10 @@ __device__ __forceinline__ void store_env(const ColdRef cold, int64_t e, const E
 // only the rows a microsecond READS are loaded and only the rows it can have CHANGED are stored.
 // Write-only rows (assigned by every step before any use): last_crater, cavity, tmax, the control-step
 // flag; with the ignition module enabled also current and is_short_circuit.
-__device__ __forceinline__ void load_env_inputs(const ColdRef cold, int64_t e, Env& v, bool ignition_on) {
+// h64: when given, the two convection coefficients are handed back as loaded (float64) and v.h_base / v.h_zone are left for
+// the caller to convert LATER: the conversion is the first use of loaded data, and placed here it made the compiler wait
+// for the state rows (a whole memory round trip) before the single-microsecond kernel could request its wire rows.
+__device__ __forceinline__ void load_env_inputs(const ColdRef cold, int64_t e, Env& v, bool ignition_on, double* h64 = nullptr) {
     const ColdPtr c = cold.get();
     const int64_t stride = c->s.stride;
     const struct { const double* f64; const int32_t* i32; const int8_t* i8; } s{c->s.f64, c->s.i32, c->s.i8};
@@ -415,7 +418,8 @@ __device__ __forceinline__ void load_env_inputs(const ColdRef cold, int64_t e, E
     v.on = *WEDM_ROW(s.f64, WEDM_F_ON_TIME); v.off = *WEDM_ROW(s.f64, WEDM_F_OFF_TIME);
     v.tpos = *WEDM_ROW(s.f64, WEDM_F_TARGET_POS); v.unwind = *WEDM_ROW(s.f64, WEDM_F_UNWIND_VEL);
     v.vacc = *WEDM_ROW(s.f64, WEDM_F_VOLT_ACC);
-    v.h_base = (float)*WEDM_ROW(s.f64, WEDM_F_H_BASE); v.h_zone = (float)*WEDM_ROW(s.f64, WEDM_F_H_ZONE);
+    if (h64) { h64[0] = *WEDM_ROW(s.f64, WEDM_F_H_BASE); h64[1] = *WEDM_ROW(s.f64, WEDM_F_H_ZONE); v.h_base = 0.0f; v.h_zone = 0.0f; }
+    else { v.h_base = (float)*WEDM_ROW(s.f64, WEDM_F_H_BASE); v.h_zone = (float)*WEDM_ROW(s.f64, WEDM_F_H_ZONE); }
     v.time = *WEDM_ROW(s.i32, WEDM_I_TIME); v.tss = *WEDM_ROW(s.i32, WEDM_I_SINCE_SERVO);
     v.tsov = *WEDM_ROW(s.i32, WEDM_I_SINCE_OPEN_V); v.tsi = *WEDM_ROW(s.i32, WEDM_I_SINCE_IGNITION);
     v.tse = *WEDM_ROW(s.i32, WEDM_I_SINCE_SPARK_END); v.dur = *WEDM_ROW(s.i32, WEDM_I_SPARK_DUR);

@@ -1164,9 +1164,10 @@ __global__ void __launch_bounds__(256, 2) wedm_step_stream(const KArgs k) {
     Geom g;
     Persist ps{0.0f, 0.0f, 0.0f, 0};
     load_geom(k.hot, cold, live ? e : 0, g);
+    double h64[2] = {0.0, 0.0};  // convection coefficients as loaded; converted after the wire rows are requested
     if (live) {
         if (TRACE) load_env(cold, e, s);  // frozen environments are sampled too: every row
-        else load_env_inputs(cold, e, s, !k.hot.disable_ignition);
+        else load_env_inputs(cold, e, s, !k.hot.disable_ignition, h64);
     } else {
         s.done = 1; s.unwind = 0.0; s.h_base = 0.0f; s.h_zone = 0.0f;
     }
@@ -1190,6 +1191,11 @@ __global__ void __launch_bounds__(256, 2) wedm_step_stream(const KArgs k) {
             off += (j < jmax) ? rowb : 0u;
         }
     }
+    // nothing that USES a loaded state row may be scheduled above this point: the first such use (the compiler hoisted
+    // the test of the DONE flag) made the wave wait for the state rows -- a whole memory round trip -- before it had
+    // requested its wire rows
+    __builtin_amdgcn_sched_barrier(0);
+    if (!TRACE && live) { s.h_base = (float)h64[0]; s.h_zone = (float)h64[1]; }
     WEDM_S2_STAMP(0);  // everything requested
     // next-step autoreset (all L lanes of the environment agree)
     const bool reinit = live && s.done && WEDM_AUTORESET_SCALAR(cold);
