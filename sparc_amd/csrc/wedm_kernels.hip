@@ -1938,6 +1938,30 @@ __global__ void __launch_bounds__(256, 2) wedm_step_packed(const KArgs k) {
 }
 
 
+// ------------------------------------------------------------ translation-unit parts (build time only)
+// The packed and fused kernels exist in 32 and 40 instantiations and take hipcc two minutes in one translation unit.
+// __graft_entry__.build_hip() compiles this file three times in parallel: -DWEDM_PART=1 emits the packed instantiations
+// only, -DWEDM_PART=2 the fused ones, -DWEDM_PART=0 everything else (host code, the other kernels) with the two families
+// declared `extern template`; the three objects link into the one shared library.  Without -DWEDM_PART the file is one
+// self-contained translation unit (the diagnostic builds of tools/ use it that way).
+#define WEDM_BOOLS3(X, L) X(L, false, false, false) X(L, false, false, true) X(L, false, true, false) X(L, false, true, true) \
+                          X(L, true, false, false) X(L, true, false, true) X(L, true, true, false) X(L, true, true, true)
+#define WEDM_PACKED_LIST(X) WEDM_BOOLS3(X, 1) WEDM_BOOLS3(X, 2) WEDM_BOOLS3(X, 4) WEDM_BOOLS3(X, 8)
+#define WEDM_FUSED_LIST(X) WEDM_BOOLS3(X, 1) WEDM_BOOLS3(X, 2) WEDM_BOOLS3(X, 4) WEDM_BOOLS3(X, 8) WEDM_BOOLS3(X, 16)
+#define WEDM_INST_PACKED(L, a, b, c) template __global__ void wedm_step_packed<L, a, b, c>(const KArgs);
+#define WEDM_INST_FUSED(L, a, b, c) template __global__ void wedm_step_fused<L, a, b, c>(const KArgs);
+#define WEDM_EXT_PACKED(L, a, b, c) extern template __global__ void wedm_step_packed<L, a, b, c>(const KArgs);
+#define WEDM_EXT_FUSED(L, a, b, c) extern template __global__ void wedm_step_fused<L, a, b, c>(const KArgs);
+#if defined(WEDM_PART) && WEDM_PART == 1
+WEDM_PACKED_LIST(WEDM_INST_PACKED)
+#elif defined(WEDM_PART) && WEDM_PART == 2
+WEDM_FUSED_LIST(WEDM_INST_FUSED)
+#else
+#if defined(WEDM_PART)
+WEDM_PACKED_LIST(WEDM_EXT_PACKED)
+WEDM_FUSED_LIST(WEDM_EXT_FUSED)
+#endif
+
 __global__ void __launch_bounds__(256)
 wedm_reset_kernel(const wedm_params p, const wedm_state_ptrs s, int32_t num_envs, int32_t n_seg_max,
                   const uint8_t* mask, uint32_t key_lo, uint32_t key_hi, int32_t reseed) {
@@ -2686,3 +2710,5 @@ int32_t wedm_debug_poison_lds(float value, void* stream) {
 }
 
 }  // extern "C"
+
+#endif  // WEDM_PART
