@@ -24,7 +24,16 @@
  * State layout: struct-of-arrays, field-major, environment-minor.  Field `f` of
  * environment `e` lives at  block[f * stride + e]  so that the 64 lanes of a
  * wavefront (64 consecutive environments) read 64 consecutive elements.
- * The wire temperature is  T[seg * stride + e]  (float32).
+ * The wire temperature (float32) is QUAD-INTERLEAVED (ABI v4): four consecutive
+ * segments of one environment form one 16-byte word, words are environment-minor,
+ *     T[((seg >> 2) * stride + e) * 4 + (seg & 3)]          (WEDM_T_INDEX below),
+ * i.e. T[ceil(n_seg_max / 4)][stride][4].  A lane that owns a run of consecutive
+ * segments of one environment loads / stores it 16 bytes at a time
+ * (global_load_dwordx4), and the 64 lanes of a wavefront still touch contiguous
+ * 1-KB runs.  The cells of the last word past n_seg_max are padding: written at
+ * reset (spool temperature), never read into a result, never rewritten by a step.
+ * (ABI v3 had T[seg][env]: one dword per lane and instruction, which is what bound
+ * the one-launch-per-microsecond kernels: DESIGN.md section 4.2.)
  */
 #ifndef WEDM_HIP_H
 #define WEDM_HIP_H
@@ -35,7 +44,12 @@
 extern "C" {
 #endif
 
-#define WEDM_ABI_VERSION 3
+#define WEDM_ABI_VERSION 4
+
+/* element index of wire segment `seg` of environment `e` in the T block */
+#define WEDM_T_INDEX(seg, stride, e) ((((int64_t)((seg) >> 2) * (int64_t)(stride) + (int64_t)(e)) << 2) + ((seg) & 3))
+/* 16-byte words (rows of the T block) a wire of n_seg_max segments occupies */
+#define WEDM_T_QUADS(n_seg_max) (((n_seg_max) + 3) >> 2)
 
 /* ------------------------------------------------------------------ status */
 typedef enum wedm_status {
@@ -239,7 +253,7 @@ typedef struct wedm_state_ptrs {
     double* f64;        /* [WEDM_F64_COUNT][stride] */
     int32_t* i32;       /* [WEDM_I32_COUNT][stride] */
     int8_t* i8;         /* [WEDM_I8_COUNT ][stride] */
-    float* T;           /* [n_seg_max][stride]      */
+    float* T;           /* [WEDM_T_QUADS(n_seg_max)][stride][4], see WEDM_T_INDEX */
     float* obs;         /* [obs_dim][stride] or NULL */
     int64_t stride;     /* >= num_envs, multiple of 64 recommended */
     double* stats;      /* [WEDM_STAT_COUNT][stride] or NULL (statistics not kept) */

@@ -993,7 +993,7 @@ static void gather_env(const wedm_state_ptrs* s, int64_t e, wedm_oracle_env* v) 
     v->is_wire_broken = I8(WEDM_B_WIRE_BROKEN); v->is_target_reached = I8(WEDM_B_TARGET_REACHED);
     v->error = I8(WEDM_B_ERROR);
     v->dielectric_temperature = v->c.dielectric_temperature;
-    for (int i = 0; i < v->c.n_seg; ++i) v->T[i] = s->T[(int64_t)i * stride + e];
+    for (int i = 0; i < v->c.n_seg; ++i) v->T[i] = s->T[WEDM_T_INDEX(i, stride, e)];  /* quad-interleaved block, include/wedm_hip.h */
 }
 
 static void scatter_env(const wedm_state_ptrs* s, int64_t e, const wedm_oracle_env* v, int done) {
@@ -1027,7 +1027,7 @@ static void scatter_env(const wedm_state_ptrs* s, int64_t e, const wedm_oracle_e
     I8(WEDM_B_WIRE_BROKEN) = (int8_t)v->is_wire_broken; I8(WEDM_B_TARGET_REACHED) = (int8_t)v->is_target_reached;
     I8(WEDM_B_DONE) = (int8_t)done; I8(WEDM_B_CTRL_STEP) = (int8_t)v->last_ctrl_step;
     I8(WEDM_B_ERROR) = (int8_t)(v->error & 1);
-    for (int i = 0; i < v->c.n_seg; ++i) s->T[(int64_t)i * stride + e] = v->T[i];
+    for (int i = 0; i < v->c.n_seg; ++i) s->T[WEDM_T_INDEX(i, stride, e)] = v->T[i];
 }
 
 /* observation columns written at control steps (build-defined; the reference's
@@ -1124,7 +1124,7 @@ int32_t wedm_oracle_step_batch(const wedm_params* p, const wedm_state_ptrs* s, c
                 /* wedm_params.autoreset: next-step autoreset inside the call = wedm_reset(mask = DONE, reseed = 0)
                  * for this environment (all n_seg_max wire rows at the spool temperature, observation zeroed) */
                 reset_env_rows(p, s, e, 0, 0);
-                for (int i = 0; i < n_seg_max; ++i) s->T[(int64_t)i * stride + e] = (float)p->spool_T;
+                for (int i = 0; i < 4 * WEDM_T_QUADS(n_seg_max); ++i) s->T[WEDM_T_INDEX(i, stride, e)] = (float)p->spool_T;
                 if (s->obs)
                     for (int q = 0; q < p->obs_dim; ++q) s->obs[(int64_t)q * stride + e] = 0.0f;
             }

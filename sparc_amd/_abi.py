@@ -9,8 +9,14 @@ from __future__ import annotations
 import ctypes as C
 import enum
 
-ABI_VERSION = 3
+ABI_VERSION = 4
 MAX_MODE = 19
+
+
+def t_quads(n_seg_max: int) -> int:
+    """``WEDM_T_QUADS``: 16-byte words (rows of the quad-interleaved T block) a wire of n_seg_max segments occupies."""
+    return (int(n_seg_max) + 3) >> 2
+
 
 # status codes -----------------------------------------------------------------
 OK = 0

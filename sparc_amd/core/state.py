@@ -1,9 +1,11 @@
 """``BatchedEDMState`` — the reference's ``EDMState`` (core/state.py:25-91) with a
 leading batch dimension, stored struct-of-arrays for the kernels.
 
-Three field-major blocks hold every mutable scalar (float64 / int32 / int8) and
-one ``[n_seg][stride]`` float32 block holds the wire temperature, environment-minor,
-so that a wavefront's 64 lanes read 64 consecutive elements.  Attribute access keeps
+Three field-major blocks hold every mutable scalar (float64 / int32 / int8), environment-minor,
+so that a wavefront's 64 lanes read 64 consecutive elements; the wire temperature (float32) is
+quad-interleaved, ``T[n_seg / 4][stride][4]`` (four consecutive segments of one environment in one
+16-byte word, include/wedm_hip.h), so that a lane moves its run of segments 16 bytes at a time.
+Attribute access keeps
 the reference's names: ``state.workpiece_position`` is a length-``num_envs`` tensor
 view into the float64 block; assigning to it writes through
 (``state.workpiece_position = 70.0`` works like it does on the reference's state).
@@ -49,6 +51,77 @@ _FIELDS = {
 }
 
 
+_BINARY_DUNDERS = ("add", "sub", "mul", "truediv", "radd", "rsub", "rmul", "eq", "ne", "lt", "le", "gt", "ge")
+
+
+class WireTemperature:
+    """``state.wire_temperature``: the ``[num_envs, n_seg]`` face of the quad-interleaved ``T`` block.
+
+    The block's layout (``T[seg >> 2][env][seg & 3]``) cannot be expressed as ONE strided 2-D view, so this small
+    proxy keeps the reference's indexing on both sides: reading (``wt[e]``, ``wt[2:5, 10:20]``, ``wt.cpu()``, any
+    torch function) gathers a ``[num_envs, n_seg]`` tensor; writing (``wt[: n // 2, 180:186] = 1600.0``,
+    ``wt.copy_(x)``, ``wt.fill_(v)``) gathers, assigns and scatters back, so assignments write through as they
+    do on the reference's NumPy array.  ``wt.quads`` is the zero-copy ``[num_envs, n_seg / 4, 4]`` view."""
+
+    def __init__(self, T: torch.Tensor, num_envs: int, n_seg: int):
+        self._T, self._n, self._s = T, num_envs, n_seg
+
+    @property
+    def quads(self) -> torch.Tensor:
+        return self._T[:, : self._n].permute(1, 0, 2)
+
+    def tensor(self) -> torch.Tensor:
+        return self.quads.reshape(self._n, -1)[:, : self._s]
+
+    def _scatter(self, full: torch.Tensor) -> None:
+        q = self.quads
+        flat = q.reshape(self._n, -1)
+        flat[:, : self._s] = full
+        q.copy_(flat.reshape(q.shape))
+
+    shape = property(lambda self: torch.Size((self._n, self._s)))
+    dtype = property(lambda self: self._T.dtype)
+    device = property(lambda self: self._T.device)
+
+    def size(self, dim=None):
+        return self.shape if dim is None else self.shape[dim]
+
+    def __len__(self):
+        return self._n
+
+    def __getitem__(self, idx):
+        return self.tensor()[idx]
+
+    def __setitem__(self, idx, value) -> None:
+        full = self.tensor()
+        full[idx] = value
+        self._scatter(full)
+
+    def copy_(self, value):
+        self._scatter(torch.as_tensor(value, dtype=torch.float32, device=self._T.device).expand(self._n, self._s))
+        return self
+
+    def fill_(self, value):
+        return self.copy_(torch.as_tensor(float(value)))
+
+    def __array__(self, dtype=None, copy=None):
+        a = self.tensor().cpu().numpy()
+        return a if dtype is None else a.astype(dtype)
+
+    def __getattr__(self, name):  # everything else (cpu, numpy, clone, max, mean, ...) on the gathered tensor
+        return getattr(self.tensor(), name)
+
+    @classmethod
+    def __torch_function__(cls, func, types, args=(), kwargs=None):
+        conv = lambda a: a.tensor() if isinstance(a, cls) else a
+        return func(*[conv(a) for a in args], **{k: conv(v) for k, v in (kwargs or {}).items()})
+
+
+for _op in _BINARY_DUNDERS:
+    setattr(WireTemperature, f"__{_op}__", (lambda op: lambda self, other: getattr(self.tensor(), f"__{op}__")(
+        other.tensor() if isinstance(other, WireTemperature) else other))(_op))
+
+
 class BatchedEDMState:
     def __init__(self, num_envs: int, n_seg_max: int, obs_dim: int, device, crater_log_capacity: int = 0):
         stride = (num_envs + 63) // 64 * 64
@@ -61,7 +134,7 @@ class BatchedEDMState:
         object.__setattr__(self, "i32", torch.zeros((_abi.I32_COUNT, stride), dtype=torch.int32, **kw))
         object.__setattr__(self, "i8", torch.zeros((_abi.I8_COUNT, stride), dtype=torch.int8, **kw))
         object.__setattr__(self, "b", self.i8.view(torch.bool))  # zero-copy 0/1 view of the flags
-        object.__setattr__(self, "T", torch.zeros((n_seg_max, stride), dtype=torch.float32, **kw))
+        object.__setattr__(self, "T", torch.zeros((_abi.t_quads(n_seg_max), stride, 4), dtype=torch.float32, **kw))
         object.__setattr__(self, "obs", torch.zeros((max(obs_dim, 1), stride), dtype=torch.float32, **kw))
         # running statistics the kernels accumulate (material.py:207-227)
         object.__setattr__(self, "stats", torch.zeros((_abi.STAT_COUNT, stride), dtype=torch.float64, **kw))
@@ -102,14 +175,14 @@ class BatchedEDMState:
             else:
                 view.copy_(torch.as_tensor(value, dtype=view.dtype, device=view.device).expand_as(view))
         elif name == "wire_temperature":
-            self.wire_temperature.copy_(torch.as_tensor(value, dtype=torch.float32, device=self.device))
+            self.wire_temperature.copy_(value.tensor() if isinstance(value, WireTemperature) else value)
         else:
             raise AttributeError(f"BatchedEDMState has no writable field {name!r}")
 
     @property
-    def wire_temperature(self) -> torch.Tensor:
-        """``[num_envs, n_seg]`` view (strided: storage is segment-major)."""
-        return self.T[:, : self.num_envs].t()
+    def wire_temperature(self) -> WireTemperature:
+        """``[num_envs, n_seg]`` face of the quad-interleaved block: reads gather, writes go through (`WireTemperature`)."""
+        return WireTemperature(self.T, self.num_envs, self.n_seg_max)
 
     @property
     def spark_status(self):

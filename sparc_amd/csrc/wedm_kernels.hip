@@ -1,9 +1,10 @@
 // wedm_kernels.hip — gfx950 kernels + the C-ABI of include/wedm_hip.h.
 //
 // Kernels (DESIGN.md section 4 has the table with what binds each of them)
-//   wedm_step_global : one lane per environment, wire temperature walked in place in global memory (layout
-//                      T[seg][env] -> every row access is a 256-B coalesced wave transaction); the float64-stencil and
-//                      variate-injection modes, and wires no LDS kernel fits.
+//   wedm_step_global : one lane per environment, wire temperature walked in place in global memory; the float64-stencil
+//                      and variate-injection modes, and wires no LDS kernel fits.
+// The wire block is quad-interleaved, T[seg >> 2][env][seg & 3] (include/wedm_hip.h, ABI v4): a lane that owns a run of
+// segments of one environment moves it with global_load / store_dwordx4, a wavefront still touches contiguous 1-KB runs.
 //   wedm_step_split  : single microseconds where the stream kernel does not fit: the wire cut over the four waves of
 //                      a block, in place in global memory.
 //   wedm_step_stream<L>: single microseconds (the reference's step() cadence), uniform geometry: the whole chunk of a
@@ -139,12 +140,50 @@ __device__ __forceinline__ ColdRef kernarg_cold() {
     }
 
 // ------------------------------------------------------------ T accessors
+typedef float f4v __attribute__((ext_vector_type(4)));
+
+// One environment's wire in the quad-interleaved block T[seg >> 2][env][seg & 3] (WEDM_T_INDEX).
 struct GlobalT {
-    float* base;     // &T[0][e]
-    int64_t stride;  // elements between consecutive segments
-    __device__ __forceinline__ float ld(int i) const { return base[(int64_t)i * stride]; }
-    __device__ __forceinline__ void st(int i, float v) const { base[(int64_t)i * stride] = v; }
+    float* base;      // &T[0][e][0]
+    int64_t qstride;  // elements between consecutive quads of one environment (4 * stride)
+    __device__ __forceinline__ float ld(int i) const { return base[(int64_t)(i >> 2) * qstride + (i & 3)]; }
+    __device__ __forceinline__ void st(int i, float v) const { base[(int64_t)(i >> 2) * qstride + (i & 3)] = v; }
+    __device__ __forceinline__ f4v ldq(int q) const { return *(const f4v*)(base + (int64_t)q * qstride); }
+    __device__ __forceinline__ void stq(int q, f4v v) const { *(f4v*)(base + (int64_t)q * qstride) = v; }
 };
+__device__ __forceinline__ GlobalT global_wire(float* T, int64_t stride, int64_t e) { return GlobalT{T + 4 * e, 4 * stride}; }
+
+// Block-cooperative copy of the wire cells [0, n) of the block's 256 / L environments between the quad-interleaved
+// block in HBM and the kernel's LDS image, 16 bytes per lane and instruction (a wave touches contiguous runs of
+// 64 x 16 B).  `slot(i)` = LDS float offset of wire cell i for the block's first environment (the kernel's own
+// chunk / row mapping); environment slot `sel` adds sel * L.  Cells of the last quad past n are padding: not copied.
+template <int L, bool TO_LDS, class Slot>
+__device__ __forceinline__ void copy_wire(float* T, int64_t stride, int64_t e0, int num_envs, int n, int tid, float* lds, Slot slot) {
+    constexpr int EPB = 256 / L;
+    const int qr = tid / EPB, sel = tid % EPB;  // L quads per iteration
+    if (e0 + sel >= num_envs) return;
+    float* const base = T + 4 * (e0 + sel);
+    const int64_t qstride = 4 * stride;
+    const int nq = (n + 3) >> 2;
+    for (int q = qr; q < nq; q += L) {
+        float* const g = base + (int64_t)q * qstride;
+        if (TO_LDS) {
+            const f4v v = *(const f4v*)g;
+#pragma unroll
+            for (int k = 0; k < 4; ++k)
+                if (4 * q + k < n) lds[slot(4 * q + k) + sel * L] = v[k];
+        } else if (4 * q + 3 < n) {
+            f4v v;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) v[k] = lds[slot(4 * q + k) + sel * L];
+            *(f4v*)g = v;
+        } else {
+#pragma unroll
+            for (int k = 0; k < 4; ++k)
+                if (4 * q + k < n) g[k] = lds[slot(4 * q + k) + sel * L];
+        }
+    }
+}
 
 // One in-place pass of wire.py:58-123 over the lane's wire.  Tiles of 8 cells: the 8
 // "next" temperatures are loaded before any of the tile's stores, so every cell sees
@@ -218,10 +257,10 @@ __global__ void __launch_bounds__(256) wedm_step_global(const KArgs k) {
     const bool reinit = s.done && WEDM_AUTORESET(cold);
     const bool frozen = s.done && !reinit;  // terminated and not reset: nothing to step
     if (frozen && !WEDM_TRACING(k)) return;
-    GlobalT T{cold->s.T + e, cold->s.stride};
+    const GlobalT T = global_wire(cold->s.T, cold->s.stride, e);
     if (reinit) {  // next-step autoreset: wedm_reset for this environment, inside the launch
         reinit_env(cold, e, s, true);
-        for (int i = 0; i < k.n_seg_max; ++i) T.st(i, k.hot.spool);
+        for (int q = 0; q < WEDM_T_QUADS(k.n_seg_max); ++q) T.stq(q, f4v{k.hot.spool, k.hot.spool, k.hot.spool, k.hot.spool});
     }
     s.ipk = s.done ? 0.0 : peak_current(cold, s.mode);
     Geom g;
@@ -282,15 +321,16 @@ __global__ void __launch_bounds__(256) wedm_step_split(const KArgs k) {
     Geom g;
     load_geom(k.hot, cold, live ? e : 0, g);
     const int n = g.n_seg;
-    const int C = (k.n_seg_max + WEDM_QL - 1) / WEDM_QL;
+    // cells per wave: a multiple of 4, so that every wave's chunk starts on a 16-byte word of the quad-interleaved block
+    const int C = ((k.n_seg_max + 4 * WEDM_QL - 1) / (4 * WEDM_QL)) * 4;
     const int i0 = c * C, i1 = (i0 + C < n) ? i0 + C : n;  // this lane's cells [i0, i1) (may be empty)
-    GlobalT T{cold->s.T + (live ? e : 0), stride};
+    const GlobalT T = global_wire(cold->s.T, stride, live ? e : 0);
 
     // next-step autoreset: every wave of the block sees the environment's DONE flag
     const bool reinit = live && WEDM_AUTORESET(cold) && cold->s.i8[(int64_t)WEDM_B_DONE * stride + e] != 0;
-    if (reinit) {  // this lane's rows of the wire (all n_seg_max rows, as wedm_reset does)
-        const int f1 = (i0 + C < k.n_seg_max) ? i0 + C : k.n_seg_max;
-        for (int i = i0; i < f1; ++i) T.st(i, spool);
+    if (reinit) {  // this lane's words of the wire (all of the block's rows, as wedm_reset does)
+        const int qe = (i0 + C) >> 2, qn = WEDM_T_QUADS(k.n_seg_max);
+        for (int q = i0 >> 2; q < (qe < qn ? qe : qn); ++q) T.stq(q, f4v{spool, spool, spool, spool});
     }
     Env s;
     Persist ps{0.0f, 0.0f, 0.0f, 0};
@@ -333,29 +373,50 @@ __global__ void __launch_bounds__(256) wedm_step_split(const KArgs k) {
         const bool skip = sh_i[3][el] != 0;
         float tmax = spool;
         if (live && !skip && i0 < i1) {
-            // RB rows per batch of loads, unconditional from a clamped index (no branch between them,
-            // all in flight together).  Stamps show the walk phase itself moving ~7.7 TB/s chip-wide:
-            // what is left is the lock-step of the blocks (all in the scalar phase, then all walking).
+            // RB cells = RB / 4 sixteen-byte words per batch of loads, unconditional from a clamped word index (no branch
+            // between them, all in flight together), plus the first cell after them (right neighbour of the batch's last).
+            // Stamps show the walk phase itself moving ~7.7 TB/s chip-wide: what is left is the lock-step of the blocks
+            // (all in the scalar phase, then all walking).
             constexpr int RB = WEDM_SPLIT_RB;
+            static_assert(RB % 4 == 0, "a batch is a whole number of 16-byte words");
             float tm1 = halo_l;
+            const int qlast = (i1 - 1) >> 2;
             for (int ib = i0; ib < i1; ib += RB) {
-                float buf[RB + 1];
+                float buf[RB + 1], tn[RB];
 #pragma unroll
-                for (int u = 0; u <= RB; ++u) {
-                    int idx = ib + u;
-                    idx = idx < i1 ? idx : i1 - 1;  // past the chunk: any valid row, the value is not used
-                    buf[u] = T.ld(idx);
+                for (int h = 0; h < RB / 4; ++h) {
+                    int q = (ib >> 2) + h;
+                    q = q < qlast ? q : qlast;  // past the chunk: any valid word, the values are not used
+                    const f4v v = T.ldq(q);
+#pragma unroll
+                    for (int w = 0; w < 4; ++w) buf[4 * h + w] = v[w];
+                }
+                {
+                    int idx = ib + RB;
+                    idx = idx < i1 ? idx : i1 - 1;
+                    buf[RB] = T.ld(idx);
                 }
 #pragma unroll
                 for (int u = 0; u < RB; ++u) {
                     const int i = ib + u;
+                    tn[u] = buf[u];
                     if (i < i1) {
                         const float tp1 = (i + 1 < i1) ? buf[u + 1] : halo_r;
-                        const float tn = (i >= 1) ? stencil_cell(i, n, (i == 1) ? spool : tm1, buf[u], tp1, g, cf, pw, tref, alpha, tdiel)
-                                                  : spool;
-                        T.st(i, tn);
-                        tmax = tn > tmax ? tn : tmax;
+                        tn[u] = (i >= 1) ? stencil_cell(i, n, (i == 1) ? spool : tm1, buf[u], tp1, g, cf, pw, tref, alpha, tdiel)
+                                         : spool;
+                        tmax = tn[u] > tmax ? tn[u] : tmax;
                         tm1 = buf[u];
+                    }
+                }
+#pragma unroll
+                for (int h = 0; h < RB / 4; ++h) {
+                    const int iq = ib + 4 * h;
+                    if (iq + 3 < i1) {
+                        T.stq(iq >> 2, f4v{tn[4 * h], tn[4 * h + 1], tn[4 * h + 2], tn[4 * h + 3]});
+                    } else {  // the wire's last, partial word: the cells past the end are padding and keep their value
+#pragma unroll
+                        for (int w = 0; w < 4; ++w)
+                            if (iq + w < i1) T.st(iq + w, tn[4 * h + w]);
                     }
                 }
             }
@@ -524,19 +585,9 @@ __global__ void __launch_bounds__(256, 2) wedm_step_lanes(const KArgs k) {
     const int nmax = k.n_seg_max;
     const int C = (nmax + L - 1) / L;
     const int64_t stride = cold->s.stride;
-    {
-        const int r = tid / EPB, sel = tid % EPB;
-        int ci = 0, ji = r;
-        while (ji >= C) { ji -= C; ++ci; }
-        const bool ok = e0 + sel < k.num_envs;
-        const float* src = cold->s.T + e0 + sel;
-        for (int i0 = 0; i0 < nmax; i0 += L) {
-            const int i = i0 + r;
-            if (i < nmax && ok) lds[ji * 256 + sel * L + ci] = src[(int64_t)i * stride];
-            ji += L;
-            while (ji >= C) { ji -= C; ++ci; }
-        }
-    }
+    // wire cell i -> chunk i / C, cell i % C -> LDS [cell][256 lanes], lane = environment slot * L + chunk
+    const auto wire_slot = [C](int i) { const int ci = i / C; return (i - ci * C) * 256 + ci; };
+    copy_wire<L, true>(cold->s.T, stride, e0, k.num_envs, nmax, tid, lds, wire_slot);
     __syncthreads();
 
     Env s;
@@ -680,19 +731,7 @@ __global__ void __launch_bounds__(256, 2) wedm_step_lanes(const KArgs k) {
     }
 
     __syncthreads();
-    {
-        const int r = tid / EPB, sel = tid % EPB;
-        int ci = 0, ji = r;
-        while (ji >= C) { ji -= C; ++ci; }
-        const bool ok = e0 + sel < k.num_envs;
-        float* dst = cold->s.T + e0 + sel;
-        for (int i0 = 0; i0 < nmax; i0 += L) {
-            const int i = i0 + r;
-            if (i < nmax && ok) dst[(int64_t)i * stride] = lds[ji * 256 + sel * L + ci];
-            ji += L;
-            while (ji >= C) { ji -= C; ++ci; }
-        }
-    }
+    copy_wire<L, false>(cold->s.T, stride, e0, k.num_envs, nmax, tid, lds, wire_slot);
     if (live && c == 0) {
         if (WEDM_REWARD_ON(cold) && !frozen0) write_reward(cold, e, s);
         store_env(cold, e, s);
@@ -764,20 +803,10 @@ __global__ void __launch_bounds__(256, 2) wedm_step_fused(const KArgs k) {
     const int n = k.hot.n_seg;
     const int64_t stride = cold->s.stride;
 
-    // ---- stage the block's EPB wire columns: coalesced rows of T[seg][env] -> LDS
-    {
-        const int r = tid / EPB, sel = tid % EPB;  // L rows per iteration
-        int ci = 0, ji = r;                        // (chunk, cell) of row i = i0 + r
-        while (ji >= C) { ji -= C; ++ci; }
-        const bool ok = e0 + sel < k.num_envs;
-        const float* src = cold->s.T + e0 + sel;
-        for (int i0 = 0; i0 < n; i0 += L) {
-            const int i = i0 + r;
-            if (i < n && ok) lds[ji * 256 + sel * L + ci] = src[(int64_t)i * stride];
-            ji += L;
-            while (ji >= C) { ji -= C; ++ci; }
-        }
-    }
+    // ---- stage the block's EPB wire columns: 16-byte words of the quad-interleaved block -> LDS
+    // wire cell i -> chunk i / C, cell i % C -> LDS [cell][256 lanes], lane = environment slot * L + chunk
+    const auto wire_slot = [C](int i) { const int ci = i / C; return (i - ci * C) * 256 + ci; };
+    copy_wire<L, true>(cold->s.T, stride, e0, k.num_envs, n, tid, lds, wire_slot);
     __syncthreads();
 
     Env s;
@@ -1089,19 +1118,7 @@ __global__ void __launch_bounds__(256, 2) wedm_step_fused(const KArgs k) {
     WEDM_STAMP_OUT();
 
     __syncthreads();
-    {
-        const int r = tid / EPB, sel = tid % EPB;
-        int ci = 0, ji = r;
-        while (ji >= C) { ji -= C; ++ci; }
-        const bool ok = e0 + sel < k.num_envs;
-        float* dst = cold->s.T + e0 + sel;
-        for (int i0 = 0; i0 < n; i0 += L) {
-            const int i = i0 + r;
-            if (i < n && ok) dst[(int64_t)i * stride] = lds[ji * 256 + sel * L + ci];
-            ji += L;
-            while (ji >= C) { ji -= C; ++ci; }
-        }
-    }
+    copy_wire<L, false>(cold->s.T, stride, e0, k.num_envs, n, tid, lds, wire_slot);
     if (live && c == 0) {
         if (WEDM_REWARD_ON(cold) && !frozen0) write_reward(cold, e, s);
         store_env(cold, e, s);
@@ -1174,21 +1191,24 @@ __global__ void __launch_bounds__(256, 2) wedm_step_stream(const KArgs k) {
     // per-lane tile membership, gathered by the host (build_walk): requested with the rest
     const uint32_t zone_lo = wt->chunk_flags[c][0], joule_lo = wt->chunk_flags[c][1];
     const uint32_t zone_hi = wt->chunk_flags[c][2], joule_hi = wt->chunk_flags[c][3];
-    // (2) the wire: the lane's whole chunk into registers, 32-bit byte offsets from the (wave-uniform) base of T
-    // (the host checks that the block is below 4 GB): one v_add per row instead of a 64-bit multiply-add.
-    // Rows past the chunk repeat its last row (a lane without cells reads row 0): every load is unconditional
-    // and from a valid address, so the compiler can count them and waits for each row only where it is used.
+    // (2) the wire: the lane's whole chunk into registers, 16 bytes (four consecutive cells of the quad-interleaved block)
+    // per load, 32-bit byte offsets from the (wave-uniform) base of T (the host checks that the block is below 4 GB): one
+    // v_add per word instead of a 64-bit multiply-add.  The chunk starts on a word (the stream kernel's walk tables
+    // round the chunk length up to a multiple of 4).  Words past the chunk repeat its last word (a lane without cells
+    // reads word 0): every load is unconditional and from a valid address, so the compiler can count them and waits
+    // for each word only where it is used.  CMAX / 4 loads where ABI v3's T[seg][env] needed CMAX.
+    static_assert(CMAX % 4 == 0, "whole 16-byte words");
     const char* const Tb = (const char*)cold->s.T;
-    const uint32_t rowb = (uint32_t)stride * 4u;                                                   // bytes per wire row
-    const uint32_t off0 = (uint32_t)((jn > 0 ? cbase : 0) * stride + (live ? e : 0)) * 4u;        // this lane's first row
-    float w[CMAX];
+    const uint32_t rowb = (uint32_t)stride * 16u;                                                         // bytes per row of words
+    const uint32_t off0 = (uint32_t)((jn > 0 ? (cbase >> 2) : 0) * stride + (live ? e : 0)) * 16u;       // this lane's first word
+    f4v w4[CMAX / 4];
     {
-        const int jmax = jn > 0 ? jn - 1 : 0;
+        const int qmax = jn > 0 ? ((jn + 3) >> 2) - 1 : 0;
         uint32_t off = off0;
 #pragma unroll
-        for (int j = 0; j < CMAX; ++j) {
-            w[j] = *(const float*)(Tb + off);
-            off += (j < jmax) ? rowb : 0u;
+        for (int q = 0; q < CMAX / 4; ++q) {
+            w4[q] = *(const f4v*)(Tb + off);
+            off += (q < qmax) ? rowb : 0u;
         }
     }
     // nothing that USES a loaded state row may be scheduled above this point: the first such use (the compiler hoisted
@@ -1231,7 +1251,9 @@ __global__ void __launch_bounds__(256, 2) wedm_step_stream(const KArgs k) {
     int trace_next = k.trace_next, trace_slot = k.trace_slot;
     (void)trace_next; (void)trace_slot;
     const bool no_ragged = L * C == n && k.num_envs % EPB == 0;  // every cell of every lane of the launch exists
-    const uint32_t offc = (uint32_t)(cbase * stride + (live ? e : 0)) * 4u;  // row cbase of this environment (stores)
+    const uint32_t offc = (uint32_t)((cbase >> 2) * stride + (live ? e : 0)) * 16u;  // the word of cell cbase of this environment (stores)
+    // byte offset of chunk cell j from offc
+    const auto cell_off = [rowb](int j) -> uint32_t { return (uint32_t)(j >> 2) * rowb + (uint32_t)(j & 3) * 4u; };
     bool quiet_only = true;
     int patch0 = -1, patch1 = -1;  // cells patched after the last walk (chunk-local), -1: none
     uint32_t stored = 0u;  // tiles of the last microsecond that went to global memory from the walk itself (wave-uniform)
@@ -1319,11 +1341,11 @@ __global__ void __launch_bounds__(256, 2) wedm_step_stream(const KArgs k) {
                     const float last_v = (owns_last && t == t_last) ? spool : tn[7];
 #pragma unroll
                     for (int u = 0; u < 8; ++u) col[(j + u) * 256] = tn[u];
-                    if (last) {  // the launch's last microsecond: the tile also goes straight to global memory
+                    if (last) {  // the launch's last microsecond: the tile also goes straight to global memory, two words
                         char* const Tw = (char*)cold->s.T;
-                        uint32_t off = off0 + (uint32_t)j * rowb;
-#pragma unroll
-                        for (int u = 0; u < 8; ++u) { *(float*)(Tw + off) = tn[u]; off += rowb; }
+                        const uint32_t off = offc + (uint32_t)(j >> 2) * rowb;
+                        *(f4v*)(Tw + off) = f4v{tn[0], tn[1], tn[2], tn[3]};
+                        *(f4v*)(Tw + off + rowb) = f4v{tn[4], tn[5], tn[6], tn[7]};
                         stored |= 1u << t;
                     }
                     float m0 = fmax_gt(tn[0], tn[1]), m1 = fmax_gt(tn[2], tn[3]);
@@ -1361,15 +1383,15 @@ __global__ void __launch_bounds__(256, 2) wedm_step_stream(const KArgs k) {
                         // (spool temperature, never rewritten), goes straight to global memory; the cells patched
                         // after the walk are stored again behind these (same lane, same address: in order)
                         char* const Tw = (char*)cold->s.T;
-                        uint32_t offt = offc + (uint32_t)j * rowb;
-                        if (no_ragged && cnt == 8) {  // every cell of every lane exists: 8 unconditional stores
+                        const uint32_t offt = offc + (uint32_t)(j >> 2) * rowb;
+                        if (no_ragged && cnt == 8) {  // every cell of every lane exists: two unconditional 16-byte stores
                             tnv[0] = (im1 == 0xffffffffu) ? spool : tnv[0];  // wire cell 0
-#pragma unroll
-                            for (int u = 0; u < 8; ++u) { *(float*)(Tw + offt) = tnv[u]; offt += rowb; }
+                            *(f4v*)(Tw + offt) = f4v{tnv[0], tnv[1], tnv[2], tnv[3]};
+                            *(f4v*)(Tw + offt + rowb) = f4v{tnv[4], tnv[5], tnv[6], tnv[7]};
                         } else {
 #pragma unroll
                             for (int u = 0; u < 8; ++u)
-                                if (u < cnt && im1 + (uint32_t)u < (uint32_t)(n - 1)) *(float*)(Tw + offt + (uint32_t)u * rowb) = tnv[u];
+                                if (u < cnt && im1 + (uint32_t)u < (uint32_t)(n - 1)) *(float*)(Tw + offt + cell_off(u)) = tnv[u];
                         }
                         stored |= 1u << t;
                     }
@@ -1435,10 +1457,10 @@ __global__ void __launch_bounds__(256, 2) wedm_step_stream(const KArgs k) {
         Coef cf{0.0f, 0.0f, 0, -1};
         if (!idle) prelude(cf);
         WEDM_S2_STAMP(2);  // prelude done (first microsecond)
-        // (3) the chunk into the lane's LDS column (each row is waited for where it is written: one round trip in all)
+        // (3) the chunk into the lane's LDS column (each word is waited for where it is written: one round trip in all)
 #pragma unroll
         for (int j = 0; j < CMAX; ++j)
-            if (j < C) col[j * 256] = reinit ? k.hot.spool : w[j];
+            if (j < C) col[j * 256] = reinit ? k.hot.spool : w4[j >> 2][j & 3];
         if (c == 0) col[0] = k.hot.spool;  // wire cell 0 is held at the spool temperature (wire.py:83)
         WEDM_S2_STAMP(1);  // wire in LDS
         if (!idle) rest(0, cf);
@@ -1464,13 +1486,21 @@ __global__ void __launch_bounds__(256, 2) wedm_step_stream(const KArgs k) {
 #pragma unroll
                 for (int u = 0; u < 8; ++u) v[u] = col[((8 * t + u < C) ? 8 * t + u : C - 1) * 256];
 #pragma unroll
-                for (int u = 0; u < 8; ++u)
-                    if (8 * t + u < jn) *(float*)(Tw + offc + (uint32_t)(8 * t + u) * rowb) = v[u];
+                for (int h = 0; h < 2; ++h) {
+                    const int j = 8 * t + 4 * h;
+                    if (j + 3 < jn) {  // a whole word of cells that exist
+                        *(f4v*)(Tw + offc + (uint32_t)(j >> 2) * rowb) = f4v{v[4 * h], v[4 * h + 1], v[4 * h + 2], v[4 * h + 3]};
+                    } else {  // the wire's last, partial word: the cells past the end are padding and keep their value
+#pragma unroll
+                        for (int u = 0; u < 4; ++u)
+                            if (j + u < jn) *(float*)(Tw + offc + cell_off(j + u)) = v[4 * h + u];
+                    }
+                }
             }
         }
         // cells patched after the walk inside a tile that was already stored
-        if (patch0 >= 0 && patch0 < jn && ((stored >> (patch0 >> 3)) & 1u)) *(float*)(Tw + offc + (uint32_t)patch0 * rowb) = col[patch0 * 256];
-        if (patch1 >= 0 && patch1 < jn && ((stored >> (patch1 >> 3)) & 1u)) *(float*)(Tw + offc + (uint32_t)patch1 * rowb) = col[patch1 * 256];
+        if (patch0 >= 0 && patch0 < jn && ((stored >> (patch0 >> 3)) & 1u)) *(float*)(Tw + offc + cell_off(patch0)) = col[patch0 * 256];
+        if (patch1 >= 0 && patch1 < jn && ((stored >> (patch1 >> 3)) & 1u)) *(float*)(Tw + offc + cell_off(patch1)) = col[patch1 * 256];
     }
     if (live && c == 0 && !frozen0) {
         if (WEDM_REWARD_ON_SCALAR(cold)) {
@@ -1538,19 +1568,8 @@ __global__ void __launch_bounds__(256, 2) wedm_step_packed(const KArgs k) {
     const int64_t stride = cold->s.stride;
 
     // ---- stage: wire cell i -> virtual chunk vc = i / Cv, cell r = i % Cv -> lane vc/2, row 2r + vc%2
-    {
-        const int rr = tid / EPB, sel = tid % EPB;
-        int vc = 0, r = rr;
-        while (r >= Cv) { r -= Cv; ++vc; }
-        const bool ok = e0 + sel < k.num_envs;
-        const float* src = cold->s.T + e0 + sel;
-        for (int i0 = 0; i0 < n; i0 += L) {
-            const int i = i0 + rr;
-            if (i < n && ok) lds[(2 * r + (vc & 1)) * 256 + sel * L + (vc >> 1)] = src[(int64_t)i * stride];
-            r += L;
-            while (r >= Cv) { r -= Cv; ++vc; }
-        }
-    }
+    const auto wire_slot = [Cv](int i) { const int vc = i / Cv; return (2 * (i - vc * Cv) + (vc & 1)) * 256 + (vc >> 1); };
+    copy_wire<L, true>(cold->s.T, stride, e0, k.num_envs, n, tid, lds, wire_slot);
     __syncthreads();
 
     Env s;
@@ -1918,19 +1937,7 @@ __global__ void __launch_bounds__(256, 2) wedm_step_packed(const KArgs k) {
     WEDM_STAMP_OUT();
 
     __syncthreads();
-    {
-        const int rr = tid / EPB, sel = tid % EPB;
-        int vc = 0, r = rr;
-        while (r >= Cv) { r -= Cv; ++vc; }
-        const bool ok = e0 + sel < k.num_envs;
-        float* dst = cold->s.T + e0 + sel;
-        for (int i0 = 0; i0 < n; i0 += L) {
-            const int i = i0 + rr;
-            if (i < n && ok) dst[(int64_t)i * stride] = lds[(2 * r + (vc & 1)) * 256 + sel * L + (vc >> 1)];
-            r += L;
-            while (r >= Cv) { r -= Cv; ++vc; }
-        }
-    }
+    copy_wire<L, false>(cold->s.T, stride, e0, k.num_envs, n, tid, lds, wire_slot);
     if (live && c == 0) {
         if (WEDM_REWARD_ON(cold) && !frozen0) write_reward(cold, e, s);
         store_env(cold, e, s);
@@ -1995,7 +2002,8 @@ wedm_reset_kernel(const wedm_params p, const wedm_state_ptrs s, int32_t num_envs
     *WEDM_ROW(s.f64, WEDM_F_LAST_DENSITY) = -1.0;                      // dielectric.py:79
     const float spool = (float)p.spool_T;
     *WEDM_ROW(s.f64, WEDM_F_TMAX) = (double)spool;
-    for (int i = 0; i < n_seg_max; ++i) s.T[(int64_t)i * stride + e] = spool;  // wire.py:264-269
+    for (int q = 0; q < WEDM_T_QUADS(n_seg_max); ++q)  // wire.py:264-269 (whole 16-byte words: padding cells included)
+        *(f4v*)(s.T + (((int64_t)q * stride + e) << 2)) = f4v{spool, spool, spool, spool};
     if (s.obs)
         for (int c = 0; c < p.obs_dim; ++c) s.obs[(int64_t)c * stride + e] = 0.0f;
     if (s.reward) s.reward[e] = 0.0f;
@@ -2060,9 +2068,11 @@ struct wedm_ctx {
     bool auto_prefers_packed = true;
     unsigned long long* dbg = nullptr; // diagnostic builds: phase stamp buffer
     int lds_limit = 0;
-    WalkTable* walk_dev = nullptr;     // [5] tables for L = 1, 2, 4, 8, 16
+    WalkTable* walk_dev = nullptr;     // [10] tables for L = 1, 2, 4, 8, 16; then the same with chunks of whole 16-byte words (stream kernel)
     bool walk_ok[5] = {false, false, false, false, false};
     int32_t walk_C[5] = {0, 0, 0, 0, 0};
+    bool walk4_ok[5] = {false, false, false, false, false};
+    int32_t walk4_C[5] = {0, 0, 0, 0, 0};
     uint32_t walk_n1z = 0;             // bit i: table i has a one-change tile with a zone change (see WalkTable::kind_n1_mask)
     // signal trace (wedm_bind_trace): descriptor, microseconds stepped and samples written since the bind
     const double* replay = nullptr;    // wedm_bind_rng_replay
@@ -2090,10 +2100,13 @@ static int32_t hip_fail(wedm_ctx* ctx, hipError_t e, const char* what) {
 // Walk table for L lanes per environment (uniform geometry): for every chunk-local cell j
 // which chunks have that cell inside the zone / between the contacts / interior / valid, and
 // per 8-cell tile whether it needs the per-cell (SPECIAL) path.
-static bool build_walk(const wedm_params& p, int L, WalkTable& t) {
+// `align`: the chunk length is rounded up to a multiple of it (4 for the stream kernel, whose lanes load their chunk in
+// 16-byte words of the quad-interleaved block: every chunk then starts on a word; chunks may end up partly or wholly
+// past the wire's end, which the valid / interior masks express like any ragged tail).
+static bool build_walk(const wedm_params& p, int L, WalkTable& t, int align = 1) {
     std::memset(&t, 0, sizeof(t));
     const int n = p.n_seg;
-    const int C = (n + L - 1) / L;
+    const int C = ((n + L - 1) / L + align - 1) / align * align;
     if (C + 1 > WEDM_MAX_C) return false;  // +1: the halo row
     const int cb = p.contact_bottom, ct = p.contact_top, zs = p.az_start, ze = p.az_end;
     t.C = C;
@@ -2291,18 +2304,18 @@ static int32_t plan_launch(wedm_ctx* ctx, bool single, bool tr, LaunchPlan& out)
     // kernel 6 (stream, single microseconds, uniform geometry): the caller's lane count, else the smallest L whose
     // chunk has at most 64 cells (the registers a lane holds its chunk in; failing that at most 104)
     int slanes = 0;
-    if (uniform && (uint64_t)ctx->n_seg_max * (uint64_t)ctx->s.stride * 4ull < (1ull << 32)) {
+    if (uniform && (uint64_t)WEDM_T_QUADS(ctx->n_seg_max) * (uint64_t)ctx->s.stride * 16ull < (1ull << 32)) {
         const int Ls[5] = {1, 2, 4, 8, 16};
         for (int pass = 0; pass < 2 && !slanes; ++pass)
             for (int i = 0; i < 5 && !slanes; ++i) {
-                if (!ctx->walk_ok[i] || ctx->walk_C[i] > (pass ? 104 : 64) ||
-                    ((size_t)ctx->walk_C[i] + 1) * 1024 > (size_t)ctx->lds_limit) continue;
+                if (!ctx->walk4_ok[i] || ctx->walk4_C[i] > (pass ? 104 : 64) ||
+                    ((size_t)ctx->walk4_C[i] + 1) * 1024 > (size_t)ctx->lds_limit) continue;
                 if (ctx->lanes && Ls[i] != ctx->lanes) continue;
                 slanes = Ls[i];
             }
     }
     const bool stream_ok = slanes > 0;
-    const bool stream_auto = stream_ok && ctx->walk_C[lanes_index(slanes)] <= 64 &&
+    const bool stream_auto = stream_ok && ctx->walk4_C[lanes_index(slanes)] <= 64 &&
                              (long)((ctx->num_envs + (256 / slanes) - 1) / (256 / slanes)) * 4 <= 2048;
     int variant = ctx->variant;
     if (ctx->replay) {
@@ -2355,9 +2368,9 @@ static int32_t plan_launch(wedm_ctx* ctx, bool single, bool tr, LaunchPlan& out)
     } else if (variant == 6) {
         const int sli = lanes_index(slanes);
         grid = (ctx->num_envs + 256 / slanes - 1) / (256 / slanes);
-        fl = ((size_t)ctx->walk_C[sli] + 1) * 1024;
-        out.walk = ctx->walk_dev + sli;
-        fn = ctx->walk_C[sli] <= 64 ? (tr ? pick_stream<true, 64>(slanes) : pick_stream<false, 64>(slanes))
+        fl = ((size_t)ctx->walk4_C[sli] + 1) * 1024;
+        out.walk = ctx->walk_dev + 5 + sli;
+        fn = ctx->walk4_C[sli] <= 64 ? (tr ? pick_stream<true, 64>(slanes) : pick_stream<false, 64>(slanes))
                                     : (tr ? pick_stream<true, 104>(slanes) : pick_stream<false, 104>(slanes));
         std::snprintf(out.name, sizeof(out.name), "wedm_step_stream<%d><<<%d,256,%zuB>>>", slanes, grid, fl);
     } else if (variant == 2) {
@@ -2488,15 +2501,18 @@ int32_t wedm_create(const wedm_params* params, int32_t num_envs, int32_t n_seg_m
         return WEDM_ERR_HIP;
     }
     if (!params->per_env_geometry) {
-        WalkTable host_tabs[5];
+        std::vector<WalkTable> host_tabs(10);
         const int Ls[5] = {1, 2, 4, 8, 16};
         for (int i = 0; i < 5; ++i) {
             ctx->walk_ok[i] = build_walk(*params, Ls[i], host_tabs[i]);
             ctx->walk_C[i] = host_tabs[i].C;
             if (ctx->walk_ok[i] && (host_tabs[i].kind_n1_mask & 0x80000000u)) ctx->walk_n1z |= 1u << i;
+            ctx->walk4_ok[i] = build_walk(*params, Ls[i], host_tabs[5 + i], 4);
+            ctx->walk4_C[i] = host_tabs[5 + i].C;
         }
-        if ((e = hipMalloc((void**)&ctx->walk_dev, sizeof(host_tabs))) != hipSuccess ||
-            (e = hipMemcpy(ctx->walk_dev, host_tabs, sizeof(host_tabs), hipMemcpyHostToDevice)) != hipSuccess) {
+        const size_t tab_bytes = host_tabs.size() * sizeof(WalkTable);
+        if ((e = hipMalloc((void**)&ctx->walk_dev, tab_bytes)) != hipSuccess ||
+            (e = hipMemcpy(ctx->walk_dev, host_tabs.data(), tab_bytes, hipMemcpyHostToDevice)) != hipSuccess) {
             g_create_error = std::string("walk tables: ") + hipGetErrorString(e);
             if (ctx->walk_dev) (void)hipFree(ctx->walk_dev);
             (void)hipFree(ctx->params_dev);

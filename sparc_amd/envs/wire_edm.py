@@ -450,7 +450,7 @@ class WireEDMEnv:
             raise NotImplementedError("zone mean needs uniform geometry")
         g = self.geometry
         lo, hi = g.az_start, g.az_end
-        T = self.state.T[:, : self.num_envs]
+        T = self.state.wire_temperature.tensor().t()  # [segment, env], as the reduction was written for ABI v3
         if hi > lo:
             return T[lo:hi].mean(dim=0)
         return T[: g.n_seg].mean(dim=0)

@@ -19,8 +19,10 @@ def block_diffs(got, want, n, *, skip_rows=(), T_rows=None):
         if k not in got or k not in want:
             continue
         a, b = got[k][:, :n], want[k][:, :n]
-        if k == "T" and T_rows is not None:
-            a, b = a[:T_rows], b[:T_rows]
+        if k == "T":  # quad-interleaved block [seg / 4][env][4] -> one row per segment (padding cells included)
+            a, b = (x.permute(0, 2, 1).reshape(-1, x.shape[1]) for x in (a, b))
+            if T_rows is not None:
+                a, b = a[:T_rows], b[:T_rows]
         if a.is_floating_point():
             neq = ~((a == b) | (a.isnan() & b.isnan()))
         else:

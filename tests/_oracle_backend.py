@@ -44,7 +44,8 @@ class OracleBackend:
         assert rc == 0, rc
         # like wedm_reset: all n_seg_max temperature rows at the spool temperature, obs zeroed
         stride = self.state.stride
-        T = np.ctypeslib.as_array(C.cast(self.state.T, C.POINTER(C.c_float)), shape=(self.n_seg_max, stride))
+        T = np.ctypeslib.as_array(C.cast(self.state.T, C.POINTER(C.c_float)),
+                                  shape=(_abi.t_quads(self.n_seg_max), stride, 4))  # quad-interleaved (include/wedm_hip.h)
         obs = np.ctypeslib.as_array(C.cast(self.state.obs, C.POINTER(C.c_float)),
                                     shape=(self.params.obs_dim, stride))
         if mask_ptr is None:
@@ -97,7 +98,10 @@ class OracleBackend:
             dst[slot] = self._block(src, ctype, nrows)[rows, lo:lo + cnt]
         if tr.T:
             dst = np.ctypeslib.as_array(C.cast(tr.T, C.POINTER(C.c_float)), shape=(tr.capacity, self.n_seg_max, cnt))
-            dst[slot] = self._block(self.state.T, C.c_float, self.n_seg_max)[:, lo:lo + cnt]
+            nq = _abi.t_quads(self.n_seg_max)
+            T = np.ctypeslib.as_array(C.cast(self.state.T, C.POINTER(C.c_float)), shape=(nq, self.state.stride, 4))
+            # trace rings stay [capacity][n_seg_max][env_count]
+            dst[slot] = T[:, lo:lo + cnt].transpose(0, 2, 1).reshape(4 * nq, cnt)[: self.n_seg_max]
 
     def bind_trace(self, desc):
         self._trace, self._trace_us, self._trace_count = desc, 0, 0
