@@ -153,12 +153,29 @@ def recorded(kernel_name, file_name):
     return None
 
 
+def recorded_for_this_build(kernel_name, file_name):
+    """(row, None) when profiles/<file_name> holds counters of the kernel that ran, counted on THIS build of the library
+    (the row's `build_id` equals `wedm_build_id()` of the loaded library: sha256 over the kernel sources and flags);
+    (None, reason) otherwise -- a kernel edit that keeps its name and launch geometry must not price the new duration
+    with the old instruction count."""
+    from sparc_amd import _lib
+
+    row = recorded(kernel_name, file_name)
+    if row is None:
+        return None, f"no recorded pass matches this kernel (profiles/{file_name})"
+    have, want = row.get("build_id"), _lib.build_id()
+    if have != want:
+        return None, (f"profiles/{file_name} was counted on build {have}, the loaded library is build {want}: "
+                      "re-run tools/profile_round.sh on this build")
+    return row, None
+
+
 def measured_traffic(kernel_name):
-    """HBM bytes per launch from the separate rocprofv3 --pmc passes recorded under profiles/
-    (FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for gfx950, + WRITE_SIZE); null when
-    no recorded pass matches the kernel that ran."""
-    row = recorded(kernel_name, "traffic.json")
-    return row["hbm_bytes_per_launch"] if row else None
+    """(HBM bytes per launch, None) from the separate rocprofv3 --pmc passes recorded under profiles/
+    (FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for gfx950, + WRITE_SIZE), or (None, reason)
+    when no recorded pass of this build matches the kernel that ran."""
+    row, why = recorded_for_this_build(kernel_name, "traffic.json")
+    return (row["hbm_bytes_per_launch"], None) if row else (None, why)
 
 
 def roofline_block(kernel_name, kernel_ms, n_envs, n_sub, n_seg, traffic_override=None):
@@ -166,7 +183,7 @@ def roofline_block(kernel_name, kernel_ms, n_envs, n_sub, n_seg, traffic_overrid
     t = kernel_ms * 1e-3
     env_steps = n_envs * n_sub
     alg_bytes = env_steps * algorithmic_bytes_per_env_step(n_seg)
-    traffic = traffic_override if traffic_override is not None else measured_traffic(kernel_name)
+    traffic, traffic_why = (traffic_override, None) if traffic_override is not None else measured_traffic(kernel_name)
     alg = {"GB/s": alg_bytes / t / 1e9, "frac_of_hbm_peak": alg_bytes / t / 1e9 / HBM_PEAK_GBS,
            "bytes_per_launch": alg_bytes,
            "note": "B(S) = 8 S + 208 bytes per env-step (SURVEY.md §8d) x env-steps per launch"}
@@ -179,30 +196,41 @@ def roofline_block(kernel_name, kernel_ms, n_envs, n_sub, n_seg, traffic_overrid
     if n_sub == 1:
         # one launch per microsecond: every byte crosses HBM once per launch -> HBM is the roof, priced with the
         # algorithmic bytes as SURVEY.md §8d defines them
-        return {"bound": "hbm", "achieved": alg["GB/s"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": alg["frac_of_hbm_peak"], "traffic": traffic, "kernel_ms": kernel_ms,
-                "algorithmic_bytes_per_launch": alg_bytes, "hbm_physical": hbm, "fp32_useful": fp32}
-    valu = recorded(kernel_name, "valu.json")
+        out = {"bound": "hbm", "achieved": alg["GB/s"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
+               "frac": alg["frac_of_hbm_peak"], "traffic": traffic, "kernel_ms": kernel_ms,
+               "algorithmic_bytes_per_launch": alg_bytes, "hbm_physical": hbm, "fp32_useful": fp32}
+        if traffic is None:
+            out["traffic_note"] = traffic_why
+        return out
+    valu, valu_why = recorded_for_this_build(kernel_name, "valu.json")
     out = {"bound": "valu-issue", "unit": "wave-instr/s", "peak": VALU_ISSUE_PEAK, "traffic": traffic,
            "kernel_ms": kernel_ms, "hbm_physical": hbm, "fp32_useful": fp32, "algorithmic_hbm_equivalent": alg}
+    if traffic is None:
+        out["traffic_note"] = traffic_why
     if valu is not None:
         insts = valu["valu_insts_per_launch"] * (env_steps / valu["env_steps_per_launch"])
         out["achieved"] = insts / t
         out["frac"] = out["achieved"] / VALU_ISSUE_PEAK
         out["valu_insts_per_env_step"] = valu["valu_insts_per_launch"] / valu["env_steps_per_launch"]
         out["source"] = valu["source"]
-        if "sq_active_inst_valu" in valu:
-            # SQ_ACTIVE_INST_VALU counts quad-cycles in which a wave's VALU instruction occupies its SIMD (packed-f32
-            # and f64 instructions hold it twice as long as the 2-cycle f32 instruction the issue peak assumes)
-            busy = valu["sq_active_inst_valu"] * 4.0 * (env_steps / valu["env_steps_per_launch"])
-            out["valu_pipe_busy"] = {"simd_cycles_per_launch": busy,
-                                     "frac_of_simd_cycles_at_2.4GHz": busy / (t * 2.4e9 * 1024),
-                                     "note": "SQ_ACTIVE_INST_VALU x 4 / (kernel duration x 2.4 GHz x 1024 SIMDs); the chip "
-                                             "clocks below 2.4 GHz under load, so the true pipe occupancy is higher"}
+        if "sq_active_inst_valu" in valu and "sq_wave_cycles" in valu and "sq_waves" in valu:
+            # SQ_ACTIVE_INST_VALU counts quad-cycles in which a wave's VALU instruction occupies its SIMD (packed-f32 and
+            # f64 instructions hold it twice as long as the 2-cycle f32 instruction the issue peak assumes);
+            # SQ_WAVE_CYCLES counts the quad-cycles the launch's waves were resident.  Both from the SAME counter pass,
+            # so their ratio is the pipe occupancy at the clock the chip really ran at, whatever that was.
+            waves_per_simd = max(1.0, valu["sq_waves"] / 1024.0)
+            simd_cycles = valu["sq_wave_cycles"] / waves_per_simd            # quad-cycles a SIMD was occupied by the launch
+            scale = env_steps / valu["env_steps_per_launch"]
+            out["valu_pipe_busy"] = {
+                "frac": valu["sq_active_inst_valu"] / simd_cycles,
+                "measured_clock_GHz": valu["sq_wave_cycles"] * scale * 4.0 / valu["sq_waves"] / t / 1e9,
+                "note": "SQ_ACTIVE_INST_VALU / (SQ_WAVE_CYCLES / resident waves per SIMD), one counter pass; the clock is "
+                        "SQ_WAVE_CYCLES x 4 / waves / the live kernel duration (the 2.4 GHz of the issue peak is the "
+                        "data-sheet maximum, under this load the chip runs lower)"}
     else:
         out["achieved"] = None
         out["frac"] = None
-        out["source"] = "no recorded SQ_INSTS_VALU pass matches this kernel (profiles/valu.json)"
+        out["source"] = valu_why
     out["note"] = ("the fused launch keeps the wire in LDS for all its microseconds: HBM sees each byte once per launch, "
                    "the kernel is bound by VALU issue; frac = wave-level VALU instructions per second / (1024 SIMDs x 2.4 GHz / 2)")
     return out
@@ -257,19 +285,27 @@ def side_measurements(n_local, wire, S, device):
     env.state.wire_position = 10.0
     env.state.target_position = 5000.0
     ctl = VoltageController(30.0)
-    run_controlled(env, ctl, 100 * 1000 + 1)  # approach: the controller needs ~90 ms to close the 60 um gap
+    # ONE driver loop: a 100 ms approach (the controller needs ~90 ms to close the 60 um gap), then 10 timed control
+    # intervals, bracketed by HIP events recorded from the loop's own control-step hook (two calls of run_controlled in a
+    # row would evaluate the controller twice for the sample between them: one extra PI-integrator update).
+    marks = {}
+
+    def mark(e, done):
+        if done in (100 * 1000 + 1, 110 * 1000 + 1):
+            ev = torch.cuda.Event(enable_timing=True)
+            ev.record()
+            marks[done] = (ev, e.state.spark_count.sum())  # (device-side sum: no host sync inside the loop)
+
+    run_controlled(env, ctl, 110 * 1000 + 1, on_control_step=mark)
     torch.cuda.synchronize()
-    s0 = int(env.state.spark_count.sum().item())
-    t0 = time.perf_counter()
-    done = run_controlled(env, ctl, 10 * 1000)
-    torch.cuda.synchronize()
-    dt = time.perf_counter() - t0
+    (ev0, s0), (ev1, s1) = marks[100 * 1000 + 1], marks[110 * 1000 + 1]
+    dt = ev0.elapsed_time(ev1) * 1e-3
     gap = float((env.state.workpiece_position - env.state.wire_position).mean().item())
     out.append({"name": "closed loop: the reference driver's PI voltage controller on the device, steady state",
-                "value": n_local * done / dt, "unit": "env-steps/s", "kernel": env._backend.last_kernel(),
+                "value": n_local * 10 * 1000 / dt, "unit": "env-steps/s", "kernel": env._backend.last_kernel(),
                 "ms_per_control_interval": dt / 10 * 1e3, "mean_gap_um": gap,
-                "sparks_per_env_per_ms": (int(env.state.spark_count.sum().item()) - s0) / n_local / 10.0,
-                "timing": "wall clock around 10 control intervals incl. the controller's torch ops"})
+                "sparks_per_env_per_ms": (int(s1.item()) - int(s0.item())) / n_local / 10.0,
+                "timing": "HIP events around 10 control intervals of one driver loop, incl. the controller's torch ops"})
     env.close()
     # a training-style batch: in-launch autoreset and a cutting target a few sparks ahead, so that in steady state a sixth
     # of the environments terminates in every launch and waits, frozen, for the next launch's re-initialisation
@@ -410,7 +446,7 @@ def main():
                                 "counter), no data-path collective; obs all-gather per control step (async, overlapped "
                                 "with the next launch)") if world > 1 else "single GPU",
                 "ranks": world, "env_id_offsets": [r * n_local for r in range(world)],
-                "kernel": kname,
+                "kernel": kname, "build_id": env._backend.build_id(),
                 **({"trace": args.trace} if args.trace != "off" else {}),
                 **({"initial_gap_um": args.gap} if args.gap is not None else {}),
             },

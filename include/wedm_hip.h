@@ -325,6 +325,13 @@ typedef struct wedm_ctx wedm_ctx;
 /* version of this header the library was built against */
 int32_t wedm_abi_version(void);
 
+/* fingerprint of the build: the first 16 hex digits of the sha256 over the kernel sources (wedm_kernels.hip,
+ * wedm_device.h, this header) and the compiler flags, baked in by the build (__graft_entry__.build_hip).  Measurement
+ * records (profiles/valu.json, profiles/traffic.json) carry the id of the library they were counted on, and bench.py
+ * prices a live duration with a recorded instruction / byte count only when the ids agree.  "unknown" for a library
+ * built by hand without -DWEDM_BUILD_ID.                                                                        */
+const char* wedm_build_id(void);
+
 /* replaces WireEDMEnv.__init__ (wire_edm.py:22-101): validates sizes, copies
  * `params`, selects the device that is current at call time.                  */
 int32_t wedm_create(const wedm_params* params, int32_t num_envs, int32_t n_seg_max, wedm_ctx** out);

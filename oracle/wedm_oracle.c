@@ -1120,7 +1120,10 @@ int32_t wedm_oracle_step_batch(const wedm_params* p, const wedm_state_ptrs* s, c
 #endif
         for (int64_t e = 0; e < num_envs; ++e) {
             if (I8(WEDM_B_DONE)) {
-                if (!p->autoreset) continue;
+                if (!p->autoreset) {  /* frozen until the caller resets it: it earns nothing in this launch */
+                    if (p->reward_mode && s->reward) s->reward[e] = 0.0f;
+                    continue;
+                }
                 /* wedm_params.autoreset: next-step autoreset inside the call = wedm_reset(mask = DONE, reseed = 0)
                  * for this environment (all n_seg_max wire rows at the spool temperature, observation zeroed) */
                 reset_env_rows(p, s, e, 0, 0);

@@ -74,6 +74,8 @@ def load() -> C.CDLL:
     L.wedm_debug_math.restype = C.c_int32
     L.wedm_debug_poison_lds.argtypes = [C.c_float, C.c_void_p]
     L.wedm_debug_poison_lds.restype = C.c_int32
+    L.wedm_build_id.argtypes = []
+    L.wedm_build_id.restype = C.c_char_p
     _lib = L
     return L
 
@@ -81,8 +83,13 @@ def load() -> C.CDLL:
 EXPORTS = (
     "wedm_abi_version", "wedm_create", "wedm_destroy", "wedm_bind_state", "wedm_bind_geometry",
     "wedm_reset", "wedm_step", "wedm_bind_trace", "wedm_bind_rng_replay", "wedm_trace_samples", "wedm_set_kernel", "wedm_set_lanes", "wedm_last_kernel", "wedm_last_error",
-    "wedm_sizeof_params", "wedm_debug_math", "wedm_debug_poison_lds",
+    "wedm_sizeof_params", "wedm_debug_math", "wedm_debug_poison_lds", "wedm_build_id",
 )
+
+
+def build_id() -> str:
+    """`wedm_build_id()` of the loaded library: the fingerprint measurement records are bound to (include/wedm_hip.h)."""
+    return load().wedm_build_id().decode()
 
 
 class _NoGuard:
@@ -173,6 +180,9 @@ class HipBackend:
 
     def last_kernel(self) -> str:
         return (self._L.wedm_last_kernel(self._ctx) or b"").decode()
+
+    def build_id(self) -> str:
+        return build_id()
 
     def close(self) -> None:
         if self._ctx:

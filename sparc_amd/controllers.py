@@ -77,6 +77,12 @@ class VoltageController:
         """Attach to `env`.  ``trace`` (ring mode only): an existing `DeviceTrace` that records
         ``"voltage"`` of every environment every step with capacity >= the window, to share it with
         a logger; passing one selects the ring mode."""
+        if getattr(env, "autoreset", False) and not (self.use_ring or trace is not None):
+            # The running-sum form decides "no control step yet" from the batch-wide step count and adds sums published in
+            # lock-step: an environment re-initialised inside a launch (VOLT_SUM = VOLT_ACC = 0, its control steps shifted
+            # against the batch) would be averaged over sums that are not its own and wind up its integrator.
+            raise ValueError("VoltageController's running-sum form needs environments in lock-step: it cannot drive an "
+                             "environment built with autoreset=True (use use_ring=True, or reset from the host)")
         self._env = env
         steps = -(-env.servo_interval // env.dt)              # physics steps between two control steps
         period_us = steps * env.dt

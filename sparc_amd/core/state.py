@@ -201,9 +201,15 @@ class BatchedEDMState:
 
     def clone_blocks(self):
         """Host copies of the raw blocks (used by checkpointing and by the parity tests)."""
-        return {k: getattr(self, k).detach().cpu().clone() for k in ("f64", "i32", "i8", "T", "obs", "stats", "reward")}
+        out = {k: getattr(self, k).detach().cpu().clone() for k in ("f64", "i32", "i8", "T", "obs", "stats", "reward")}
+        if self.crater_log is not None:  # the ring spark_count indexes (material.py:133): part of the state
+            out["crater_log"] = self.crater_log.detach().cpu().clone()
+        return out
 
     def load_blocks(self, blocks) -> None:
-        for k in ("f64", "i32", "i8", "T", "obs", "stats", "reward"):
-            if k in blocks:
+        for k in ("f64", "i32", "i8", "T", "obs", "stats", "reward", "crater_log"):
+            if k in blocks and getattr(self, k) is not None:
+                if tuple(blocks[k].shape) != tuple(getattr(self, k).shape):
+                    raise ValueError(f"state block {k!r} has shape {tuple(blocks[k].shape)}, this environment's is "
+                                     f"{tuple(getattr(self, k).shape)} (another ABI version or crater_log_capacity?)")
                 getattr(self, k).copy_(blocks[k].to(self.device))

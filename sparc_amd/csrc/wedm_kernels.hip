@@ -256,7 +256,10 @@ __global__ void __launch_bounds__(256) wedm_step_global(const KArgs k) {
     load_env(cold, e, s);
     const bool reinit = s.done && WEDM_AUTORESET(cold);
     const bool frozen = s.done && !reinit;  // terminated and not reset: nothing to step
-    if (frozen && !WEDM_TRACING(k)) return;
+    if (frozen && !WEDM_TRACING(k)) {
+        if (WEDM_REWARD_ON(cold)) cold->s.reward[e] = 0.0f;  // a frozen environment earns nothing (not the previous launch's reward)
+        return;
+    }
     const GlobalT T = global_wire(cold->s.T, cold->s.stride, e);
     if (reinit) {  // next-step autoreset: wedm_reset for this environment, inside the launch
         reinit_env(cold, e, s, true);
@@ -266,7 +269,10 @@ __global__ void __launch_bounds__(256) wedm_step_global(const KArgs k) {
     Geom g;
     load_geom(k.hot, cold, e, g);
     run_substeps<TRACE, F64, REPLAY>(k, cold, g, e, k.hot.env_id_offset + (uint32_t)e, s, T);
-    if (WEDM_REWARD_ON(cold) && !frozen) write_reward(cold, e, s);
+    if (WEDM_REWARD_ON(cold)) {
+        if (!frozen) write_reward(cold, e, s);
+        else cold->s.reward[e] = 0.0f;
+    }
     store_env(cold, e, s);
 }
 
@@ -450,7 +456,10 @@ __global__ void __launch_bounds__(256) wedm_step_split(const KArgs k) {
     }
     WEDM_SPLIT_STAMP(5);
     if (c == 0 && live) {
-        if (WEDM_REWARD_ON(cold) && !frozen0) write_reward(cold, e, s);
+        if (WEDM_REWARD_ON(cold)) {
+            if (!frozen0) write_reward(cold, e, s);
+            else cold->s.reward[e] = 0.0f;  // a frozen environment earns nothing (not the previous launch's reward)
+        }
         store_env(cold, e, s);
     }
     WEDM_SPLIT_STAMP(6);
@@ -466,7 +475,7 @@ __global__ void __launch_bounds__(256) wedm_step_split(const KArgs k) {
 #else
 #define WEDM_S2_CLOCK "s_memtime"
 #endif
-#define WEDM_S2_STAMP_DECL unsigned long long sst[8] = {0, 0, 0, 0, 0, 0, 0, 0}; \
+#define WEDM_S2_STAMP_DECL unsigned long long sst[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}; \
     asm volatile(WEDM_S2_CLOCK " %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(sst[7])::"memory")
 #define WEDM_S2_STAMP(i) do { __builtin_amdgcn_sched_barrier(0); \
     asm volatile(WEDM_S2_CLOCK " %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(sst[i])::"memory"); \
@@ -475,8 +484,8 @@ __global__ void __launch_bounds__(256) wedm_step_split(const KArgs k) {
     asm volatile("s_waitcnt vmcnt(0)\n\t" WEDM_S2_CLOCK " %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(sst[i])::"memory"); \
     __builtin_amdgcn_sched_barrier(0); } while (0)
 #define WEDM_S2_STAMP_OUT() do { if (k.dbg && (threadIdx.x & 63) == 0) { \
-    unsigned long long* o = k.dbg + ((size_t)blockIdx.x * 4 + (threadIdx.x >> 6)) * 8; \
-    for (int q = 0; q < 8; ++q) o[q] = sst[q]; } } while (0)
+    unsigned long long* o = k.dbg + ((size_t)blockIdx.x * 4 + (threadIdx.x >> 6)) * 12; \
+    for (int q = 0; q < 12; ++q) o[q] = sst[q]; } } while (0)
 #else
 #define WEDM_S2_STAMP_DECL do { } while (0)
 #define WEDM_S2_STAMP(i) do { } while (0)
@@ -733,7 +742,10 @@ __global__ void __launch_bounds__(256, 2) wedm_step_lanes(const KArgs k) {
     __syncthreads();
     copy_wire<L, false>(cold->s.T, stride, e0, k.num_envs, nmax, tid, lds, wire_slot);
     if (live && c == 0) {
-        if (WEDM_REWARD_ON(cold) && !frozen0) write_reward(cold, e, s);
+        if (WEDM_REWARD_ON(cold)) {
+            if (!frozen0) write_reward(cold, e, s);
+            else cold->s.reward[e] = 0.0f;  // a frozen environment earns nothing (not the previous launch's reward)
+        }
         store_env(cold, e, s);
     }
 }
@@ -1120,7 +1132,10 @@ __global__ void __launch_bounds__(256, 2) wedm_step_fused(const KArgs k) {
     __syncthreads();
     copy_wire<L, false>(cold->s.T, stride, e0, k.num_envs, n, tid, lds, wire_slot);
     if (live && c == 0) {
-        if (WEDM_REWARD_ON(cold) && !frozen0) write_reward(cold, e, s);
+        if (WEDM_REWARD_ON(cold)) {
+            if (!frozen0) write_reward(cold, e, s);
+            else cold->s.reward[e] = 0.0f;  // a frozen environment earns nothing (not the previous launch's reward)
+        }
         store_env(cold, e, s);
     }
 }
@@ -1175,12 +1190,14 @@ __global__ void __launch_bounds__(256, 2) wedm_step_stream(const KArgs k) {
     // (0) the peak-current table (ignition.py:98-113), entry `lane` in lane `lane`: the wave's first vector load, so that
     // the lookup by the latched mode further down is a cross-lane read of a register that arrived long ago instead of a
     // load queued behind the whole wire (vector loads return in order: the first prelude would wait for every row)
+    WEDM_S2_STAMP(10);  // kernel arguments here
     const double ipk_entry = cold->tb.mode_current[(tid & 63) <= WEDM_MAX_MODE ? (tid & 63) : WEDM_MAX_MODE];
     // (1) the state rows a microsecond reads: requested first, so that the first prelude runs while the wire is in flight
     Env s;
     Geom g;
     Persist ps{0.0f, 0.0f, 0.0f, 0};
     load_geom(k.hot, cold, live ? e : 0, g);
+    WEDM_S2_STAMP(11);  // geometry constants here (two dependent scalar loads)
     double h64[2] = {0.0, 0.0};  // convection coefficients as loaded; converted after the wire rows are requested
     if (live) {
         if (TRACE) load_env(cold, e, s);  // frozen environments are sampled too: every row
@@ -1191,6 +1208,7 @@ __global__ void __launch_bounds__(256, 2) wedm_step_stream(const KArgs k) {
     // per-lane tile membership, gathered by the host (build_walk): requested with the rest
     const uint32_t zone_lo = wt->chunk_flags[c][0], joule_lo = wt->chunk_flags[c][1];
     const uint32_t zone_hi = wt->chunk_flags[c][2], joule_hi = wt->chunk_flags[c][3];
+    WEDM_S2_STAMP(8);  // state rows requested
     // (2) the wire: the lane's whole chunk into registers, 16 bytes (four consecutive cells of the quad-interleaved block)
     // per load, 32-bit byte offsets from the (wave-uniform) base of T (the host checks that the block is below 4 GB): one
     // v_add per word instead of a 64-bit multiply-add.  The chunk starts on a word (the stream kernel's walk tables
@@ -1198,6 +1216,20 @@ __global__ void __launch_bounds__(256, 2) wedm_step_stream(const KArgs k) {
     // reads word 0): every load is unconditional and from a valid address, so the compiler can count them and waits
     // for each word only where it is used.  CMAX / 4 loads where ABI v3's T[seg][env] needed CMAX.
     static_assert(CMAX % 4 == 0, "whole 16-byte words");
+#ifndef WEDM_STREAM_NO_STATE_WAIT
+    // The state rows land BEFORE the wire words are requested.  All 2 048 waves of a launch start together, and when a
+    // wave queues its wire words right behind its state rows the memory system serves the chip's whole request stream
+    // interleaved: a wave's state (23 MB chip-wide) then arrives only while the 33 MB of wire stream in, ~5 us after the
+    // launch began, and its prelude -- which needs nothing but the state -- starts that late.  Waiting here costs one
+    // short round trip (the state alone is back within ~1.5 us) and puts the first prelude, the general one of an
+    // igniting wave included, underneath the arrival of the wire.
+    if (!TRACE) {
+        env_loaded_here(s);
+        asm volatile("" : "+v"(h64[0]), "+v"(h64[1]));
+        __builtin_amdgcn_sched_barrier(0);
+    }
+#endif
+    WEDM_S2_STAMP(9);  // state rows landed
     const char* const Tb = (const char*)cold->s.T;
     const uint32_t rowb = (uint32_t)stride * 16u;                                                         // bytes per row of words
     const uint32_t off0 = (uint32_t)((jn > 0 ? (cbase >> 2) : 0) * stride + (live ? e : 0)) * 16u;       // this lane's first word
@@ -1502,6 +1534,7 @@ __global__ void __launch_bounds__(256, 2) wedm_step_stream(const KArgs k) {
         if (patch0 >= 0 && patch0 < jn && ((stored >> (patch0 >> 3)) & 1u)) *(float*)(Tw + offc + cell_off(patch0)) = col[patch0 * 256];
         if (patch1 >= 0 && patch1 < jn && ((stored >> (patch1 >> 3)) & 1u)) *(float*)(Tw + offc + cell_off(patch1)) = col[patch1 * 256];
     }
+    if (live && c == 0 && frozen0 && WEDM_REWARD_ON_SCALAR(cold)) cold->s.reward[e] = 0.0f;  // a frozen environment earns nothing
     if (live && c == 0 && !frozen0) {
         if (WEDM_REWARD_ON_SCALAR(cold)) {
             const double pen = opaque(cold->p)->reward_break_penalty;
@@ -1939,7 +1972,10 @@ __global__ void __launch_bounds__(256, 2) wedm_step_packed(const KArgs k) {
     __syncthreads();
     copy_wire<L, false>(cold->s.T, stride, e0, k.num_envs, n, tid, lds, wire_slot);
     if (live && c == 0) {
-        if (WEDM_REWARD_ON(cold) && !frozen0) write_reward(cold, e, s);
+        if (WEDM_REWARD_ON(cold)) {
+            if (!frozen0) write_reward(cold, e, s);
+            else cold->s.reward[e] = 0.0f;  // a frozen environment earns nothing (not the previous launch's reward)
+        }
         store_env(cold, e, s);
     }
 }
@@ -2399,7 +2435,10 @@ static int32_t plan_launch(wedm_ctx* ctx, bool single, bool tr, LaunchPlan& out)
         std::snprintf(out.name, sizeof(out.name), "wedm_step_fused<%d><<<%d,256,%zuB>>>", lanes, grid, fl);
     }
     if (fl) {
-        hipError_t ea = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)fl);
+        // The attribute belongs to the kernel FUNCTION, not to this handle or plan: two live handles with different wire
+        // lengths can resolve to the same instantiation, and a later plan with a smaller image must not lower the limit
+        // under an earlier plan that is still cached.  Every function is therefore opened up to the device's limit.
+        hipError_t ea = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, ctx->lds_limit);
         if (ea != hipSuccess) return hip_fail(ctx, ea, "hipFuncSetAttribute(MaxDynamicSharedMemorySize)");
     }
     out.fn = fn;
@@ -2414,6 +2453,10 @@ static thread_local std::string g_create_error;
 extern "C" {
 
 int32_t wedm_abi_version(void) { return WEDM_ABI_VERSION; }
+#ifndef WEDM_BUILD_ID
+#define WEDM_BUILD_ID "unknown"
+#endif
+const char* wedm_build_id(void) { return WEDM_BUILD_ID; }
 int64_t wedm_sizeof_params(void) { return (int64_t)sizeof(wedm_params); }
 
 const char* wedm_last_error(wedm_ctx* ctx) { return ctx ? ctx->err.c_str() : g_create_error.c_str(); }

@@ -424,11 +424,14 @@ class WireEDMEnv:
         and clocks live in them, so the random streams resume exactly), the reset seed, and a
         fingerprint of the physics parameters (tensors, ints and strings only: loads with
         ``weights_only=True``)."""
-        return {"blocks": self.state.clone_blocks(), "seed": self._seed, "num_envs": self.num_envs,
+        return {"abi_version": _abi.ABI_VERSION, "blocks": self.state.clone_blocks(), "seed": self._seed, "num_envs": self.num_envs,
                 "n_segments": self.n_segments, "env_id_offset": self.env_id_offset,
                 "steps_since_reset": self.steps_since_reset, "physics": self._physics_fingerprint()}
 
     def load_state_dict(self, sd: Dict[str, Any]) -> None:
+        if sd.get("abi_version") != _abi.ABI_VERSION:
+            raise ValueError(f"checkpoint was written with state layout ABI {sd.get('abi_version', '<= 3')}, this build is ABI "
+                             f"{_abi.ABI_VERSION} (rows and the wire-temperature layout differ): it cannot be continued here")
         if (sd["num_envs"], sd["n_segments"], sd["env_id_offset"]) != (self.num_envs, self.n_segments, self.env_id_offset):
             raise ValueError("checkpoint was taken from an environment of a different shape / shard")
         if sd.get("physics") != self._physics_fingerprint():

@@ -36,6 +36,15 @@ def test_library_exports_every_declared_symbol():
     assert L.wedm_sizeof_params() == C.sizeof(_abi.Params)
 
 
+def test_build_id_names_the_sources_the_library_was_built_from():
+    """`wedm_build_id()` = sha256 over the kernel sources + compiler flags at build time: the in-tree library is the one
+    `__graft_entry__.build()` makes from the sources as they are (an edited kernel with a stale library fails here), and
+    the id is what bench.py compares the recorded counter rows of profiles/*.json with."""
+    import __graft_entry__ as g
+
+    assert _lib.build_id() == g.kernel_build_id() and len(_lib.build_id()) == 16
+
+
 def test_bad_arguments_return_status_codes_not_crashes():
     L = _lib.load()
     assert L.wedm_create(None, 4, 4, None) == _abi.ERR_BAD_ARG

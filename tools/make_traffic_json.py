@@ -9,7 +9,8 @@ HBM bytes per launch = 2 x FETCH_SIZE + WRITE_SIZE (KB -> bytes).  FETCH_SIZE is
 that calibration is for 16-B-per-lane streams, ours are 4-8 B per lane, so the doubled figure is
 an upper estimate.  VALU instructions per launch = SQ_INSTS_VALU (wave-level instructions, summed
 over the launch's waves) from its own pass.  bench.py reports the row whose kernel_prefix matches
-the kernel that ran."""
+the kernel that ran, and only when the row's build_id (wedm_build_id() of the library, read from the bench line) is the
+loaded library's."""
 import json
 import sys
 from pathlib import Path
@@ -35,12 +36,13 @@ for cfg, bench in CASES:
         continue
     b = json.loads((d / bench).read_text().strip().splitlines()[-1])
     env_steps = b["config"]["global_num_envs"] * b["config"]["substeps_per_step"]
+    build_id = b["config"].get("build_id")  # wedm_build_id() of the library the counters were taken on
     f = d / f"rocprofv3_pmc_hbm_{cfg}.txt"
     if f.exists():
         vals = table(f)
         if "FETCH_SIZE" in vals and "WRITE_SIZE" in vals:
             traffic.append({
-                "kernel_prefix": b["config"]["kernel"], "workload": b["config"]["workload"],
+                "kernel_prefix": b["config"]["kernel"], "workload": b["config"]["workload"], "build_id": build_id,
                 "FETCH_SIZE_KB": vals["FETCH_SIZE"], "WRITE_SIZE_KB": vals["WRITE_SIZE"],
                 "hbm_bytes_per_launch": (2 * vals["FETCH_SIZE"] + vals["WRITE_SIZE"]) * 1024.0,
                 "env_steps_per_launch": env_steps,
@@ -51,7 +53,7 @@ for cfg, bench in CASES:
         vals = table(f)
         if "SQ_INSTS_VALU" in vals:
             valu.append({
-                "kernel_prefix": b["config"]["kernel"], "workload": b["config"]["workload"],
+                "kernel_prefix": b["config"]["kernel"], "workload": b["config"]["workload"], "build_id": build_id,
                 "valu_insts_per_launch": vals["SQ_INSTS_VALU"], "env_steps_per_launch": env_steps,
                 **{k.lower(): v for k, v in vals.items() if k != "SQ_INSTS_VALU"},
                 "source": f"{label}/rocprofv3_pmc_sq_{cfg}.txt (separate rocprofv3 --pmc SQ_* pass of bench.py)",

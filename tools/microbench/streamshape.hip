@@ -20,7 +20,9 @@ struct Ptrs { double* f64; int32_t* i32; int8_t* i8; float* T; int stride; int n
 // WIRE_FIRST: the wire words are requested before the state rows.  INDEP: the wire stores do not wait for the state.
 // DELAY: dependent f32 operations between the loads and the stores (stands in for the microsecond's arithmetic).
 template <bool WIRE, bool STATE, bool QUAD, bool WIRE_FIRST = false, bool INDEP = false, int DELAY = 0, int BLOCK = 256>
-__global__ void __launch_bounds__(BLOCK, 512 / BLOCK) k_rows(Ptrs p) {
+__global__ void __launch_bounds__(BLOCK, (BLOCK >= 512 ? 1 : 512 / BLOCK)) k_rows(Ptrs p) {
+    extern __shared__ float dyn_lds[];
+    if (p.n_seg < 0) dyn_lds[threadIdx.x] = 0.0f;  // keeps the dynamic allocation alive
     const int tid = threadIdx.x, el = tid >> 1, c = tid & 1;
     const int e = blockIdx.x * (BLOCK / 2) + el;
     const int stride = p.stride;
@@ -183,6 +185,8 @@ int main() {
     CK(hipMemset(p.f64, 0, (size_t)NF * N * 8)); CK(hipMemset(p.i32, 0, (size_t)16 * N * 4)); CK(hipMemset(p.i8, 0, (size_t)NB * N));
     CK(hipMemset(p.T, 0, (size_t)S * N * 4));
     const dim3 g(N / 128), b(256);
+    CK(hipFuncSetAttribute((const void*)k_rows<true, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    CK(hipFuncSetAttribute((const void*)k_rows<true, true, true, false, false, 0, 512>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     auto rep = [&](const char* nm, float ms) { printf("  %-66s %8.2f us\n", nm, ms * 1e3); };
     printf("N=%d S=%d, L=2 lanes per environment, %d blocks x 256\n", N, S, N / 128);
     rep("A  rows: 40 state loads + 64 wire dword loads, 25 + 64 stores", time_it([&] { hipLaunchKernelGGL((k_rows<true, true, false>), g, b, 0, 0, p); }, 300));
@@ -200,6 +204,11 @@ int main() {
     rep("B  + 8000 dependent f32 ops between loads and stores", time_it([&] { hipLaunchKernelGGL((k_rows<true, true, true, false, false, 4000>), g, b, 0, 0, p); }, 300));
     rep("B  blocks of 64 threads (2048 blocks)", time_it([&] { hipLaunchKernelGGL((k_rows<true, true, true, false, false, 0, 64>), dim3(N / 32), dim3(64), 0, 0, p); }, 300));
     rep("B  blocks of 128 threads (1024 blocks)", time_it([&] { hipLaunchKernelGGL((k_rows<true, true, true, false, false, 0, 128>), dim3(N / 64), dim3(128), 0, 0, p); }, 300));
+    rep("B  blocks of 512 threads (256 blocks)", time_it([&] { hipLaunchKernelGGL((k_rows<true, true, true, false, false, 0, 512>), dim3(N / 256), dim3(512), 0, 0, p); }, 300));
+    rep("B  blocks of 1024 threads (128 blocks)", time_it([&] { hipLaunchKernelGGL((k_rows<true, true, true, false, false, 0, 1024>), dim3(N / 512), dim3(1024), 0, 0, p); }, 300));
+    rep("B  blocks of 256 threads + 65 KB dynamic LDS each", time_it([&] { hipLaunchKernelGGL((k_rows<true, true, true>), g, b, 65 * 1024, 0, p); }, 300));
+    rep("B  blocks of 512 threads + 130 KB dynamic LDS each", time_it([&] { hipLaunchKernelGGL((k_rows<true, true, true, false, false, 0, 512>), dim3(N / 256), dim3(512), 130 * 1024, 0, p); }, 300));
+    rep("B  + delay 500, blocks of 512 threads", time_it([&] { hipLaunchKernelGGL((k_rows<true, true, true, false, false, 500, 512>), dim3(N / 256), dim3(512), 0, 0, p); }, 300));
     rep("A  again", time_it([&] { hipLaunchKernelGGL((k_rows<true, true, false>), g, b, 0, 0, p); }, 300));
     rep("C  packed state only, again", time_it([&] { hipLaunchKernelGGL((k_packed<false, true, false>), g, b, 0, 0, p); }, 300));
     rep("empty (no loads)", time_it([&] { hipLaunchKernelGGL((k_rows<false, false, false>), g, b, 0, 0, p); }, 300));

@@ -15,7 +15,7 @@ env.set_kernel(6, lanes)
 env.reset(seed=1234)
 act = env.make_action(0.1, 80.0, 5, 3.0, 80.0)
 nblk = (n * lanes + 255) // 256
-buf = torch.zeros(nblk * 4 * 8, dtype=torch.int64, device="cuda")
+buf = torch.zeros(nblk * 4 * 12, dtype=torch.int64, device="cuda")
 L = env._backend._L
 L.wedm_debug_set_stamp_buffer.argtypes = [C.c_void_p, C.c_void_p]
 L.wedm_debug_set_stamp_buffer(env._backend._ctx, C.c_void_p(buf.data_ptr()))
@@ -25,9 +25,10 @@ buf.zero_()
 env.step(act)
 torch.cuda.synchronize()
 print(env._backend.last_kernel())
-raw = buf.cpu().numpy().reshape(nblk * 4, 8).astype(np.float64)
-names = ["everything requested", "first prelude done", "wire in LDS", "walk done", "patches + reduce + epilogue done", "stores issued", "stores landed"]
-idx = [0, 2, 1, 3, 4, 5, 6]
+raw = buf.cpu().numpy().reshape(nblk * 4, 12).astype(np.float64)
+names = ["kernel arguments here", "peak-current table requested, geometry constants here", "state rows requested", "state rows landed", "wire words requested", "first prelude done", "wire in LDS", "walk done",
+         "patches + reduce + epilogue done", "stores issued", "stores landed"]
+idx = [10, 11, 8, 9, 0, 2, 1, 3, 4, 5, 6]
 prev = raw[:, 7]
 for i, nm in zip(idx, names):
     d = raw[:, i] - prev
