@@ -104,7 +104,9 @@ enum wedm_f64_field {
 
 /* --------------------------------------------------------- int32 state rows */
 enum wedm_i32_field {
-    WEDM_I_TIME = 0,           /* state.time                       [us] */
+    WEDM_I_TIME = 0,           /* state.time [us], LOW 32 bits (unsigned, wraps); the high word is WEDM_I_TIME_HI:
+                                  the reference counts in unbounded Python ints (wire_edm.py:135).  Also Philox
+                                  counter word 0 (an episode's variates repeat after 2^32 us = 71.6 simulated minutes) */
     WEDM_I_SINCE_SERVO,        /* state.time_since_servo                */
     WEDM_I_SINCE_OPEN_V,       /* state.time_since_open_voltage         */
     WEDM_I_SINCE_IGNITION,     /* state.time_since_spark_ignition       */
@@ -118,6 +120,8 @@ enum wedm_i32_field {
     WEDM_I_KEY_LO,             /* Philox key, low  32 bits of the reset seed */
     WEDM_I_KEY_HI,             /* Philox key, high 32 bits of the reset seed */
     WEDM_I_SPARK_COUNT,        /* fresh sparks since reset (len(crater_volumes_um3), material.py:133) */
+    WEDM_I_TIME_HI,            /* state.time >> 32: bumped by wedm_step when the low word wraps inside a launch (a launch
+                                  advances an environment by less than 2^32 us; n_substeps * dt_us must stay below that) */
     WEDM_I32_COUNT
 };
 

@@ -865,9 +865,11 @@ int32_t wedm_oracle_step(wedm_oracle_env* e, const wedm_oracle_action* action) {
         return 1;
     }
     mechanics_update(e);
-    e->time += c->dt_us;
+    /* wire_edm.py:135-137.  `time` is an unbounded Python int there; here the low 32 bits (unsigned, wrapping: also the
+     * Philox counter word) -- the batch driver carries the high word, row WEDM_I_TIME_HI */
+    e->time = (int32_t)((uint32_t)e->time + (uint32_t)c->dt_us);
     e->time_since_servo += c->dt_us;
-    e->time_since_open_voltage += c->dt_us;
+    e->time_since_open_voltage = (int32_t)((uint32_t)e->time_since_open_voltage + (uint32_t)c->dt_us);
     if (e->spark_state == 1) {
         e->time_since_spark_ignition += c->dt_us;
         e->time_since_spark_end = 0;
@@ -1142,6 +1144,7 @@ int32_t wedm_oracle_step_batch(const wedm_params* p, const wedm_state_ptrs* s, c
                                       a->current_mode[e]};
             int done = 0;
             const double wp0 = v->workpiece_position;
+            const uint32_t t0 = (uint32_t)v->time;  /* low word of state.time at the start of the launch */
             for (int k = 0; k < n_substeps && !done; ++k) {
                 done = wedm_oracle_step(v, &act);
                 if (v->last_ctrl_step) write_obs(p, s, e, v);
@@ -1150,6 +1153,9 @@ int32_t wedm_oracle_step_batch(const wedm_params* p, const wedm_state_ptrs* s, c
             if (p->reward_mode && s->reward)
                 s->reward[e] = (float)(v->workpiece_position - wp0) -
                                (float)p->reward_break_penalty * (v->is_wire_broken ? 1.0f : 0.0f);
+            /* the clock's high word: the low word wrapped in this launch iff it ended below where it started
+             * (a launch advances an environment by less than 2^32 us) */
+            if ((uint32_t)v->time < t0) I32(WEDM_I_TIME_HI) += 1;
             scatter_env(s, e, v, done);
         }
         free(v);

@@ -89,9 +89,10 @@ class I32(enum.IntEnum):
     KEY_LO = 11
     KEY_HI = 12
     SPARK_COUNT = 13
+    TIME_HI = 14
 
 
-I32_COUNT = 14
+I32_COUNT = 15
 
 
 class I8(enum.IntEnum):

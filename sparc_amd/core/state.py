@@ -36,8 +36,10 @@ _FIELDS = {
     "h_eff_base": ("f64", F64.H_BASE), "h_eff_zone": ("f64", F64.H_ZONE),
     # the driver's 1 ms voltage history as running sums (run_simulation.py:258-281; include/wedm_hip.h)
     "voltage_sum_since_control_step": ("f64", F64.VOLT_ACC), "voltage_sum_at_control_step": ("f64", F64.VOLT_SUM),
-    "time": ("i32", I32.TIME), "time_since_servo": ("i32", I32.SINCE_SERVO),
-    "time_since_open_voltage": ("i32", I32.SINCE_OPEN_V),
+    # `state.time` / `state.time_since_open_voltage` are Python ints in the reference (wire_edm.py:135-137): here 64-bit,
+    # the low 32 bits (unsigned) in the rows below + the shared high word TIME_HI, composed on access (`_WIDE`)
+    "time_low32": ("i32", I32.TIME), "time_high32": ("i32", I32.TIME_HI), "time_since_servo": ("i32", I32.SINCE_SERVO),
+    "time_since_open_voltage_low32": ("i32", I32.SINCE_OPEN_V),
     "time_since_spark_ignition": ("i32", I32.SINCE_IGNITION),
     "time_since_spark_end": ("i32", I32.SINCE_SPARK_END), "spark_duration": ("i32", I32.SPARK_DUR),
     "random_short_remaining": ("i32", I32.RANDOM_SHORT_REM),
@@ -122,6 +124,11 @@ for _op in _BINARY_DUNDERS:
         other.tensor() if isinstance(other, WireTemperature) else other))(_op))
 
 
+# int64 attributes composed from a low-word row and the clock's high word (both clocks advance together, every step
+# that is not a wire-break early return: wire_edm.py:129-137)
+_WIDE = {"time": "time_low32", "time_since_open_voltage": "time_since_open_voltage_low32"}
+
+
 class BatchedEDMState:
     def __init__(self, num_envs: int, n_seg_max: int, obs_dim: int, device, crater_log_capacity: int = 0):
         stride = (num_envs + 63) // 64 * 64
@@ -162,13 +169,21 @@ class BatchedEDMState:
     def __getattr__(self, name: str):
         if name in _FIELDS:
             return self._view(name)
+        if name in _WIDE:  # exact 64-bit clock: (high word << 32) | unsigned low word
+            lo = self._view(_WIDE[name]).to(torch.int64) & 0xFFFFFFFF
+            return (self._view("time_high32").to(torch.int64) << 32) | lo
         derived = self.__dict__.get("derived", {})
         if name in derived:
             return derived[name]()
         raise AttributeError(name)
 
     def __setattr__(self, name: str, value) -> None:
-        if name in _FIELDS:
+        if name in _WIDE:
+            v = torch.as_tensor(value, dtype=torch.int64, device=self.device).expand(self.num_envs)
+            lo = v & 0xFFFFFFFF
+            self._view(_WIDE[name]).copy_(torch.where(lo >= 2**31, lo - 2**32, lo).to(torch.int32))
+            self._view("time_high32").copy_((v >> 32).to(torch.int32))
+        elif name in _FIELDS:
             view = self._view(name)
             if torch.is_tensor(value):
                 view.copy_(value.to(view.device))
@@ -197,7 +212,7 @@ class BatchedEDMState:
                               self.crater_log.shape[0] if self.crater_log is not None else 0)
 
     def field_names(self):
-        return tuple(_FIELDS)
+        return tuple(_FIELDS) + tuple(_WIDE)
 
     def clone_blocks(self):
         """Host copies of the raw blocks (used by checkpointing and by the parity tests)."""

@@ -369,6 +369,22 @@ __device__ __forceinline__ void load_env(const ColdRef cold, int64_t e, Env& v) 
     v.ipk = 0.0;
 }
 
+// The high word of `state.time` (row WEDM_I_TIME_HI; the reference counts in unbounded Python ints, wire_edm.py:135).
+// The microsecond loop only carries the low word; a launch advances an environment by less than 2^32 us, so the low
+// word wrapped inside this launch exactly when it ended below where it started.  Called by the writer lane BEFORE the
+// TIME row is stored: the row still holds the launch's starting value (reinit_env stores the reset value there).
+// `span` = n_substeps * dt_us: a low word that ended at or above it cannot have wrapped -- the rows are read only
+// behind that (almost never taken) test.
+__device__ __forceinline__ void store_time_hi(const ColdRef cold, int64_t e, const Env& v, uint32_t span) {
+    if ((uint32_t)v.time < span) {
+        const ColdPtr c = cold.get();
+        const int64_t stride = c->s.stride;
+        int32_t* const i32 = c->s.i32;
+        const uint32_t t0 = (uint32_t)*WEDM_ROW(i32, WEDM_I_TIME);
+        if ((uint32_t)v.time < t0) *WEDM_ROW(i32, WEDM_I_TIME_HI) += 1;
+    }
+}
+
 __device__ __forceinline__ void store_env(const ColdRef cold, int64_t e, const Env& v) {
     const ColdPtr c = cold.get();
     const int64_t stride = c->s.stride;
@@ -1129,9 +1145,9 @@ __device__ __forceinline__ void scalar_epilogue(const Hot& p, Env& s, float tmax
         s.x = x;
     }
 #endif
-    s.time += p.dt_us;
+    s.time = (int32_t)((uint32_t)s.time + (uint32_t)p.dt_us);  // low word of the 64-bit clock: wraps (store_time_hi)
     s.tss += p.dt_us;
-    s.tsov += p.dt_us;
+    s.tsov = (int32_t)((uint32_t)s.tsov + (uint32_t)p.dt_us);  // never reset by the reference either: in step with `time`
     if (s.state == 1) { s.tsi += p.dt_us; s.tse = 0; }
     else { s.tse += p.dt_us; s.tsi = 0; }
     if (s.x > s.wp + 100) { s.broken = 1; s.done = 1; }
@@ -1193,6 +1209,8 @@ __device__ __forceinline__ void reinit_env(const ColdRef cold, int64_t e, Env& s
         *WEDM_ROW(c->s.f64, WEDM_F_UNWIND_VEL) = s.unwind;
         *WEDM_ROW(c->s.f64, WEDM_F_VOLT_SUM) = 0.0;
         *WEDM_ROW(c->s.i32, WEDM_I_EPISODE) = episode;
+        *WEDM_ROW(c->s.i32, WEDM_I_TIME) = 0;      // store_time_hi's "low word at the start of the launch"
+        *WEDM_ROW(c->s.i32, WEDM_I_TIME_HI) = 0;
         if (c->s.stats) {
             *WEDM_ROW(c->s.stats, WEDM_S_CRATER_SUM) = 0.0; *WEDM_ROW(c->s.stats, WEDM_S_CRATER_SUMSQ) = 0.0;
             *WEDM_ROW(c->s.stats, WEDM_S_CRATER_MIN) = __builtin_inf(); *WEDM_ROW(c->s.stats, WEDM_S_CRATER_MAX) = -__builtin_inf();

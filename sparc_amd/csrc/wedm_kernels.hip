@@ -273,7 +273,8 @@ __global__ void __launch_bounds__(256) wedm_step_global(const KArgs k) {
         if (!frozen) write_reward(cold, e, s);
         else cold->s.reward[e] = 0.0f;
     }
-    store_env(cold, e, s);
+    store_time_hi(cold, e, s, (uint32_t)k.n_substeps * (uint32_t)k.hot.dt_us);
+        store_env(cold, e, s);
 }
 
 // np.max over finite temperatures; maps to v_max_f32 / v_max3_f32
@@ -460,6 +461,7 @@ __global__ void __launch_bounds__(256) wedm_step_split(const KArgs k) {
             if (!frozen0) write_reward(cold, e, s);
             else cold->s.reward[e] = 0.0f;  // a frozen environment earns nothing (not the previous launch's reward)
         }
+        store_time_hi(cold, e, s, (uint32_t)k.n_substeps * (uint32_t)k.hot.dt_us);
         store_env(cold, e, s);
     }
     WEDM_SPLIT_STAMP(6);
@@ -746,6 +748,7 @@ __global__ void __launch_bounds__(256, 2) wedm_step_lanes(const KArgs k) {
             if (!frozen0) write_reward(cold, e, s);
             else cold->s.reward[e] = 0.0f;  // a frozen environment earns nothing (not the previous launch's reward)
         }
+        store_time_hi(cold, e, s, (uint32_t)k.n_substeps * (uint32_t)k.hot.dt_us);
         store_env(cold, e, s);
     }
 }
@@ -1136,6 +1139,7 @@ __global__ void __launch_bounds__(256, 2) wedm_step_fused(const KArgs k) {
             if (!frozen0) write_reward(cold, e, s);
             else cold->s.reward[e] = 0.0f;  // a frozen environment earns nothing (not the previous launch's reward)
         }
+        store_time_hi(cold, e, s, (uint32_t)k.n_substeps * (uint32_t)k.hot.dt_us);
         store_env(cold, e, s);
     }
 }
@@ -1541,6 +1545,7 @@ __global__ void __launch_bounds__(256, 2) wedm_step_stream(const KArgs k) {
             cold->s.reward[e] = (float)(s.wp - wp0) - (float)pen * (s.broken ? 1.0f : 0.0f);
         }
         store_env_after_prelude(cold, e, s, quiet_only);
+        store_time_hi(cold, e, s, (uint32_t)k.n_substeps * (uint32_t)k.hot.dt_us);
         store_env_after_epilogue(cold, e, s);
     }
     WEDM_S2_STAMP(5);     // stores issued
@@ -1976,6 +1981,7 @@ __global__ void __launch_bounds__(256, 2) wedm_step_packed(const KArgs k) {
             if (!frozen0) write_reward(cold, e, s);
             else cold->s.reward[e] = 0.0f;  // a frozen environment earns nothing (not the previous launch's reward)
         }
+        store_time_hi(cold, e, s, (uint32_t)k.n_substeps * (uint32_t)k.hot.dt_us);
         store_env(cold, e, s);
     }
 }
@@ -2607,6 +2613,8 @@ int32_t wedm_bind_trace(wedm_ctx* ctx, const wedm_trace_desc* desc) {
                    i8_all = (1u << WEDM_I8_COUNT) - 1u;
     if ((desc->f64_mask & ~f64_all) || (desc->i32_mask & ~i32_all) || (desc->i8_mask & ~i8_all))
         return fail(ctx, WEDM_ERR_BAD_ARG, "wedm_bind_trace: mask names a row that does not exist");
+    if (desc->i32_mask & (1u << WEDM_I_TIME_HI))
+        return fail(ctx, WEDM_ERR_BAD_ARG, "wedm_bind_trace: TIME_HI is maintained at the end of a launch only (read it from the state block)");
     if (desc->f64_mask & (1u << WEDM_F_VOLT_SUM))
         return fail(ctx, WEDM_ERR_BAD_ARG, "wedm_bind_trace: VOLT_SUM is published at control steps only (read it from the state block)");
     if ((desc->f64_mask != 0) != (desc->f64 != nullptr) || (desc->i32_mask != 0) != (desc->i32 != nullptr) ||
@@ -2684,6 +2692,8 @@ int32_t wedm_step(wedm_ctx* ctx, int32_t n_substeps, const wedm_action_ptrs* act
     if (ctx->p.per_env_geometry && !ctx->geom_bound)
         return fail(ctx, WEDM_ERR_NOT_BOUND, "wedm_step: per_env_geometry set but wedm_bind_geometry not called");
     if (n_substeps == 0) return WEDM_OK;
+    if ((uint64_t)n_substeps * (uint64_t)ctx->p.dt_us >= (1ull << 31))
+        return fail(ctx, WEDM_ERR_BAD_ARG, "wedm_step: n_substeps * dt_us must stay below 2^31 us per launch (the clock's high word is carried per launch)");
     if (int32_t rc = check_device(ctx, "wedm_step")) return rc;
 
     const wedm_params& P = ctx->p;

@@ -266,12 +266,10 @@ class WireEDMEnv:
         act = self._prepare_action(action)
         self._last_action = act  # keep the tensors alive while the launch is in flight
         n_substeps = int(n_substeps)
-        # `state.time` is an int32 microsecond count (and a Philox counter word): refuse to run past it.
-        # steps_since_reset bounds every environment's clock from above (a masked reset only lowers clocks).
-        if (self.steps_since_reset + n_substeps) * self.dt > _TIME_LIMIT_US:
-            raise OverflowError(
-                f"state.time would pass {_TIME_LIMIT_US} us (int32, ~35.8 simulated minutes) in some environment: "
-                "reset() the batch first (the reference counts time in unbounded Python ints, wire_edm.py:135)")
+        # (`state.time` is 64-bit: the kernels carry its low word and bump the high word once per launch, so a single
+        # launch may not advance an environment by 2**31 us or more; nothing limits the number of launches)
+        if n_substeps * self.dt >= 2**31:
+            raise ValueError(f"one launch may advance an environment by less than 2**31 us (asked: {n_substeps} x {self.dt} us)")
         self._backend.step(n_substeps, act.ptrs)
         self.steps_since_reset += n_substeps
         # obs / done / info are views of caller-owned memory the kernel has just (asynchronously)
@@ -283,7 +281,7 @@ class WireEDMEnv:
                 "wire_broken": st.is_wire_broken,
                 "target_reached": st.is_target_distance_reached,
                 "spark_state": st.spark_state,
-                "time": st.time,
+                "time": st.time_low32,  # (the zero-cost view: low 32 bits of the clock; `env.state.time` is the exact int64)
                 "control_step": st.control_step,
             })
         return out[0], self._reward, out[1], self._truncated, dict(out[2])
@@ -514,8 +512,6 @@ class WireEDMEnv:
     def wire_diameter(self) -> float:
         return self.config.wire_diameter
 
-
-_TIME_LIMIT_US = 2**31 - 1
 
 
 def _to_numpy(x):

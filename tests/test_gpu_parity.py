@@ -856,6 +856,34 @@ def test_randomized_configurations_all_kernels_bit_exact(case):
     assert ran >= (2 if case < 20 else 1)   # (a widened hunt may draw three kernels that do not fit the geometry)
 
 
+@pytest.mark.parametrize("variant,lanes", [(1, 0), (2, 4), (3, 8), (4, 4), (5, 0), (6, 8)])
+def test_clock_high_word_across_the_32_bit_wrap_matches_oracle(variant, lanes):
+    """`state.time` past 2**31 and 2**32 us: the kernels carry the low word (also the Philox counter word) through the
+    launch and bump row TIME_HI when it wrapped inside it; every kernel == the oracle on every byte, in fused and in
+    single-microsecond launches, with autoreset (a re-initialised environment starts again at 0 / 0)."""
+    n = 192
+    kw = dict(autoreset=True, config=EnvironmentConfig(target_cutting_distance=5000.0))
+    gpu, cpu = make_pair(n, **kw)
+    start = torch.tensor([2**31 - 300, 2**32 - 300, 2**32 - 1, 5 * 2**32 - 40] * (n // 4))
+    for env in (gpu, cpu):
+        env.reset(seed=5)
+        close_gap(env, 22.0, 10.0)
+        env.state.target_position = torch.where(torch.arange(n) % 5 == 1, 22.000001, 5000.0)   # the first crater terminates these: re-initialised by the next launch
+        env.state.time = start
+        env.state.time_since_open_voltage = start
+    gpu.set_kernel(variant, lanes)
+    for env in (gpu, cpu):
+        a = env.make_action(0.1, 80.0, 9, 3.0, 30.0)
+        for k in (1, 1, 298, 1, 1, 1200):
+            env.step_many(a, k)
+    check(gpu, cpu, n)
+    t = gpu.state.time.cpu()
+    alive = gpu.state.episode.cpu() == 0
+    assert alive.sum() > n // 2 and (~alive).sum() > 0
+    assert torch.equal(t[alive], (start + 1502)[alive]) and int(t[~alive].max()) < 1502
+    assert (gpu.state.time_high32.cpu()[alive] == ((start + 1502) >> 32)[alive]).all()
+
+
 SWEEP_N = list(range(9, 171))
 
 

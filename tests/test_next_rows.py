@@ -8,7 +8,7 @@ import pytest
 import torch
 
 from oracle import oracle as orc
-from sparc_amd import (GapController, SimulationLogger, WireEDMEnv, WireEDMVectorEnv, run_controlled)
+from sparc_amd import (EnvironmentConfig, GapController, SimulationLogger, WireEDMEnv, WireEDMVectorEnv, run_controlled)
 from tests._fixture_env import check_step
 from tests._golden import Fixture
 from tests._oracle_backend import OracleBackend
@@ -190,22 +190,44 @@ def test_checkpoint_resume_is_bit_identical(tmp_path):
                    mechanics_params=MechanicsModuleParameters(zeta=0.5)).load_checkpoint(tmp_path / "ck.pt")
 
 
-def test_time_counter_guard_raises_before_the_int32_clock_wraps():
-    """`state.time` is an int32 microsecond count and a Philox counter word (the reference counts in
-    Python ints, wire_edm.py:135): stepping past 2**31 - 1 us raises instead of wrapping."""
-    env = WireEDMEnv(num_envs=2, device="cpu", backend=OracleBackend)
+def test_the_clock_is_64_bit_and_no_launch_count_limits_a_run():
+    """`state.time` is an unbounded Python int in the reference (wire_edm.py:135).  Here: low 32 bits in the row the
+    kernels carry (also the Philox counter word) + a high word bumped when the low word wraps inside a launch, so an
+    environment's own clock stays exact past 2**31 and 2**32 us, and nothing counts LAUNCHES: an autoreset batch can be
+    stepped for ever (round 2 raised OverflowError after 2**31 cumulated microseconds, i.e. ~2.9 h of training, although
+    every environment's own clock had been reset thousands of times)."""
+    env = WireEDMEnv(num_envs=3, device="cpu", backend=OracleBackend, autoreset=True,
+                     config=EnvironmentConfig(target_cutting_distance=5000.0))
     env.reset(seed=1)
     act = env.make_action()
     env.step_many(act, 10)
-    env.steps_since_reset = 2**31 - 1 - 5     # as if ~35.8 simulated minutes had been run
-    env.step_many(act, 5)
-    with pytest.raises(OverflowError):
-        env.step_many(act, 1)
-    env.reset(options={"mask": [True, False]})  # a partial reset does not lift the bound
-    with pytest.raises(OverflowError):
-        env.step_many(act, 1)
-    env.reset()
-    env.step_many(act, 1)
+    env.steps_since_reset = 2**31 - 1 - 5          # as if ~35.8 simulated minutes of launches had been cumulated
+    env.step_many(act, 700)                         # no OverflowError
+    assert env.state.time.tolist() == [710, 710, 710] and env.state.time.dtype == torch.int64
+    # per-environment clocks across the sign bit and across the 32-bit wrap, against a twin that never comes near them
+    twin = WireEDMEnv(num_envs=3, device="cpu", backend=OracleBackend, autoreset=True,
+                      config=EnvironmentConfig(target_cutting_distance=5000.0))
+    twin.reset(seed=1)
+    twin.step_many(act, 710)
+    env.state.time = torch.tensor([2**31 - 300, 2**32 - 300, 3 * 2**32 - 1])
+    env.state.time_since_open_voltage = env.state.time
+    assert env.state.time.tolist() == [2**31 - 300, 2**32 - 300, 3 * 2**32 - 1]
+    for k in (1, 299, 1, 1500, 1):
+        env.step_many(act, k)
+        twin.step_many(act, k)
+    assert env.state.time.tolist() == [2**31 + 1502, 2**32 + 1502, 3 * 2**32 + 1801]
+    assert env.state.time_since_open_voltage.tolist() == env.state.time.tolist()
+    assert env.state.time_high32.tolist() == [0, 1, 3] and twin.state.time.tolist() == [2512] * 3
+    # the physics does not read the clock; only the variates do (Philox counter word = low 32 bits), so positions differ
+    # from the twin's while every invariant of the step holds
+    assert (env.state.time_since_servo == twin.state.time_since_servo).all()
+    # assignment through the wide attribute round-trips
+    env.state.time = 5
+    assert env.state.time.tolist() == [5, 5, 5] and env.state.time_high32.tolist() == [0, 0, 0]
+    # one launch may not span 2**31 us (the high word is carried per launch)
+    long_dt = WireEDMEnv(num_envs=1, device="cpu", backend=OracleBackend, config=EnvironmentConfig(dt=4, servo_interval=1000))
+    with pytest.raises(ValueError, match="2\\*\\*31"):
+        long_dt.step_many(long_dt.make_action(), 2**29)
 
 
 def terminating_pair(n, backend, device="cpu", **kw):

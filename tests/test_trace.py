@@ -48,7 +48,8 @@ def test_trace_equals_per_microsecond_reads_and_ring_wraps():
         for _ in range(launch):
             b.step(act_b)
             for k in names:
-                v = getattr(b.state, "spark_state" if k == "spark_status" else k)
+                # (a trace records the rows the kernels carry: the clock's low 32 bits; `state.time` is the 64-bit value)
+                v = getattr(b.state, {"spark_status": "spark_state", "time": "time_low32"}.get(k, k))
                 want[k].append(v[2:5].clone())
             want["wire_temperature"].append(b.state.wire_temperature[2:5].clone())
     assert trace.count == 950
