@@ -134,6 +134,10 @@ enum wedm_i8_field {
     WEDM_B_DONE,               /* terminated: the environment is frozen until reset */
     WEDM_B_CTRL_STEP,          /* info["control_step"] of the LAST substep run */
     WEDM_B_ERROR,              /* sticky: 1 = fresh spark with a mode that has no crater data */
+    WEDM_B_MODE_CACHED,        /* IgnitionModule._cached_current_mode is not None (ignition.py:79-81,98-113): a peak current
+                                  has been looked up for a latched mode.  Survives a reset with reset_semantics 1; while
+                                  state.current_mode is None, a set flag makes the lookup answer `default_current`
+                                  instead of the fresh module's 60 A */
     WEDM_I8_COUNT
 };
 
@@ -249,7 +253,19 @@ typedef struct wedm_params {
      * NumPy-2 scalar promotion evaluates it, i.e. without Numba); 1 = float64 expressions rounded at each
      * float32 store (how Numba types the same lines; without fastmath re-association).                 */
     int32_t stencil_mode;
-    int32_t reserved0, reserved1;
+    /* what wedm_reset (and the in-launch autoreset) re-initialises: 0 = everything, module-private state included (a
+     * fresh environment: the default, documented deviation); 1 = what the reference's reset() does (wire_edm.py:106-114):
+     * a new EDMState only -- the module objects live on, so the ignition short timers and current cache
+     * (ignition.py:75-81), the debris volume and the flow / density caches (dielectric.py:69-80), `prev_accel`
+     * (mechanics.py:60), the convection cache and coefficients (wire.py:205,224) and the crater list / statistics
+     * (material.py:133) carry over into the next episode.                                                        */
+    int32_t reset_semantics;
+    /* 0 = a terminated environment is frozen until it is reset (the default, documented deviation); 1 = it keeps being
+     * stepped as the reference does when step() is called after `terminated` (wire_edm.py:116-157 has no guard): after a
+     * wire break the wire module returns at once (wire.py:260-261) and the step returns before mechanics and clocks
+     * (wire_edm.py:129-130); after the cutting target everything goes on.  WEDM_B_DONE then holds `terminated` of the
+     * last step (is_wire_broken or is_target_distance_reached) and freezes nothing.                              */
+    int32_t keep_stepping_terminated;
     double reward_break_penalty;  /* reward_mode 1 */
 } wedm_params;
 
@@ -346,9 +362,13 @@ int32_t wedm_bind_state(wedm_ctx* ctx, const wedm_state_ptrs* state);
 int32_t wedm_bind_geometry(wedm_ctx* ctx, const wedm_geom_ptrs* geom);
 
 /* replaces WireEDMEnv.reset (wire_edm.py:106-114) for the environments whose
- * mask byte is non-zero (mask == NULL: all).  Re-keys their RNG with `seed`
- * when reseed != 0, else bumps their episode counter.  Module-private state is
- * reset too (documented deviation).                                */
+ * mask byte is non-zero (mask == NULL: all).  `reseed` bit 0: re-key their RNG with
+ * `seed` (else their episode counter is bumped).  Module-private state is reset too
+ * unless wedm_params.reset_semantics is 1 (the reference's own reset); `reseed` bit 1
+ * (WEDM_RESET_FRESH) resets it whatever the semantics -- what constructing the module
+ * objects does in WireEDMEnv.__init__ (wire_edm.py:60-82): a handle's first reset. */
+#define WEDM_RESET_RESEED 1
+#define WEDM_RESET_FRESH 2
 int32_t wedm_reset(wedm_ctx* ctx, const uint8_t* mask, uint64_t seed, int32_t reseed, void* stream);
 
 /* replaces `n_substeps` consecutive WireEDMEnv.step(action) calls

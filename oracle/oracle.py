@@ -113,7 +113,7 @@ class Env(C.Structure):
         ("crater_stat_sum", _d), ("crater_stat_sumsq", _d), ("crater_stat_min", _d), ("crater_stat_max", _d),
         ("crater_log", C.c_void_p), ("crater_log_capacity", C.c_int64), ("crater_log_stride", C.c_int64),
         ("tmax", C.c_float),
-        ("last_terminated", _i), ("last_ctrl_step", _i), ("last_early_return", _i),
+        ("last_terminated", _i), ("last_ctrl_step", _i), ("last_early_return", _i), ("mode_cached", _i),
         ("T", C.c_float * MAX_SEG), ("dT", C.c_float * MAX_SEG),
     ]
 
@@ -159,6 +159,8 @@ def lib() -> C.CDLL:
     L.wedm_oracle_init.restype = _i
     L.wedm_oracle_reset.argtypes = [C.POINTER(Env)]
     L.wedm_oracle_reset.restype = None
+    L.wedm_oracle_reset_reference.argtypes = [C.POINTER(Env)]
+    L.wedm_oracle_reset_reference.restype = None
     L.wedm_oracle_step.argtypes = [C.POINTER(Env), C.POINTER(Action)]
     L.wedm_oracle_step.restype = _i
     L.wedm_oracle_philox4x32_10.argtypes = [C.POINTER(C.c_uint32), C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]

@@ -420,7 +420,37 @@ void wedm_oracle_reset(wedm_oracle_env* e) {
     e->spark_count = 0;
     e->crater_stat_sum = 0.0; e->crater_stat_sumsq = 0.0; e->crater_stat_min = INFINITY; e->crater_stat_max = -INFINITY;
     e->last_terminated = 0; e->last_ctrl_step = 0; e->last_early_return = 0;
+    e->mode_cached = 0;
     for (int i = 0; i < c->n_seg; ++i) { e->T[i] = (float)c->spool_T; e->dT[i] = 0.0f; } /* wire.py:264-269 */
+    e->tmax = (float)c->spool_T;
+}
+
+/* wire_edm.py:106-114 on a used environment: `self.state = EDMState()` + the two configured positions.  Everything the
+ * MODULE objects keep outside the state survives: ignition.py:75-81 (short timers, current cache), dielectric.py:69-80
+ * (debris volume; flow, gap and density caches), mechanics.py:60 (prev_accel), wire.py:205,224 (convection coefficients
+ * and their flow cache), material.py:133 (crater list -> count and statistics).  The new state's empty
+ * `wire_temperature` is re-allocated at the spool temperature by the first wire.update (wire.py:264-269). */
+void wedm_oracle_reset_reference(wedm_oracle_env* e) {
+    const wedm_oracle_consts* c = &e->c;
+    e->error = 0;
+    e->time = 0; e->time_since_servo = 0; e->time_since_open_voltage = 0;
+    e->time_since_spark_ignition = 0; e->time_since_spark_end = 0;
+    e->voltage = 0.0; e->current = 0.0;
+    e->target_voltage = 0.0; e->on_time = 0.0; e->off_time = 0.0; e->current_mode = 0;
+    e->workpiece_position = c->initial_gap;
+    e->wire_position = 0.0; e->wire_velocity = 0.0; e->wire_unwinding_velocity = 0.2;
+    e->time_in_critical_temp = 0;
+    e->spark_state = 0; e->spark_dur = 0; e->spark_y = NAN;
+    e->dielectric_temperature = 0.0;
+    e->debris_density = 0.0; /* state.debris_density: what ignition reads on the first step (ignition.py:213) */
+    e->cavity_volume = 0.0;
+    e->last_crater_volume = 0.0;
+    e->is_short_circuit = 0; e->is_wire_broken = 0; e->is_target_reached = 0;
+    e->target_delta = 0.0;
+    e->target_position = c->target_cutting_distance;
+    e->volt_acc = 0.0; e->volt_sum = 0.0; /* the driver's history belongs to one run of its loop */
+    e->last_terminated = 0; e->last_ctrl_step = 0; e->last_early_return = 0;
+    for (int i = 0; i < c->n_seg; ++i) { e->T[i] = (float)c->spool_T; e->dT[i] = 0.0f; }
     e->tmax = (float)c->spool_T;
 }
 
@@ -449,10 +479,13 @@ static double get_off_time(const wedm_oracle_env* e) {
 /* ignition.py:98-113 with the cache of ignition.py:79-81.  A fresh module starts with
  * `_cached_current_mode = None, _cached_current_value = 60.0`, so `current_mode is None` (before
  * the first control-step latch) HITS the cache and yields 60 A whatever `default_current_mode`
- * says; that parameter only serves modes that are not in currents.json. */
-static double get_peak_current(const wedm_oracle_env* e) {
+ * says; that parameter only serves modes that are not in currents.json.
+ * After a reset that keeps the module (wedm_oracle_reset_reference) the cache may hold a mode of the previous episode:
+ * None then misses it and resolves through `default_current_mode`. */
+static double get_peak_current(wedm_oracle_env* e) {
     int m = e->current_mode;
-    if (m == 0) return 60.0;
+    if (m == 0) return e->mode_cached ? e->c.default_current : 60.0;
+    e->mode_cached = 1; /* `_cached_current_mode` now names a mode (an unknown one is replaced by the default, :107-110) */
     if (m < 1 || m > WEDM_MAX_MODE) return e->c.default_current;
     return e->c.mode_current[m];
 }
@@ -994,6 +1027,7 @@ static void gather_env(const wedm_state_ptrs* s, int64_t e, wedm_oracle_env* v) 
     v->spark_state = I8(WEDM_B_SPARK_STATE); v->is_short_circuit = I8(WEDM_B_IS_SHORT);
     v->is_wire_broken = I8(WEDM_B_WIRE_BROKEN); v->is_target_reached = I8(WEDM_B_TARGET_REACHED);
     v->error = I8(WEDM_B_ERROR);
+    v->mode_cached = I8(WEDM_B_MODE_CACHED);
     v->dielectric_temperature = v->c.dielectric_temperature;
     for (int i = 0; i < v->c.n_seg; ++i) v->T[i] = s->T[WEDM_T_INDEX(i, stride, e)];  /* quad-interleaved block, include/wedm_hip.h */
 }
@@ -1029,6 +1063,7 @@ static void scatter_env(const wedm_state_ptrs* s, int64_t e, const wedm_oracle_e
     I8(WEDM_B_WIRE_BROKEN) = (int8_t)v->is_wire_broken; I8(WEDM_B_TARGET_REACHED) = (int8_t)v->is_target_reached;
     I8(WEDM_B_DONE) = (int8_t)done; I8(WEDM_B_CTRL_STEP) = (int8_t)v->last_ctrl_step;
     I8(WEDM_B_ERROR) = (int8_t)(v->error & 1);
+    I8(WEDM_B_MODE_CACHED) = (int8_t)(v->mode_cached & 1);
     for (int i = 0; i < v->c.n_seg; ++i) s->T[WEDM_T_INDEX(i, stride, e)] = v->T[i];
 }
 
@@ -1060,15 +1095,26 @@ int32_t wedm_oracle_max_threads(void) {
  * fresh environment), Philox episode bumped or the stream re-keyed. */
 static void reset_env_rows(const wedm_params* p, const wedm_state_ptrs* s, int64_t e, uint64_t seed, int32_t reseed) {
     int64_t stride = s->stride;
-    for (int f = 0; f < WEDM_F64_COUNT; ++f) F64(f) = 0.0;
+    /* wedm_params.reset_semantics 1: the reference's own reset() (wire_edm.py:106-114) re-initialises EDMState only; the
+     * rows that mirror what its module objects hold survive (see wedm_oracle_reset_reference) */
+    const int keep_modules = p->reset_semantics != 0 && !(reseed & WEDM_RESET_FRESH);
+    const uint32_t module_f64 = (1u << WEDM_F_PREV_ACCEL) | (1u << WEDM_F_DEBRIS_VOLUME) | (1u << WEDM_F_FLOW) |
+                                (1u << WEDM_F_LAST_GAP) | (1u << WEDM_F_LAST_DENSITY) | (1u << WEDM_F_WIRE_LAST_FLOW) |
+                                (1u << WEDM_F_H_BASE) | (1u << WEDM_F_H_ZONE);
+    const uint32_t module_i32 = (1u << WEDM_I_RANDOM_SHORT_REM) | (1u << WEDM_I_DEBRIS_SHORT_REM) | (1u << WEDM_I_SPARK_COUNT);
+    const uint32_t module_i8 = 1u << WEDM_B_MODE_CACHED;
+    for (int f = 0; f < WEDM_F64_COUNT; ++f)
+        if (!(keep_modules && ((module_f64 >> f) & 1u))) F64(f) = 0.0;
     int32_t episode = I32(WEDM_I_EPISODE), klo = I32(WEDM_I_KEY_LO), khi = I32(WEDM_I_KEY_HI);
-    for (int f = 0; f < WEDM_I32_COUNT; ++f) I32(f) = 0;
-    for (int f = 0; f < WEDM_I8_COUNT; ++f) I8(f) = 0;
-    if (s->stats) {
+    for (int f = 0; f < WEDM_I32_COUNT; ++f)
+        if (!(keep_modules && ((module_i32 >> f) & 1u))) I32(f) = 0;
+    for (int f = 0; f < WEDM_I8_COUNT; ++f)
+        if (!(keep_modules && ((module_i8 >> f) & 1u))) I8(f) = 0;
+    if (s->stats && !keep_modules) {
         STAT(WEDM_S_CRATER_SUM) = 0.0; STAT(WEDM_S_CRATER_SUMSQ) = 0.0;
         STAT(WEDM_S_CRATER_MIN) = INFINITY; STAT(WEDM_S_CRATER_MAX) = -INFINITY;
     }
-    if (reseed) {
+    if (reseed & WEDM_RESET_RESEED) {
         I32(WEDM_I_EPISODE) = 0;
         I32(WEDM_I_KEY_LO) = (int32_t)(uint32_t)seed;
         I32(WEDM_I_KEY_HI) = (int32_t)(uint32_t)(seed >> 32);
@@ -1081,8 +1127,10 @@ static void reset_env_rows(const wedm_params* p, const wedm_state_ptrs* s, int64
     F64(WEDM_F_TARGET_POS) = p->target_cutting_distance;
     F64(WEDM_F_UNWIND_VEL) = 0.2;
     F64(WEDM_F_SPARK_Y) = NAN;
-    F64(WEDM_F_LAST_GAP) = -1.0;
-    F64(WEDM_F_LAST_DENSITY) = -1.0;
+    if (!keep_modules) {
+        F64(WEDM_F_LAST_GAP) = -1.0;
+        F64(WEDM_F_LAST_DENSITY) = -1.0;
+    }
     F64(WEDM_F_TMAX) = (double)(float)p->spool_T;
     if (s->reward) s->reward[e] = 0.0f;
 }
@@ -1122,10 +1170,12 @@ int32_t wedm_oracle_step_batch(const wedm_params* p, const wedm_state_ptrs* s, c
 #endif
         for (int64_t e = 0; e < num_envs; ++e) {
             if (I8(WEDM_B_DONE)) {
-                if (!p->autoreset) {  /* frozen until the caller resets it: it earns nothing in this launch */
+                if (!p->autoreset && !p->keep_stepping_terminated) {  /* frozen until the caller resets it: it earns nothing in this launch */
                     if (p->reward_mode && s->reward) s->reward[e] = 0.0f;
                     continue;
                 }
+            }
+            if (I8(WEDM_B_DONE) && p->autoreset) {
                 /* wedm_params.autoreset: next-step autoreset inside the call = wedm_reset(mask = DONE, reseed = 0)
                  * for this environment (all n_seg_max wire rows at the spool temperature, observation zeroed) */
                 reset_env_rows(p, s, e, 0, 0);
@@ -1145,7 +1195,9 @@ int32_t wedm_oracle_step_batch(const wedm_params* p, const wedm_state_ptrs* s, c
             int done = 0;
             const double wp0 = v->workpiece_position;
             const uint32_t t0 = (uint32_t)v->time;  /* low word of state.time at the start of the launch */
-            for (int k = 0; k < n_substeps && !done; ++k) {
+            /* a terminated environment is frozen; with wedm_params.keep_stepping_terminated it is stepped on as the
+             * reference's step() would be (wire_edm.py:116-157 has no guard), DONE = `terminated` of the last step */
+            for (int k = 0; k < n_substeps && (!done || p->keep_stepping_terminated); ++k) {
                 done = wedm_oracle_step(v, &act);
                 if (v->last_ctrl_step) write_obs(p, s, e, v);
             }

@@ -163,6 +163,9 @@ typedef struct wedm_oracle_env {
     float tmax;
     /* step() outputs */
     int32_t last_terminated, last_ctrl_step, last_early_return;
+    /* IgnitionModule._cached_current_mode is not None (ignition.py:79-81,98-113): a peak current has been looked up for a
+     * latched mode; survives wedm_oracle_reset_reference() */
+    int32_t mode_cached;
     float T[WEDM_ORACLE_MAX_SEG];
     float dT[WEDM_ORACLE_MAX_SEG];
 } wedm_oracle_env;
@@ -178,6 +181,10 @@ int32_t wedm_oracle_derive(const wedm_oracle_config* cfg, wedm_oracle_consts* ou
 /* fresh environment followed by one reset(): wire_edm.py:22-114 */
 int32_t wedm_oracle_init(wedm_oracle_env* env, const wedm_oracle_config* cfg);
 void wedm_oracle_reset(wedm_oracle_env* env);
+/* WireEDMEnv.reset as the reference does it on a USED environment (wire_edm.py:106-114): a new EDMState only; what the
+ * module objects hold lives on (short timers, current cache, debris volume, flow / density / convection caches,
+ * prev_accel, crater list and statistics) */
+void wedm_oracle_reset_reference(wedm_oracle_env* env);
 /* WireEDMEnv.step: wire_edm.py:116-157.  Returns terminated (0/1). */
 int32_t wedm_oracle_step(wedm_oracle_env* env, const wedm_oracle_action* action);
 

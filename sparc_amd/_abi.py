@@ -105,9 +105,10 @@ class I8(enum.IntEnum):
     DONE = 4
     CTRL_STEP = 5
     ERROR = 6
+    MODE_CACHED = 7
 
 
-I8_COUNT = 7
+I8_COUNT = 8
 
 
 class STAT(enum.IntEnum):
@@ -191,7 +192,7 @@ class Params(C.Structure):
         ("crater_valid", _itab),
         ("env_id_offset", C.c_uint32), ("obs_dim", _i),
         ("disable_ignition", _i), ("autoreset", _i), ("reward_mode", _i), ("stencil_mode", _i),
-        ("reserved0", _i), ("reserved1", _i),
+        ("reset_semantics", _i), ("keep_stepping_terminated", _i),
         ("reward_break_penalty", _d),
     ]
 

@@ -154,9 +154,11 @@ class HipBackend:
             return _NO_GUARD
         return torch.cuda.device(self.device)
 
-    def reset(self, mask_ptr, seed: int, reseed: bool) -> None:
+    def reset(self, mask_ptr, seed: int, reseed: bool, fresh: bool = False) -> None:
+        """`fresh`: WEDM_RESET_FRESH -- module-private state too, whatever `reset_semantics` (a handle's first reset)."""
         with self._on_device():
-            self._check(self._L.wedm_reset(self._ctx, mask_ptr, seed & (2**64 - 1), 1 if reseed else 0, self._stream()))
+            flags = (1 if reseed else 0) | (2 if fresh else 0)
+            self._check(self._L.wedm_reset(self._ctx, mask_ptr, seed & (2**64 - 1), flags, self._stream()))
 
     def step(self, n_substeps: int, action: _abi.ActionPtrs) -> None:
         with self._on_device():

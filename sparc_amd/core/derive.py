@@ -94,7 +94,8 @@ def build_params(config: EnvironmentConfig, control_mode: str, ignition: Ignitio
                  dielectric: DielectricModuleParameters, mechanics: MechanicsModuleParameters,
                  material: WireMaterial, *, geometry: Optional[WireGeometry], env_id_offset: int = 0,
                  obs_dim: int = _abi.OBS_DIM, disable_ignition: bool = False, autoreset: bool = False,
-                 reward_mode: int = 0, reward_break_penalty: float = 10.0, stencil_mode: int = 0) -> _abi.Params:
+                 reward_mode: int = 0, reward_break_penalty: float = 10.0, stencil_mode: int = 0,
+                 reset_semantics: int = 0, keep_stepping_terminated: bool = False) -> _abi.Params:
     """Fill ``struct wedm_params``.  ``geometry=None`` means per-environment rows."""
     p = _abi.Params()
     p.servo_interval = int(config.servo_interval)
@@ -171,6 +172,8 @@ def build_params(config: EnvironmentConfig, control_mode: str, ignition: Ignitio
     p.reward_mode = int(reward_mode)
     p.stencil_mode = int(stencil_mode)
     p.reward_break_penalty = float(reward_break_penalty)
+    p.reset_semantics = int(reset_semantics)
+    p.keep_stepping_terminated = 1 if keep_stepping_terminated else 0
     return p
 
 

@@ -50,6 +50,7 @@ _FIELDS = {
     "is_short_circuit": ("b", I8.IS_SHORT), "is_wire_broken": ("b", I8.WIRE_BROKEN),
     "is_target_distance_reached": ("b", I8.TARGET_REACHED), "done": ("b", I8.DONE),
     "control_step": ("b", I8.CTRL_STEP), "error": ("b", I8.ERROR),
+    "ignition_mode_cached": ("b", I8.MODE_CACHED),  # IgnitionModule._cached_current_mode is not None (ignition.py:79-81)
 }
 
 

@@ -203,6 +203,9 @@ struct Hot {
     int32_t servo_interval, dt_us, control_mode, disable_ignition, has_random_short, per_env_geometry;
     uint32_t env_id_offset;
     int32_t n_seg;  // uniform geometry only
+    // what a terminating step writes into the lane's `done` (= "frozen") register: 1, or 0 with
+    // wedm_params.keep_stepping_terminated (nothing is ever frozen then; store_env derives the DONE row from the flags)
+    int32_t done_value;
 };
 
 // Pin the float64 every-step constants in VGPRs (same value in every lane).  gfx9 VALU
@@ -332,8 +335,14 @@ __device__ __forceinline__ const WEDM_AS4 T* opaque_const(const T* p) {
 // ignition.py:98-113 with the module's initial cache (ignition.py:79-81): mode None (0, before the
 // first latch) hits the fresh cache and yields 60 A whatever `default_current_mode` is; that
 // parameter only serves modes outside currents.json.
-__device__ __forceinline__ double peak_current(const ColdRef cold, int32_t mode) {
-    if (mode == 0) return 60.0;
+// After a reset with reset_semantics 1 (the reference's own: the module object lives on) the cache may hold a mode of the
+// previous episode: None then misses it and resolves through `default_current_mode` (flag WEDM_B_MODE_CACHED, read only
+// on this rare path).
+__device__ __forceinline__ double peak_current(const ColdRef cold, int32_t mode, int64_t e) {
+    if (mode == 0) {
+        const ColdPtr c = cold.get();
+        return c->s.i8[(int64_t)WEDM_B_MODE_CACHED * c->s.stride + e] ? opaque(c->p)->default_current : 60.0;
+    }
     return (mode >= 1 && mode <= WEDM_MAX_MODE) ? cold->tb.mode_current[mode] : opaque(cold->p)->default_current;
 }
 
@@ -385,6 +394,12 @@ __device__ __forceinline__ void store_time_hi(const ColdRef cold, int64_t e, con
     }
 }
 
+// Row WEDM_B_DONE: the lane's frozen flag, or -- with keep_stepping_terminated, where nothing freezes -- `terminated` of
+// the last step as the reference's step() returns it: both of its causes are sticky flags (wire_edm.py:129-130,172-179).
+__device__ __forceinline__ int32_t done_row(const ColdRef cold, const Env& v) {
+    return opaque(cold->p)->keep_stepping_terminated ? (v.broken | v.reached) : v.done;
+}
+
 __device__ __forceinline__ void store_env(const ColdRef cold, int64_t e, const Env& v) {
     const ColdPtr c = cold.get();
     const int64_t stride = c->s.stride;
@@ -409,7 +424,7 @@ __device__ __forceinline__ void store_env(const ColdRef cold, int64_t e, const E
     *WEDM_ROW(s.i32, WEDM_I_SPARK_COUNT) = v.sparks;
     *WEDM_ROW(s.i8, WEDM_B_SPARK_STATE) = (int8_t)v.state; *WEDM_ROW(s.i8, WEDM_B_IS_SHORT) = (int8_t)v.is_short;
     *WEDM_ROW(s.i8, WEDM_B_WIRE_BROKEN) = (int8_t)v.broken; *WEDM_ROW(s.i8, WEDM_B_TARGET_REACHED) = (int8_t)v.reached;
-    *WEDM_ROW(s.i8, WEDM_B_DONE) = (int8_t)v.done; *WEDM_ROW(s.i8, WEDM_B_CTRL_STEP) = (int8_t)v.ctrl;
+    *WEDM_ROW(s.i8, WEDM_B_DONE) = (int8_t)done_row(cold, v); *WEDM_ROW(s.i8, WEDM_B_CTRL_STEP) = (int8_t)v.ctrl;
     *WEDM_ROW(s.i8, WEDM_B_ERROR) = (int8_t)v.err;
 }
 
@@ -495,7 +510,7 @@ __device__ __forceinline__ void store_env_after_epilogue(const ColdRef cold, int
     *WEDM_ROW(s.i32, WEDM_I_SINCE_OPEN_V) = v.tsov; *WEDM_ROW(s.i32, WEDM_I_SINCE_IGNITION) = v.tsi;
     *WEDM_ROW(s.i32, WEDM_I_SINCE_SPARK_END) = v.tse; *WEDM_ROW(s.i32, WEDM_I_TIME_CRITICAL) = v.tcrit;
     *WEDM_ROW(s.i8, WEDM_B_WIRE_BROKEN) = (int8_t)v.broken; *WEDM_ROW(s.i8, WEDM_B_TARGET_REACHED) = (int8_t)v.reached;
-    *WEDM_ROW(s.i8, WEDM_B_DONE) = (int8_t)v.done;
+    *WEDM_ROW(s.i8, WEDM_B_DONE) = (int8_t)done_row(cold, v);
 }
 
 // Make the compiler treat every loaded state register as USED here: it inserts the wait for the state
@@ -719,7 +734,7 @@ __device__ __forceinline__ Coef scalar_prelude(const Hot& p, const ColdRef cold,
         s.on = c->a.on_time[e];
         s.off = c->a.off_time[e];
         s.tss = 0;
-        s.ipk = peak_current(cold, s.mode);
+        s.ipk = peak_current(cold, s.mode, e);
     }
     const uint32_t t = (uint32_t)s.time, ep = (uint32_t)s.episode;
 
@@ -805,6 +820,11 @@ __device__ __forceinline__ Coef scalar_prelude(const Hot& p, const ColdRef cold,
         V = (rst && !shrt) ? (end_rest ? Vt : 0.0) : V;
         s.V = V;
         s.I = burning ? Ipk : 0.0;
+        // `_get_peak_current` is called exactly where `burning` holds; with a latched mode it fills the module's current
+        // cache (ignition.py:98-113).  The first such call after a mode was latched falls on an ignition, a short pulse
+        // or the latch step itself, and every one of those runs this general prelude: flag WEDM_B_MODE_CACHED.
+        if (writer && burning && s.mode != 0 && (ign || to_pulse || s.ctrl))
+            cc0->s.i8[(int64_t)WEDM_B_MODE_CACHED * cc0->s.stride + e] = 1;
         if (ign) {  // rare: spark location, Generator.uniform(0, h)
             const double h = p.per_env_geometry ? cc0->g.f64[(int64_t)WEDM_G_HEIGHT * cc0->s.stride + e] : h_u;
             s.y = REPLAY ? rv[WEDM_RS_SPARK_Y] : 0.0 + (h - 0.0) * u32_to_unit(w.w);
@@ -1113,12 +1133,19 @@ __device__ __forceinline__ void scalar_epilogue(const Hot& p, Env& s, float tmax
 #ifndef WEDM_ABL_NO_VACC
     s.vacc = s.vacc + s.V;
 #endif
+    int32_t tcrit = tmax > p.tcrit ? s.tcrit + 1 : 0;
+    // keep_stepping_terminated only (elsewhere a broken wire is frozen and never gets here): the wire module returns at
+    // once on a broken wire (wire.py:260-261) -- no stencil (the caller's walk left this lane's wire alone and its `tmax`
+    // is meaningless), no temperature monitor
+    if (__any(s.broken != 0)) {
+        tmax = s.broken ? s.tmax : tmax;
+        tcrit = s.broken ? s.tcrit : tcrit;
+    }
     s.tmax = tmax;
-    if (tmax > p.tcrit) s.tcrit += 1;
-    else s.tcrit = 0;
+    s.tcrit = tcrit;
     if (tmax > p.tbreak) s.broken = 1;
     if (s.broken) {  // early return before mechanics and clocks
-        s.done = 1;
+        s.done = p.done_value;
         return;
     }
 #ifndef WEDM_ABL_NO_MECH
@@ -1150,9 +1177,16 @@ __device__ __forceinline__ void scalar_epilogue(const Hot& p, Env& s, float tmax
     s.tsov = (int32_t)((uint32_t)s.tsov + (uint32_t)p.dt_us);  // never reset by the reference either: in step with `time`
     if (s.state == 1) { s.tsi += p.dt_us; s.tse = 0; }
     else { s.tse += p.dt_us; s.tsi = 0; }
-    if (s.x > s.wp + 100) { s.broken = 1; s.done = 1; }
-    else if (s.wp >= s.tpos) { s.reached = 1; s.done = 1; }
+    if (s.x > s.wp + 100) { s.broken = 1; s.done = p.done_value; }
+    else if (s.wp >= s.tpos) { s.reached = 1; s.done = p.done_value; }
 }
+
+// The wire of a lane whose wire is broken stays as it is: around its walk a kernel ORs `broken` into the lane's frozen
+// flag (`freeze_wire`) and afterwards takes it out again (`unfreeze_wire`).  Without keep_stepping_terminated both are
+// no-ops (a broken wire is frozen anyway: done_value 1); with it they make the walk skip exactly the lanes whose wire
+// module would return at once (wire.py:260-261) while prelude and epilogue go on running.
+__device__ __forceinline__ void freeze_wire(Env& s) { s.done |= s.broken; }
+__device__ __forceinline__ void unfreeze_wire(const Hot& p, Env& s) { s.done &= p.done_value; }
 
 __device__ __forceinline__ void write_obs(const ColdRef cold, int64_t e, const Env& s) {
     const ColdPtr c = cold.get();
@@ -1193,15 +1227,21 @@ __device__ __forceinline__ void reinit_env(const ColdRef cold, int64_t e, Env& s
     const int32_t episode = s.episode + 1;
     const uint32_t k0 = s.key0, k1 = s.key1;
     const float spool = (float)p->spool_T;
-    s.wp = p->initial_gap; s.x = 0.0; s.v = 0.0; s.prev_a = 0.0;
-    s.debris = 0.0; s.rho = 0.0; s.flow = 0.0; s.last_gap = -1.0; s.last_rho = -1.0; s.wire_last_flow = 0.0;
-    s.V = 0.0; s.I = 0.0; s.y = __builtin_nan(""); s.last_crater = 0.0; s.cavity = 0.0;
+    // reset_semantics 1: the reference's reset() builds a new EDMState only (wire_edm.py:106-114); what its module objects
+    // hold lives on: short timers, debris volume, flow / density / convection caches, `prev_accel`, the crater list
+    const bool keep_modules = p->reset_semantics != 0;
+    s.wp = p->initial_gap; s.x = 0.0; s.v = 0.0;
+    s.rho = 0.0; s.V = 0.0; s.I = 0.0; s.y = __builtin_nan(""); s.last_crater = 0.0; s.cavity = 0.0;
     s.tdelta = 0.0; s.tvolt = 0.0; s.on = 0.0; s.off = 0.0; s.tpos = p->target_cutting_distance; s.unwind = 0.2;
     s.vacc = 0.0;
-    s.h_base = 0.0f; s.h_zone = 0.0f; s.tmax = spool;
-    s.time = 0; s.tss = 0; s.tsov = 0; s.tsi = 0; s.tse = 0; s.dur = 0; s.rnd_rem = 0; s.deb_rem = 0; s.tcrit = 0;
-    s.mode = 0; s.episode = episode; s.sparks = 0; s.key0 = k0; s.key1 = k1;
+    s.tmax = spool;
+    s.time = 0; s.tss = 0; s.tsov = 0; s.tsi = 0; s.tse = 0; s.dur = 0; s.tcrit = 0;
+    s.mode = 0; s.episode = episode; s.key0 = k0; s.key1 = k1;
     s.state = 0; s.is_short = 0; s.broken = 0; s.reached = 0; s.done = 0; s.ctrl = 0; s.err = 0;
+    if (!keep_modules) {
+        s.prev_a = 0.0; s.debris = 0.0; s.flow = 0.0; s.last_gap = -1.0; s.last_rho = -1.0; s.wire_last_flow = 0.0;
+        s.h_base = 0.0f; s.h_zone = 0.0f; s.rnd_rem = 0; s.deb_rem = 0; s.sparks = 0;
+    }
     if (writer) {
         const int64_t stride = c->s.stride;
         *WEDM_ROW(c->s.f64, WEDM_F_WORKPIECE_POS) = s.wp;   // the reward's "position at the start of the launch"
@@ -1211,9 +1251,12 @@ __device__ __forceinline__ void reinit_env(const ColdRef cold, int64_t e, Env& s
         *WEDM_ROW(c->s.i32, WEDM_I_EPISODE) = episode;
         *WEDM_ROW(c->s.i32, WEDM_I_TIME) = 0;      // store_time_hi's "low word at the start of the launch"
         *WEDM_ROW(c->s.i32, WEDM_I_TIME_HI) = 0;
-        if (c->s.stats) {
-            *WEDM_ROW(c->s.stats, WEDM_S_CRATER_SUM) = 0.0; *WEDM_ROW(c->s.stats, WEDM_S_CRATER_SUMSQ) = 0.0;
-            *WEDM_ROW(c->s.stats, WEDM_S_CRATER_MIN) = __builtin_inf(); *WEDM_ROW(c->s.stats, WEDM_S_CRATER_MAX) = -__builtin_inf();
+        if (!keep_modules) {
+            *WEDM_ROW(c->s.i8, WEDM_B_MODE_CACHED) = 0;
+            if (c->s.stats) {
+                *WEDM_ROW(c->s.stats, WEDM_S_CRATER_SUM) = 0.0; *WEDM_ROW(c->s.stats, WEDM_S_CRATER_SUMSQ) = 0.0;
+                *WEDM_ROW(c->s.stats, WEDM_S_CRATER_MIN) = __builtin_inf(); *WEDM_ROW(c->s.stats, WEDM_S_CRATER_MAX) = -__builtin_inf();
+            }
         }
         if (c->s.obs)
             for (int q = 0; q < p->obs_dim; ++q) c->s.obs[(int64_t)q * stride + e] = 0.0f;

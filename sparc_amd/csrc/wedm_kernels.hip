@@ -236,7 +236,8 @@ __device__ __forceinline__ void run_substeps(const KArgs& k, const ColdRef cold,
     for (int it = 0; it < k.n_substeps; ++it) {
         if (!s.done) {
             Coef c = scalar_prelude<REPLAY>(k.hot, cold, g, e, gid, s, ps, true);  // single steps: the quiet test does not pay
-            float tmax = stencil_pass<F64>(T, g, c, ps, k.hot, f64c, s.h_base, s.h_zone);
+            // (keep_stepping_terminated: the wire module returns at once on a broken wire, wire.py:260-261)
+            float tmax = s.broken ? s.tmax : stencil_pass<F64>(T, g, c, ps, k.hot, f64c, s.h_base, s.h_zone);
             scalar_epilogue(k.hot, s, tmax);
             if (s.ctrl) control_step_outputs(cold, e, s, true);
         } else if (!tracing) {
@@ -255,7 +256,7 @@ __global__ void __launch_bounds__(256) wedm_step_global(const KArgs k) {
     Env s;
     load_env(cold, e, s);
     const bool reinit = s.done && WEDM_AUTORESET(cold);
-    const bool frozen = s.done && !reinit;  // terminated and not reset: nothing to step
+    const bool frozen = s.done && !reinit && k.hot.done_value;  // terminated and not reset: nothing to step
     if (frozen && !WEDM_TRACING(k)) {
         if (WEDM_REWARD_ON(cold)) cold->s.reward[e] = 0.0f;  // a frozen environment earns nothing (not the previous launch's reward)
         return;
@@ -265,7 +266,8 @@ __global__ void __launch_bounds__(256) wedm_step_global(const KArgs k) {
         reinit_env(cold, e, s, true);
         for (int q = 0; q < WEDM_T_QUADS(k.n_seg_max); ++q) T.stq(q, f4v{k.hot.spool, k.hot.spool, k.hot.spool, k.hot.spool});
     }
-    s.ipk = s.done ? 0.0 : peak_current(cold, s.mode);
+    s.done &= k.hot.done_value;  // keep_stepping_terminated: the DONE row is `terminated` of the last step and freezes nothing
+    s.ipk = s.done ? 0.0 : peak_current(cold, s.mode, e);
     Geom g;
     load_geom(k.hot, cold, e, g);
     run_substeps<TRACE, F64, REPLAY>(k, cold, g, e, k.hot.env_id_offset + (uint32_t)e, s, T);
@@ -346,9 +348,10 @@ __global__ void __launch_bounds__(256) wedm_step_split(const KArgs k) {
         if (live) load_env(cold, e, s);
         else s.done = 1;
         if (reinit) reinit_env(cold, e, s, true);
+        s.done &= k.hot.done_value;  // keep_stepping_terminated: nothing is frozen
         frozen0 = s.done;
         if (!s.done) {
-            s.ipk = peak_current(cold, s.mode);
+            s.ipk = peak_current(cold, s.mode, e);
             init_persist(k.hot, cold, e, s, ps);
         }
     }
@@ -363,7 +366,8 @@ __global__ void __launch_bounds__(256) wedm_step_split(const KArgs k) {
             if (!s.done) cf = scalar_prelude(k.hot, cold, g, e, gid, s, ps, true);
             sh_f[0][el] = cf.jf; sh_f[1][el] = cf.q; sh_f[2][el] = ps.conv_base; sh_f[3][el] = ps.conv_zone;
             sh_f[4][el] = ps.adv;
-            sh_i[0][el] = cf.joule_on; sh_i[1][el] = cf.pidx; sh_i[2][el] = ps.adv_on; sh_i[3][el] = s.done;
+            sh_i[0][el] = cf.joule_on; sh_i[1][el] = cf.pidx; sh_i[2][el] = ps.adv_on;
+            sh_i[3][el] = s.done | s.broken;  // (keep_stepping_terminated: a broken wire stays as it is, wire.py:260-261)
         }
         WEDM_SPLIT_STAMP(1);
         // OLD neighbour values, read before the barrier that precedes every store of this step
@@ -609,13 +613,14 @@ __global__ void __launch_bounds__(256, 2) wedm_step_lanes(const KArgs k) {
     else { s.done = 1; s.unwind = 0.0; s.h_base = 0.0f; s.h_zone = 0.0f; }
     float* col = lds + tid;
     const bool reinit = live && s.done && WEDM_AUTORESET(cold);  // next-step autoreset (all L lanes of the environment agree)
-    const bool frozen0 = s.done && !reinit;
     if (reinit) {
         reinit_env(cold, e, s, c == 0);
         for (int j = 0; j < C; ++j) col[j * 256] = k.hot.spool;
     }
+    s.done &= k.hot.done_value;  // keep_stepping_terminated: the DONE row is `terminated` of the last step and freezes nothing
+    const bool frozen0 = s.done;
     if (!s.done) {
-        s.ipk = peak_current(cold, s.mode);
+        s.ipk = peak_current(cold, s.mode, e);
         init_persist(k.hot, cold, e, s, ps);
     }
     const uint32_t gid = k.hot.env_id_offset + (uint32_t)e;
@@ -634,6 +639,7 @@ __global__ void __launch_bounds__(256, 2) wedm_step_lanes(const KArgs k) {
         Coef cf{0.0f, 0.0f, 0, -1};
         QuietTry qt;
         if (!quiet_prelude_t<WEDM_FUSED_DENSE>(hv, cold, g, e, gid, s, qt, cf) && !s.done) cf = scalar_prelude(hv, cold, g, e, gid, s, ps, c == 0, qt);
+        freeze_wire(s);
         const float halo_l = (c > 0) ? col[(C - 1) * 256 - 1] : spool;
         const float halo_r = (c < L - 1) ? col[1] : 0.0f;
         float tmax = spool, tm1 = halo_l, tc = col[0];
@@ -733,6 +739,7 @@ __global__ void __launch_bounds__(256, 2) wedm_step_lanes(const KArgs k) {
         }
 #pragma unroll
         for (int m = 1; m < L; m <<= 1) tmax = fmax_gt(tmax, __shfl_xor(tmax, m));
+        unfreeze_wire(hv, s);
         if (!s.done) {
             scalar_epilogue(hv, s, tmax);
             if (s.ctrl) control_step_outputs(cold, e, s, c == 0);
@@ -832,13 +839,14 @@ __global__ void __launch_bounds__(256, 2) wedm_step_fused(const KArgs k) {
     else { s.done = 1; s.unwind = 0.0; s.h_base = 0.0f; s.h_zone = 0.0f; }
     float* col = lds + tid;
     const bool reinit = live && s.done && WEDM_AUTORESET(cold);  // next-step autoreset (all L lanes of the environment agree)
-    const bool frozen0 = s.done && !reinit;
     if (reinit) {
         reinit_env(cold, e, s, c == 0);
         for (int j = 0; j < C; ++j) col[j * 256] = k.hot.spool;
     }
+    s.done &= k.hot.done_value;  // keep_stepping_terminated: the DONE row is `terminated` of the last step and freezes nothing
+    const bool frozen0 = s.done;
     if (!s.done) {
-        s.ipk = peak_current(cold, s.mode);
+        s.ipk = peak_current(cold, s.mode, e);
         init_persist(k.hot, cold, e, s, ps);
     }
     const uint32_t gid = k.hot.env_id_offset + (uint32_t)e;
@@ -896,6 +904,7 @@ __global__ void __launch_bounds__(256, 2) wedm_step_fused(const KArgs k) {
         QuietTry qt;
         if (!quiet_prelude_t<WEDM_FUSED_DENSE>(hv, cold, g, e, gid, s, qt, cf) && !s.done) cf = scalar_prelude(hv, cold, g, e, gid, s, ps, c == 0, qt);
         WEDM_STAMP(st1);
+        freeze_wire(s);
 
         // ---- halos: OLD neighbour values, read before any lane of this wave stores.  The right
         // halo goes into the chunk's extra LDS row C, so cell C-1 is walked like any other.
@@ -1120,6 +1129,7 @@ __global__ void __launch_bounds__(256, 2) wedm_step_fused(const KArgs k) {
         }
 #pragma unroll
         for (int m = 1; m < L; m <<= 1) tmax = fmax_gt(tmax, __shfl_xor(tmax, m));
+        unfreeze_wire(hv, s);
         WEDM_STAMP(st3);
         if (!s.done) {
             scalar_epilogue(hv, s, tmax);
@@ -1256,6 +1266,7 @@ __global__ void __launch_bounds__(256, 2) wedm_step_stream(const KArgs k) {
     // next-step autoreset (all L lanes of the environment agree)
     const bool reinit = live && s.done && WEDM_AUTORESET_SCALAR(cold);
     if (reinit) reinit_env(cold, e, s, c == 0);
+    s.done &= k.hot.done_value;  // keep_stepping_terminated: the DONE row is `terminated` of the last step and freezes nothing
     const bool frozen0 = s.done;
     double wp0 = 0.0;  // workpiece position at the start of the launch (reward)
     if (WEDM_REWARD_ON_SCALAR(cold) && !frozen0) wp0 = s.wp;
@@ -1263,8 +1274,8 @@ __global__ void __launch_bounds__(256, 2) wedm_step_stream(const KArgs k) {
         const bool in_table = s.mode >= 1 && s.mode <= WEDM_MAX_MODE;
         const double from_table = __shfl(ipk_entry, in_table ? s.mode : 0, 64);  // every lane takes part
         if (!s.done) {
-            s.ipk = s.mode == 0 ? 60.0 : from_table;
-            if (s.mode != 0 && !in_table) s.ipk = peak_current(cold, s.mode);  // default_current (cold parameter)
+            s.ipk = from_table;
+            if (!in_table) s.ipk = peak_current(cold, s.mode, e);  // mode None (the module's current cache) or unknown (default_current): cold path
             init_persist<true>(k.hot, cold, e, s, ps);
         }
     }
@@ -1304,6 +1315,7 @@ __global__ void __launch_bounds__(256, 2) wedm_step_stream(const KArgs k) {
     };
     auto rest = [&](const int it, Coef& cf) {
         const bool last = it + 1 == k.n_substeps;
+        freeze_wire(s);
         // ---- halos: OLD neighbour values, read before any lane of this wave stores.  The right
         // halo goes into the chunk's extra LDS row C, so cell C-1 is walked like any other.
         const float halo_l = (c > 0) ? col[(C - 1) * 256 - 1] : spool;
@@ -1481,6 +1493,7 @@ __global__ void __launch_bounds__(256, 2) wedm_step_stream(const KArgs k) {
         }
 #pragma unroll
         for (int m = 1; m < L; m <<= 1) tmax = fmax_gt(tmax, __shfl_xor(tmax, m));
+        unfreeze_wire(hv, s);
         if (!s.done) {
             scalar_epilogue(hv, s, tmax);
             if (s.ctrl) control_step_outputs(cold, e, s, c == 0);
@@ -1618,13 +1631,14 @@ __global__ void __launch_bounds__(256, 2) wedm_step_packed(const KArgs k) {
     else { s.done = 1; s.unwind = 0.0; s.h_base = 0.0f; s.h_zone = 0.0f; }
     float* col = lds + tid;
     const bool reinit = live && s.done && WEDM_AUTORESET(cold);  // next-step autoreset (all L lanes of the environment agree)
-    const bool frozen0 = s.done && !reinit;
     if (reinit) {
         reinit_env(cold, e, s, c == 0);
         for (int row = 0; row < R; ++row) col[row * 256] = k.hot.spool;
     }
+    s.done &= k.hot.done_value;  // keep_stepping_terminated: the DONE row is `terminated` of the last step and freezes nothing
+    const bool frozen0 = s.done;
     if (!s.done) {
-        s.ipk = peak_current(cold, s.mode);
+        s.ipk = peak_current(cold, s.mode, e);
         init_persist(k.hot, cold, e, s, ps);
     }
     const uint32_t gid = k.hot.env_id_offset + (uint32_t)e;
@@ -1689,6 +1703,7 @@ __global__ void __launch_bounds__(256, 2) wedm_step_packed(const KArgs k) {
         QuietTry qt;
         const bool was_quiet = quiet_prelude_t<WEDM_PACKED_DENSE>(hv, cold, g, e, gid, s, qt, cf);
         if (!was_quiet && !s.done) cf = scalar_prelude(hv, cold, g, e, gid, s, ps, c == 0, qt);
+        freeze_wire(s);
         WEDM_STAMP(st1);
 #ifdef WEDM_STAMPS
         if (was_quiet) { accN += st1 - st0; ++cntN; } else { accB += st1 - st0; ++cntB; }  // quiet / general prelude
@@ -1959,6 +1974,7 @@ __global__ void __launch_bounds__(256, 2) wedm_step_packed(const KArgs k) {
         }
 #pragma unroll
         for (int m = 1; m < L; m <<= 1) tmax = fmax_gt(tmax, __shfl_xor(tmax, m));
+        unfreeze_wire(hv, s);
         WEDM_STAMP(st3);
         if (!s.done) {
             scalar_epilogue(hv, s, tmax);
@@ -2020,14 +2036,27 @@ wedm_reset_kernel(const wedm_params p, const wedm_state_ptrs s, int32_t num_envs
     const int64_t stride = s.stride;
     int32_t episode = *WEDM_ROW(s.i32, WEDM_I_EPISODE);
     int32_t klo = *WEDM_ROW(s.i32, WEDM_I_KEY_LO), khi = *WEDM_ROW(s.i32, WEDM_I_KEY_HI);
-    for (int f = 0; f < WEDM_F64_COUNT; ++f) *WEDM_ROW(s.f64, f) = 0.0;
-    for (int f = 0; f < WEDM_I32_COUNT; ++f) *WEDM_ROW(s.i32, f) = 0;
-    for (int f = 0; f < WEDM_I8_COUNT; ++f) *WEDM_ROW(s.i8, f) = 0;
-    if (s.stats) {
+    // reset_semantics 1 = the reference's own reset(): a new EDMState only (wire_edm.py:106-114).  The rows that mirror what
+    // its MODULE objects hold survive: `prev_accel` (mechanics.py:60), the debris volume and the flow / density caches
+    // (dielectric.py:69-80), the convection cache and coefficients (wire.py:205,224), the short timers and the current
+    // cache (ignition.py:75-81), the crater list and its statistics (material.py:133).
+    const bool keep_modules = p.reset_semantics != 0 && !(reseed & WEDM_RESET_FRESH);
+    constexpr uint32_t module_f64 = (1u << WEDM_F_PREV_ACCEL) | (1u << WEDM_F_DEBRIS_VOLUME) | (1u << WEDM_F_FLOW) |
+                                    (1u << WEDM_F_LAST_GAP) | (1u << WEDM_F_LAST_DENSITY) | (1u << WEDM_F_WIRE_LAST_FLOW) |
+                                    (1u << WEDM_F_H_BASE) | (1u << WEDM_F_H_ZONE);
+    constexpr uint32_t module_i32 = (1u << WEDM_I_RANDOM_SHORT_REM) | (1u << WEDM_I_DEBRIS_SHORT_REM) | (1u << WEDM_I_SPARK_COUNT);
+    constexpr uint32_t module_i8 = 1u << WEDM_B_MODE_CACHED;
+    for (int f = 0; f < WEDM_F64_COUNT; ++f)
+        if (!(keep_modules && ((module_f64 >> f) & 1u))) *WEDM_ROW(s.f64, f) = 0.0;
+    for (int f = 0; f < WEDM_I32_COUNT; ++f)
+        if (!(keep_modules && ((module_i32 >> f) & 1u))) *WEDM_ROW(s.i32, f) = 0;
+    for (int f = 0; f < WEDM_I8_COUNT; ++f)
+        if (!(keep_modules && ((module_i8 >> f) & 1u))) *WEDM_ROW(s.i8, f) = 0;
+    if (s.stats && !keep_modules) {
         *WEDM_ROW(s.stats, WEDM_S_CRATER_SUM) = 0.0; *WEDM_ROW(s.stats, WEDM_S_CRATER_SUMSQ) = 0.0;
         *WEDM_ROW(s.stats, WEDM_S_CRATER_MIN) = __builtin_inf(); *WEDM_ROW(s.stats, WEDM_S_CRATER_MAX) = -__builtin_inf();
     }
-    if (reseed) {
+    if (reseed & WEDM_RESET_RESEED) {
         *WEDM_ROW(s.i32, WEDM_I_EPISODE) = 0;
         *WEDM_ROW(s.i32, WEDM_I_KEY_LO) = (int32_t)key_lo;
         *WEDM_ROW(s.i32, WEDM_I_KEY_HI) = (int32_t)key_hi;
@@ -2040,8 +2069,10 @@ wedm_reset_kernel(const wedm_params p, const wedm_state_ptrs s, int32_t num_envs
     *WEDM_ROW(s.f64, WEDM_F_TARGET_POS) = p.target_cutting_distance;   // wire_edm.py:112
     *WEDM_ROW(s.f64, WEDM_F_UNWIND_VEL) = 0.2;                         // state.py:55
     *WEDM_ROW(s.f64, WEDM_F_SPARK_Y) = __builtin_nan("");              // [0, None, 0]
-    *WEDM_ROW(s.f64, WEDM_F_LAST_GAP) = -1.0;                          // dielectric.py:78
-    *WEDM_ROW(s.f64, WEDM_F_LAST_DENSITY) = -1.0;                      // dielectric.py:79
+    if (!keep_modules) {
+        *WEDM_ROW(s.f64, WEDM_F_LAST_GAP) = -1.0;                      // dielectric.py:78
+        *WEDM_ROW(s.f64, WEDM_F_LAST_DENSITY) = -1.0;                  // dielectric.py:79
+    }
     const float spool = (float)p.spool_T;
     *WEDM_ROW(s.f64, WEDM_F_TMAX) = (double)spool;
     for (int q = 0; q < WEDM_T_QUADS(n_seg_max); ++q)  // wire.py:264-269 (whole 16-byte words: padding cells included)
@@ -2716,6 +2747,7 @@ int32_t wedm_step(wedm_ctx* ctx, int32_t n_substeps, const wedm_action_ptrs* act
     h.disable_ignition = P.disable_ignition;
     h.has_random_short = P.random_short_max_probability != 0.0 ? 1 : 0;
     h.per_env_geometry = P.per_env_geometry; h.env_id_offset = P.env_id_offset; h.n_seg = P.n_seg;
+    h.done_value = P.keep_stepping_terminated ? 0 : 1;
     k.cold.p = ctx->params_dev;
     k.cold.g = ctx->g;
     k.cold.a = *action;

@@ -108,6 +108,8 @@ class WireEDMEnv:
         reward_break_penalty: float = 10.0,
         stencil_dtype: str = "float32",
         crater_log_capacity: int = 0,
+        reset_semantics: str = "full",
+        freeze_terminated: bool = True,
         backend: Optional[Callable] = None,
     ):
         """Beyond the reference's keywords (wire_edm.py:22-34):
@@ -122,7 +124,17 @@ class WireEDMEnv:
         wire.py:58-123 without Numba (NumPy-2 scalar promotion: float32 op for op); ``"float64"`` =
         as Numba types the same lines (float64 expressions rounded at each float32 store).
         ``crater_log_capacity``: keep the last that many sampled crater volumes of every environment
-        (`MaterialRemovalModule.crater_volumes_um3`, material.py:133) — see `get_crater_volumes`."""
+        (`MaterialRemovalModule.crater_volumes_um3`, material.py:133) — see `get_crater_volumes`.
+        ``reset_semantics``: ``"full"`` = a reset is a fresh environment, module-private state included (default);
+        ``"reference"`` = exactly what the reference's ``reset()`` does (wire_edm.py:106-114): only ``EDMState`` is
+        re-initialised, the module objects live on — ignition short timers and current cache, debris volume and
+        the flow / density caches, ``prev_accel``, convection cache and coefficients, crater list and statistics
+        carry over into the next episode (what every RL loop on the reference sees from its second episode on).
+        ``freeze_terminated``: True = a terminated environment is frozen until it is reset (default); False = it
+        keeps being stepped as the reference does when ``step()`` is called after ``terminated`` (wire_edm.py:116-157
+        has no guard): after a wire break the wire module returns at once and the step returns before mechanics
+        and clocks, after the cutting target everything goes on; ``terminated`` then repeats what the reference's
+        ``step()`` returns."""
         self.render_mode = render_mode
         if mechanics_control_mode not in ["position", "velocity"]:
             raise ValueError(f"mechanics_control_mode must be 'position' or 'velocity', got {mechanics_control_mode}")
@@ -155,6 +167,9 @@ class WireEDMEnv:
         if reward not in (None, "progress"):
             raise ValueError("reward must be None (the reference's constant 0.0) or 'progress'")
         self.reward_kind = reward
+        if reset_semantics not in ("full", "reference"):
+            raise ValueError("reset_semantics must be 'full' or 'reference'")
+        self.reset_semantics, self.freeze_terminated = reset_semantics, bool(freeze_terminated)
         if stencil_dtype not in ("float32", "float64"):
             raise ValueError("stencil_dtype must be 'float32' or 'float64'")
         self.stencil_dtype = stencil_dtype
@@ -182,7 +197,8 @@ class WireEDMEnv:
             self.dielectric_params, self.mechanics_params, self.wire_material, geometry=self.geometry,
             env_id_offset=self.env_id_offset, obs_dim=_abi.OBS_DIM, disable_ignition=disable_ignition,
             autoreset=self.autoreset, reward_mode=1 if reward == "progress" else 0,
-            reward_break_penalty=reward_break_penalty, stencil_mode=1 if stencil_dtype == "float64" else 0)
+            reward_break_penalty=reward_break_penalty, stencil_mode=1 if stencil_dtype == "float64" else 0,
+            reset_semantics=1 if reset_semantics == "reference" else 0, keep_stepping_terminated=not freeze_terminated)
 
         # ---- state (caller-owned memory) + backend
         self.state = BatchedEDMState(self.num_envs, self.n_segments, _abi.OBS_DIM, self.device,
@@ -234,7 +250,7 @@ class WireEDMEnv:
         self._trace = None
         self._seed = int.from_bytes(os.urandom(8), "little")
         self.steps_since_reset = 0  # host-side count of physics steps since the last reset of ALL environments
-        self._backend.reset(None, self._seed, True)
+        self._backend.reset(None, self._seed, True, fresh=True)  # fresh module objects, whatever `reset_semantics`
 
     # ------------------------------------------------------------------ Gym API
     def reset(self, *, seed: Optional[int] = None, options: Optional[Dict[str, Any]] = None):

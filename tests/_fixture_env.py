@@ -29,6 +29,8 @@ def check_step(env, fx, env_index, step, *, exact_floats, float_rtol=1e-12, tmax
     """Assert that environment `env_index` equals the fixture at `step` (after that step)."""
     st = env.state
     for name, attr in INT_MAP.items():
+        if name == "ctrl_step" and int(fx.int_row("is_wire_broken")[step]):
+            continue  # the reference's early return (wire_edm.py:129-130) carries no control_step key
         want = int(fx.int_row(name)[step])
         got = int(getattr(st, attr)[env_index].item())
         assert want == got, f"step {step} env {env_index} {name}: reference {want} got {got}"
@@ -90,7 +92,60 @@ def env_from_fixture(fx, n, *, device, backend=None, **extra):
     for k, v in m["module_init"].items():
         assert k == "dielectric.debris_volume"
         env.state.debris_volume = v
+    for lo, hi, val in m.get("T_init", []):
+        T = env.state.wire_temperature
+        T[:, lo:hi] = val
     return env
+
+
+def compat_env_from_fixture(fx, n, *, device, backend=None, **extra):
+    """The reference-compatible modes the F17 / F18 fixtures need: `reset()` re-initialises EDMState only
+    (fixtures with a second episode), `step()` goes on after `terminated` (fixtures that were stepped past it)."""
+    kw = dict(extra)
+    if fx.meta.get("resets"):
+        kw["reset_semantics"] = "reference"
+    if fx.meta.get("stop_on_terminate") is False:
+        kw["freeze_terminated"] = False
+    return env_from_fixture(fx, n, device=device, backend=backend, **kw)
+
+
+def fixture_segments(fx):
+    """[(first step, last step + 1, reset before it: (seed, state_init) or None)] of a fixture with second episodes."""
+    cuts = sorted((int(at), int(sd), si) for at, sd, si in fx.meta.get("resets", []))
+    out, lo, pending = [], 0, None
+    for at, sd, si in cuts:
+        out.append((lo, at, pending))
+        lo, pending = at, (sd, si)
+    out.append((lo, fx.n_steps, pending))
+    return out
+
+
+def apply_fixture_reset(env, reset):
+    seed, init = reset
+    env.reset(seed=seed)  # reset_semantics="reference": EDMState only
+    for k, v in init.items():
+        setattr(env.state, k, v)
+
+
+def run_fixture_stepwise(env, fx, *, exact_floats, every=1):
+    """One `step()` per microsecond, every recorded quantity of environment `env_id` compared after each step
+    (`every`: after every that-many steps), second episodes and steps past `terminated` included."""
+    e = int(fx.meta["env_id"])
+    assert len(fx.actions) == 1, "constant-action fixtures only"
+    servo, tv, on, off, mode = fx.actions[0]
+    act = env.make_action(servo, tv, int(mode), on, off)
+    checked = 0
+    for lo, hi, reset in fixture_segments(fx):
+        if reset is not None:
+            apply_fixture_reset(env, reset)
+        for step in range(lo, hi):
+            env.step(act)
+            if step % every == 0 or step in (lo, hi - 1):
+                check_step(env, fx, e, step, exact_floats=exact_floats)
+                if env.freeze_terminated is False:
+                    assert int(env.state.done[e]) == int(fx.int_row("terminated")[step]), f"step {step}: terminated"
+                checked += 1
+    return checked
 
 
 def run_fixture_through_trace(env, fx, *, exact_floats, float_rtol=1e-12, T_atol=1e-4):
@@ -103,14 +158,22 @@ def run_fixture_through_trace(env, fx, *, exact_floats, float_rtol=1e-12, T_atol
     servo, tv, on, off, mode = fx.actions[0]
     act = env.make_action(servo, tv, int(mode), on, off)
     names = sorted(set(TRACE_INT.values()) | set(TRACE_EXACT.values()) | set(TRACE_CLOSE.values()))
+    keep_stepping = getattr(env, "freeze_terminated", True) is False
+    if keep_stepping:
+        names = sorted(set(names) | {"done"})
     trace = env.bind_trace(names, every=1, capacity=fx.n_steps, envs=(e, 1))
     interval = env.servo_interval // env.dt
-    left = fx.n_steps
-    while left > 0:
-        k = min(interval, left)
-        env.step_many(act, k)
-        left -= k
+    for lo, hi, reset in fixture_segments(fx):   # (one segment unless the fixture holds a second episode)
+        if reset is not None:
+            apply_fixture_reset(env, reset)
+        left = hi - lo
+        while left > 0:
+            k = min(interval, left)
+            env.step_many(act, k)
+            left -= k
     got = {k: v[:, 0].cpu().numpy() for k, v in trace.read().items()}
+    if keep_stepping:  # WEDM_B_DONE = `terminated` as the reference's step() returns it, at every microsecond
+        assert np.array_equal(got["done"].astype(np.int64), fx.int_row("terminated").astype(np.int64)), "terminated"
     for ref, name in TRACE_INT.items():
         want = fx.int_row(ref)
         assert np.array_equal(got[name].astype(np.int64), want.astype(np.int64)), \

@@ -134,7 +134,15 @@ def replay(fx: Fixture, *, math_mode=orc.MATH_LIBM, stencil_mode=orc.STENCIL_F32
     bad = []
     fpos = {int(s): i for i, s in enumerate(fx.float_steps)}
     tpos = {int(s): i for i, s in enumerate(fx.T_snap_steps)}
+    resets = {int(at): (int(sd), si) for at, sd, si in fx.meta.get("resets", [])}
     for step in range(fx.n_steps):
+        if step in resets:  # the reference's reset() of a USED environment: EDMState only (wire_edm.py:106-114)
+            seed2, init2 = resets[step]
+            orc.lib().wedm_oracle_reset_reference(C.byref(env))
+            if fx.meta["rng"] != "native":  # reset(seed=) re-keys the stream; a native trace simply continues
+                env.rng.seed, env.rng.episode = seed2, 0
+            for k, v in init2.items():
+                setattr(env, STATE_ATTR[k], v)
         if fx.forced is not None:
             st, y, dur, V, I = fx.forced[step]
             env.spark_state, env.spark_y, env.spark_dur = int(st), float(y), int(dur)

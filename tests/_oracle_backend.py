@@ -38,9 +38,9 @@ class OracleBackend:
     def bind_geometry(self, ptrs):
         self.geom = ptrs
 
-    def reset(self, mask_ptr, seed, reseed):
+    def reset(self, mask_ptr, seed, reseed, fresh=False):
         rc = self._L.wedm_oracle_reset_batch(C.byref(self.params), C.byref(self.state), self.num_envs,
-                                             mask_ptr, seed & (2**64 - 1), 1 if reseed else 0)
+                                             mask_ptr, seed & (2**64 - 1), (1 if reseed else 0) | (2 if fresh else 0))
         assert rc == 0, rc
         # like wedm_reset: all n_seg_max temperature rows at the spool temperature, obs zeroed
         stride = self.state.stride

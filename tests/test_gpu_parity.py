@@ -976,6 +976,58 @@ def test_single_environment_batch_follows_the_reference(golden_dir):
     assert (got["spark_state"] == 1).sum() > 10
 
 
+@pytest.mark.parametrize("name", ["f17_second_episode_philox_env2", "f17_reset_during_short_philox_env4",
+                                  "f17_stale_current_cache_philox_env5", "f18_past_target_philox_env1",
+                                  "f18_past_wire_break_philox_env3", "f18_past_collision_philox_env6"])
+def test_reference_compatible_reset_and_stepping_past_termination_on_gpu(golden_dir, name):
+    """F17 / F18 (the reference's second episode on one environment object; `step()` after `terminated`) on the GPU:
+    fused launches read back through the device trace -- discrete state, clocks, positions, voltage / current and the
+    `terminated` flag exact at every microsecond, debris / flow <= 1e-12, temperatures <= 1e-4 K."""
+    from tests._fixture_env import compat_env_from_fixture, run_fixture_through_trace
+    from tests._golden import Fixture
+
+    fx = Fixture(golden_dir / f"{name}.npz")
+    env = compat_env_from_fixture(fx, 64, device="cuda:0")
+    got = run_fixture_through_trace(env, fx, exact_floats=False)
+    assert "wedm_step_" in env._backend.last_kernel()
+    if name.startswith("f18"):
+        first = int(np.argmax(fx.int_row("terminated") != 0))
+        assert got["done"][first:].all() and not got["done"][:first].any() and fx.n_steps - first >= 500
+
+
+@pytest.mark.parametrize("variant,lanes", KERNELS + [(0, 0)])
+def test_compat_modes_every_kernel_matches_oracle(variant, lanes):
+    """`reset_semantics="reference"` + `freeze_terminated=False` (+ in-launch autoreset with the reference's reset) on every
+    kernel against the oracle batch, every byte: wire breaks by temperature and by collision, reached targets, stale current
+    caches, running short timers, all stepped on past `terminated` and through several second episodes."""
+    n = 160
+    kw = dict(reset_semantics="reference", freeze_terminated=False, autoreset=variant in (0, 3, 4),
+              ignition_params=IgnitionModuleParameters(default_current_mode="I13"),
+              config=EnvironmentConfig(target_cutting_distance=5000.0))
+    gpu, cpu = make_pair(n, **kw)
+    gpu.set_kernel(variant, lanes)
+    idx = torch.arange(n)
+    for env in (gpu, cpu):
+        env.reset(seed=11)
+        close_gap(env, 21.0, 10.0)
+        env.state.workpiece_position = torch.where(idx % 9 == 2, 11.2, 21.0)          # hard shorts: timers running at the resets
+        env.state.target_position = torch.where(idx % 4 == 1, 21.0005, 5000.0)        # reached after the first craters
+        env.state.wire_position = torch.where(idx % 11 == 5, 125.0, 10.0)             # collision: wire > workpiece + 100
+        hot = env.state.wire_temperature
+        hot[7::13, 200:204] = 1600.0                                                  # breaks at the first step
+        a = env.make_action(0.1, 80.0, 9, 3.0, 30.0)
+        for k in ((1, 1, 1200, 1, 700) if variant in (5, 6) else (1, 1200, 1, 1, 700)):
+            env.step_many(a, k)
+        env.reset(seed=12, options={"mask": idx % 3 == 0})                             # a second episode for a third of them
+        env.state.wire_position = torch.where(idx % 3 == 0, 35.0, env.state.wire_position)   # (15 um gap: sparks before the latch)
+        for k in (1, 900, 1, 600):
+            env.step_many(a, k)
+    check(gpu, cpu, n)
+    st = gpu.state
+    assert bool(st.is_wire_broken.any()) and bool(st.is_target_distance_reached.any()) and bool(st.ignition_mode_cached.any())
+    assert int(st.spark_count.sum()) > n
+
+
 def test_two_microsecond_physics_step_fixture_on_gpu(golden_dir):
     from tests._fixture_env import env_from_fixture, run_fixture_through_trace
     from tests._golden import Fixture

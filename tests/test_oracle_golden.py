@@ -13,12 +13,16 @@ NATIVE = [
     "f1_config1_native", "f1_config1_f32action", "f2_single_spark", "f5_hard_short", "f5_debris_short",
     "f5_random_short", "f5_collision", "f5_target_reached", "f5_critical_temp", "f5_wire_break",
     "f5_action_latch", "f5_zero_fallbacks", "f6_velocity_mode", "f6_limits", "f7_gap_controller",
+    # the reference's second episode (reset() of a used environment) and step() after `terminated`
+    "f17_second_episode_native", "f18_past_wire_break_native",
 ]
+SECOND_EPISODE = ["f17_second_episode_philox_env2", "f17_reset_during_short_philox_env4", "f17_stale_current_cache_philox_env5"]
+PAST_TERMINATION = ["f18_past_target_philox_env1", "f18_past_wire_break_philox_env3", "f18_past_collision_philox_env6"]
 PHILOX = [f"f3_philox_env{i}" for i in (0, 1, 2, 3, 777, 65535)] + ["f3_philox_config3_env5"] + [
     f"f8_geometry_{i}" for i in range(4)
 ] + ["f7_gap_controller_philox_env0", "f7_gap_controller_philox_env9", "f7_gap_controller_velocity_philox_env3",
      "f9_voltage_controller_philox_env2", "f9_voltage_controller_velocity_philox_env5",
-     "f10_crater_statistics_philox_env1", "f13_dt2_philox_env4", "f14_copper_wire_philox_env6", "f15_default_mode_philox_env7"] + [f"f11_random_params_{k}" for k in range(8)]
+     "f10_crater_statistics_philox_env1", "f13_dt2_philox_env4", "f14_copper_wire_philox_env6", "f15_default_mode_philox_env7"] + [f"f11_random_params_{k}" for k in range(8)] + SECOND_EPISODE + PAST_TERMINATION
 
 
 @pytest.mark.parametrize("name", NATIVE)
@@ -45,6 +49,31 @@ def test_oracle_philox_matches_injected_reference(orc, golden_dir, name):
             assert abs(env.crater_stat_sum / total - mean) <= 1e-12 * mean
             var = max(env.crater_stat_sumsq / total - (env.crater_stat_sum / total) ** 2, 0.0)
             assert abs(var ** 0.5 - std) <= 1e-9 * max(std, 1.0)
+
+
+def test_second_episode_fixtures_really_carry_module_state_over(orc, golden_dir):
+    """F17 is not a fixture of two fresh episodes glued together: right after the reference's reset() the recorded
+    module state is the previous episode's (wire_edm.py:106-114 re-initialises EDMState only)."""
+    fx = Fixture(golden_dir / "f17_second_episode_philox_env2.npz")
+    (at, _seed, _init), = fx.meta["resets"]
+    pos = int(np.searchsorted(fx.float_steps, at))
+    assert fx.float_steps[pos] == at
+    row = {k: float(fx.float_row(k)[pos]) for k in fx.float_fields}
+    assert row["debris_volume"] > 1e-5 and row["h_zone"] > 0 and row["wire_last_flow"] > 0 and row["diel_last_gap"] > 0
+    assert int(fx.int_row("time")[at]) == 1 and int(fx.int_row("time")[at - 1]) == at     # a new EDMState: the clock restarts
+    assert fx.data["crater_stats"][0] == (fx.int_row("spark_state") == 1).sum() / 3 or fx.data["crater_stats"][0] > 40  # one list, two episodes
+    short = Fixture(golden_dir / "f17_reset_during_short_philox_env4.npz")
+    (at, _seed, _init), = short.meta["resets"]
+    rem = short.int_row("debris_short_remaining")
+    assert rem[at - 1] > 5 and rem[at] == rem[at - 1] - 1 and short.int_row("is_short_circuit")[at] == 1   # the timer runs on
+    assert float(short.float_row("workpiece_position")[np.searchsorted(short.float_steps, at)]) == 50.0     # at the new episode's gap
+    stale = Fixture(golden_dir / "f17_stale_current_cache_philox_env5.npz")
+    (at, _seed, _init), = stale.meta["resets"]
+    cur = stale.float_row("current")
+    fs = stale.float_steps
+    before_latch_1 = cur[(fs < 1000) & (cur > 0)]
+    before_latch_2 = cur[(fs >= at) & (fs < at + 1000) & (cur > 0)]
+    assert set(before_latch_1.tolist()) == {60.0} and len(before_latch_2) and set(before_latch_2.tolist()) != {60.0}
 
 
 def test_known_answers_from_survey(orc, golden_dir):

@@ -337,3 +337,50 @@ def test_default_modes_before_the_first_latch_fixture(golden_dir):
     got = run_fixture_through_trace(env, fx, exact_floats=True)
     early = (got["spark_state"][:1000] == 1)
     assert early.sum() > 5 and set(np.unique(got["current"][:1000][early]).tolist()) == {60.0}   # not I13's 215 A
+
+
+COMPAT_FIXTURES = ["f17_second_episode_philox_env2", "f17_reset_during_short_philox_env4", "f17_stale_current_cache_philox_env5",
+                   "f18_past_target_philox_env1", "f18_past_wire_break_philox_env3", "f18_past_collision_philox_env6"]
+
+
+@pytest.mark.parametrize("name", COMPAT_FIXTURES)
+def test_reference_compatible_reset_and_stepping_past_termination(golden_dir, name):
+    """F17 / F18 on the batched environment: `WireEDMEnv(reset_semantics="reference")` re-initialises EDMState only, as
+    the reference's reset() of a used environment does (wire_edm.py:106-114: short timers, current cache, debris, flow /
+    density / convection caches, prev_accel and the crater list live on in its module objects), and
+    `freeze_terminated=False` keeps stepping a terminated environment as the reference's unguarded step() does
+    (wire_edm.py:116-157; after a wire break: wire.py:260-261 + the early return of wire_edm.py:129-130).  Whole
+    trajectories, bit for bit on the LIBM seam: once microsecond by microsecond through `step()`, once in fused launches
+    read back through the device trace."""
+    from tests._fixture_env import compat_env_from_fixture, run_fixture_stepwise, run_fixture_through_trace
+
+    fx = Fixture(golden_dir / f"{name}.npz")
+    env = compat_env_from_fixture(fx, 8, device="cpu", backend=LibmOracleBackend)
+    assert run_fixture_stepwise(env, fx, exact_floats=True, every=7) > fx.n_steps // 8
+    env = compat_env_from_fixture(fx, 8, device="cpu", backend=LibmOracleBackend)
+    got = run_fixture_through_trace(env, fx, exact_floats=True)
+    if name.startswith("f18"):
+        first = int(np.argmax(fx.int_row("terminated") != 0))
+        assert fx.int_row("terminated")[first:].all() and fx.n_steps - first >= 500   # >= 500 us past `terminated`
+        assert got["done"][first:].all() and not got["done"][:first].any()
+
+
+def test_default_reset_and_freeze_differ_from_the_reference_where_documented(golden_dir):
+    """The defaults stay what they were (DESIGN.md deviations 1 and 2): a full reset forgets the module state the
+    reference would carry over, and a terminated environment is frozen."""
+    from tests._fixture_env import env_from_fixture, fixture_segments, apply_fixture_reset
+
+    fx = Fixture(golden_dir / "f17_second_episode_philox_env2.npz")
+    env = env_from_fixture(fx, 8, device="cpu", backend=LibmOracleBackend)        # reset_semantics="full"
+    (lo, hi, _), (lo2, hi2, reset) = fixture_segments(fx)
+    act = env.make_action(*[fx.actions[0][i] for i in (0, 1)], int(fx.actions[0][4]), fx.actions[0][2], fx.actions[0][3])
+    env.step_many(act, hi - lo)
+    assert float(env.state.debris_volume[2]) > 1e-5
+    apply_fixture_reset(env, reset)
+    assert float(env.state.debris_volume[2]) == 0.0 and float(env.state.h_eff_zone[2]) == 0.0 and int(env.state.spark_count[2]) == 0
+    fz = Fixture(golden_dir / "f18_past_target_philox_env1.npz")
+    env = env_from_fixture(fz, 8, device="cpu", backend=LibmOracleBackend)        # freeze_terminated=True
+    a = fz.actions[0]
+    env.step_many(env.make_action(a[0], a[1], int(a[4]), a[2], a[3]), fz.n_steps)
+    first = int(np.argmax(fz.int_row("terminated") != 0))
+    assert int(env.state.time[1]) == first + 1 and bool(env.state.done[1])      # frozen at the terminating step

@@ -167,8 +167,13 @@ def run_scenario(name, *, n_steps, seed=0, config=None, control_mode="position",
                  wire=None, material=None, dielectric=None, mechanics=None, rng="native", env_id=0,
                  state_init=None, module_init=None, T_init=None, action=None, action_schedule=None,
                  controller=None, forced=None, disable_ignition=False, t_snap_every=None,
-                 float_stride=1, stop_on_terminate=True, note=""):
-    """Run one scenario on the reference and write tests/golden/<name>.npz."""
+                 float_stride=1, stop_on_terminate=True, resets=None, note=""):
+    """Run one scenario on the reference and write tests/golden/<name>.npz.
+
+    ``resets``: [(step, seed, state_init), ...] -- before step number `step` the SAME environment object is reset with
+    the reference's own `env.reset(seed=seed)` (wire_edm.py:106-114: a new EDMState; the module objects live on) and
+    `state_init` is applied to the new state, as a driver's second episode does.  ``stop_on_terminate=False`` keeps
+    calling `step()` after `terminated`, as nothing in the reference forbids (wire_edm.py:116-157 has no guard)."""
     config = dict(config or {})
     mods = {"ignition": dict(ignition or {}), "wire": dict(wire or {}), "material": dict(material or {}),
             "dielectric": dict(dielectric or {}), "mechanics": dict(mechanics or {})}
@@ -211,7 +216,20 @@ def run_scenario(name, *, n_steps, seed=0, config=None, control_mode="position",
     forced_rows = []
     raised = None
 
+    resets = [(int(at), int(sd), dict(si or {})) for at, sd, si in (resets or [])]
     for step in range(n_steps):
+        for at, seed2, init2 in resets:
+            if at == step:
+                env.reset(seed=seed2)  # the reference's own reset of a USED environment
+                if rng == "native":
+                    nxt = RecordingRNG(env.np_random)
+                else:
+                    nxt = PhiloxShim(seed2, env_id)  # reset(seed=) re-keys: key = the new seed, episode 0
+                nxt.trace = rec.trace  # one continuous draw trace
+                rec = nxt
+                env.np_random = rec
+                for k, v in init2.items():
+                    setattr(env.state, k, v)
         if action_schedule is not None:
             for at, act in action_schedule:
                 if at == step:
@@ -261,6 +279,7 @@ def run_scenario(name, *, n_steps, seed=0, config=None, control_mode="position",
         "control_mode": control_mode, "config": config, "modules": mods,
         "state_init": state_init or {}, "module_init": module_init or {},
         "T_init": T_init or [], "disable_ignition": disable_ignition, "n_steps_run": len(ints["time"]),
+        "resets": [[at, sd, si] for at, sd, si in resets], "stop_on_terminate": bool(stop_on_terminate),
         "n_seg": int(env.wire.n_segments), "zone": [int(env.wire.zone_start), int(env.wire.zone_end)],
         "contacts": [int(env.wire.contact_bottom_idx), int(env.wire.contact_top_idx)],
         "raised": raised, "numpy": np.__version__,
@@ -632,6 +651,49 @@ def main():
                  state_init={"workpiece_position": 20.0, "wire_position": 10.0, "target_position": 5000.0},
                  action=make_action(0.1, 90.0, 9, 2.0, 25.0), t_snap_every=1800, float_stride=3,
                  note="sparks before the first control-step latch use the default modes")
+
+    # F17 — the reference's SECOND episode: reset() of a used environment re-initialises EDMState only
+    # (wire_edm.py:106-114); module-private state leaks into the next episode
+    dense = {"workpiece_position": 25.0, "wire_position": 10.0, "target_position": 5000.0}
+    run_scenario("f17_second_episode_philox_env2", n_steps=6000, seed=95, rng="philox", env_id=2,
+                 state_init=dense, resets=[(3000, 951, dense)], action=make_action(0.1, 80.0, 9, 3.0, 30.0),
+                 t_snap_every=1000, float_stride=3,
+                 note="reset(seed) -> 3000 us -> reset(seed') -> 3000 us on ONE environment object: debris volume, flow / "
+                      "density / convection caches, prev_accel and the crater list carry over")
+    run_scenario("f17_second_episode_native", n_steps=5000, seed=96, state_init=dense, resets=[(2500, 961, dense)],
+                 action=make_action(0.1, 80.0, 9, 3.0, 30.0), t_snap_every=1250, float_stride=3,
+                 note="the same with the reference's own PCG64 streams (reset(seed') reseeds env.np_random)")
+    run_scenario("f17_reset_during_short_philox_env4", n_steps=400, seed=97, rng="philox", env_id=4,
+                 state_init={"workpiece_position": 11.5, "wire_position": 10.0, "target_position": 5000.0},
+                 resets=[(130, 971, {"target_position": 5000.0})], action=make_action(0.0, 80.0, 5, 3.0, 80.0),
+                 note="gap 1.5 um < hard_short_gap: a 50-us debris-short timer is running when reset() comes; it runs on "
+                      "in the new episode at its 50-um gap (ignition.py:75-76,204-217)")
+    run_scenario("f17_stale_current_cache_philox_env5", n_steps=4200, seed=98, rng="philox", env_id=5,
+                 ignition={"default_current_mode": "I13"}, state_init=dense, resets=[(2500, 981, dense)],
+                 action=make_action(0.1, 90.0, 9, 2.0, 25.0), t_snap_every=2100, float_stride=3,
+                 note="after the reset state.current_mode is None again but the ignition module's current cache names the "
+                      "previous episode's mode: None resolves through default_current_mode (I13), not the fresh 60 A "
+                      "(ignition.py:98-113)")
+
+    # F18 — step() called after `terminated` (wire_edm.py:116-157 has no guard)
+    run_scenario("f18_past_target_philox_env1", n_steps=2400, seed=99, rng="philox", env_id=1,
+                 state_init={"workpiece_position": 25.0, "wire_position": 10.0, "target_position": 25.002},
+                 action=QUICKSTART, stop_on_terminate=False, t_snap_every=600, float_stride=3,
+                 note="target reached, then stepped on: everything continues, terminated stays True")
+    run_scenario("f18_past_wire_break_philox_env3", n_steps=600, seed=100, rng="philox", env_id=3,
+                 state_init=dense, T_init=[(180, 186, 1600.0)], action=make_action(0.1, 80.0, 9, 3.0, 30.0),
+                 stop_on_terminate=False, t_snap_every=100,
+                 note="Tmax > 1500 K at the first step, then 599 more: ignition / material / dielectric go on, the wire module "
+                      "returns at once, every step returns before mechanics and clocks (time stays 0, so the Philox shim "
+                      "hands out the same variates each step)")
+    run_scenario("f18_past_wire_break_native", n_steps=600, seed=101, state_init=dense, T_init=[(180, 186, 1600.0)],
+                 action=make_action(0.1, 80.0, 9, 3.0, 30.0), stop_on_terminate=False, t_snap_every=100,
+                 note="the same with the reference's own PCG64 stream (which does advance)")
+    run_scenario("f18_past_collision_philox_env6", n_steps=700, seed=102, rng="philox", env_id=6,
+                 state_init={"workpiece_position": 50.0, "wire_position": 149.5, "wire_velocity": 20000.0,
+                             "target_position": 5000.0},
+                 action=make_action(1.0, 80.0, 5, 3.0, 80.0), stop_on_terminate=False,
+                 note="wire > workpiece + 100 -> is_wire_broken by _check_termination, then stepped on")
 
     # F16 — the reference's own SimulationLogger over its own driver loop and signal list
     if not only or only in "f16_logger_philox_env3":
