@@ -253,12 +253,13 @@ def time_launches(env, act, n_sub, steps, warmup):
 
 
 def side_measurements(n_local, wire, S, device):
-    """Four side measurements of the same build at the bench batch (single GPU only):
+    """Five side measurements of the same build at the bench batch (single GPU only):
       * the reference's own cadence, one launch per microsecond (wedm_step(n_substeps=1));
       * a densely sparking start (15 um gap: ~5.6 sparks per environment per ms instead of ~0.7);
       * the closed loop of experiments/run_simulation.py with ITS PI voltage controller evaluated on the device
         from the kernel-side running voltage sum (steady state after a 100 ms approach);
-      * a batch with in-launch autoreset whose environments keep terminating at different times."""
+      * a batch with in-launch autoreset whose environments keep terminating at different times;
+      * the same batch without autoreset: terminated environments stay frozen among the live ones."""
     import torch
 
     from sparc_amd import VoltageController, WireEDMEnv, run_controlled
@@ -328,6 +329,24 @@ def side_measurements(n_local, wire, S, device):
                 "value": n_local * 20 * 1000 / dt, "unit": "env-steps/s", "kernel": env._backend.last_kernel(),
                 "resets_per_env_per_launch": (int(env.state.episode.sum().item()) - e0) / n_local / 20.0,
                 "timing": "wall clock around 20 launches of 1000 us"})
+    env.close()
+    # the same batch WITHOUT autoreset: terminated environments stay frozen until the host resets them.  The first launch that
+    # finds one reports it to the host (a host-visible word, no synchronisation) and the handle moves to the kernel
+    # instantiation whose tile code tolerates frozen lanes; before, such a wave fell back to the per-cell predicated path.
+    env = WireEDMEnv(num_envs=n_local, device=device, wire_params=wire, config=EnvironmentConfig(target_cutting_distance=50.002))
+    env.reset(seed=7)
+    act = env.make_action(0.1, 80.0, 5, 3.0, 80.0)
+    for _ in range(4):
+        env.step_many(act, 1000)
+    torch.cuda.synchronize()
+    frozen0 = int(env.state.done.sum().item())
+    sec, kname = time_launches(env, act, 1000, 8, 1)
+    frozen1 = int(env.state.done.sum().item())
+    live = n_local - 0.5 * (frozen0 + frozen1)
+    out.append({"name": "no autoreset, terminated environments stay frozen in the batch (cutting target 0.002 um ahead)",
+                "value": live * 1000 / sec, "unit": "env-steps/s (live environments only)", "kernel": kname,
+                "all_lanes_equivalent": n_local * 1000 / sec, "frozen_fraction": 0.5 * (frozen0 + frozen1) / n_local,
+                "kernel_ms": sec * 1e3})
     env.close()
     return out
 

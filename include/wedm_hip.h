@@ -115,7 +115,8 @@ enum wedm_i32_field {
     WEDM_I_RANDOM_SHORT_REM,   /* IgnitionModule.random_short_remaining */
     WEDM_I_DEBRIS_SHORT_REM,   /* IgnitionModule.debris_short_remaining */
     WEDM_I_TIME_CRITICAL,      /* state.time_in_critical_temp           */
-    WEDM_I_CURRENT_MODE,       /* state.current_mode: n for "I<n>", 0 encodes None */
+    WEDM_I_CURRENT_MODE,       /* state.current_mode: n for "I<n>", 0 encodes None; -1 = None while the ignition module's
+                                  current cache still names a mode of an earlier episode (reset_semantics 1 only) */
     WEDM_I_EPISODE,            /* resets seen by this environment (RNG counter word) */
     WEDM_I_KEY_LO,             /* Philox key, low  32 bits of the reset seed */
     WEDM_I_KEY_HI,             /* Philox key, high 32 bits of the reset seed */
@@ -396,7 +397,8 @@ int64_t wedm_trace_samples(wedm_ctx* ctx);
  * microseconds, any geometry), 6 = stream kernel (single microseconds, uniform geometry: the whole
  * chunk of a lane requested up front, tile walk in LDS, no barrier; the automatic choice for
  * n_substeps == 1 where one round of blocks covers the batch).  All variants produce bit-identical
- * results.  With wedm_params.stencil_mode 1 only 0, 1 and 2 are accepted.                       */
+ * results.  With wedm_params.stencil_mode 1 only 0, 1, 2 and 3 are accepted (3: the tile walk with
+ * per-cell coefficients, no stage-major / packed form).                                          */
 int32_t wedm_set_kernel(wedm_ctx* ctx, int32_t variant);
 
 /* lanes that share one environment in kernels 2, 3, 4 and 6: 0 = auto, or 1, 2, 4, 8 (16: not kernel 4) */

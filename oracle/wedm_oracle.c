@@ -1016,7 +1016,8 @@ static void gather_env(const wedm_state_ptrs* s, int64_t e, wedm_oracle_env* v) 
     v->time_since_spark_end = I32(WEDM_I_SINCE_SPARK_END);
     v->spark_dur = I32(WEDM_I_SPARK_DUR); v->random_short_remaining = I32(WEDM_I_RANDOM_SHORT_REM);
     v->debris_short_remaining = I32(WEDM_I_DEBRIS_SHORT_REM);
-    v->time_in_critical_temp = I32(WEDM_I_TIME_CRITICAL); v->current_mode = I32(WEDM_I_CURRENT_MODE);
+    v->time_in_critical_temp = I32(WEDM_I_TIME_CRITICAL);
+    v->current_mode = I32(WEDM_I_CURRENT_MODE) < 0 ? 0 : I32(WEDM_I_CURRENT_MODE); /* -1: None over a stale current cache */
     v->rng.episode = (uint32_t)I32(WEDM_I_EPISODE);
     v->rng.seed = (uint64_t)(uint32_t)I32(WEDM_I_KEY_LO) | ((uint64_t)(uint32_t)I32(WEDM_I_KEY_HI) << 32);
     v->spark_count = I32(WEDM_I_SPARK_COUNT);
@@ -1053,7 +1054,8 @@ static void scatter_env(const wedm_state_ptrs* s, int64_t e, const wedm_oracle_e
     I32(WEDM_I_SINCE_SPARK_END) = v->time_since_spark_end;
     I32(WEDM_I_SPARK_DUR) = v->spark_dur; I32(WEDM_I_RANDOM_SHORT_REM) = v->random_short_remaining;
     I32(WEDM_I_DEBRIS_SHORT_REM) = v->debris_short_remaining;
-    I32(WEDM_I_TIME_CRITICAL) = v->time_in_critical_temp; I32(WEDM_I_CURRENT_MODE) = v->current_mode;
+    I32(WEDM_I_TIME_CRITICAL) = v->time_in_critical_temp;
+    I32(WEDM_I_CURRENT_MODE) = (v->current_mode == 0 && v->mode_cached) ? -1 : v->current_mode; /* include/wedm_hip.h */
     I32(WEDM_I_SPARK_COUNT) = v->spark_count;
     if (s->stats) {
         STAT(WEDM_S_CRATER_SUM) = v->crater_stat_sum; STAT(WEDM_S_CRATER_SUMSQ) = v->crater_stat_sumsq;
@@ -1130,6 +1132,8 @@ static void reset_env_rows(const wedm_params* p, const wedm_state_ptrs* s, int64
     if (!keep_modules) {
         F64(WEDM_F_LAST_GAP) = -1.0;
         F64(WEDM_F_LAST_DENSITY) = -1.0;
+    } else if (I8(WEDM_B_MODE_CACHED)) {
+        I32(WEDM_I_CURRENT_MODE) = -1; /* None over a current cache that names a mode (include/wedm_hip.h) */
     }
     F64(WEDM_F_TMAX) = (double)(float)p->spool_T;
     if (s->reward) s->reward[e] = 0.0f;

@@ -278,6 +278,10 @@ struct Cold {  // everything reachable only through rare branches
     Tables tb;
     const double* replay;   // wedm_bind_rng_replay: [step][WEDM_REPLAY_SLOTS][stride], or NULL
     int64_t replay_steps;
+    // host-visible word (pinned, mapped): a wave of a kernel instantiation WITHOUT the frozen-lane tile code that finds a
+    // terminated environment at its start sets it; wedm_step reads it (plain host read, no synchronisation) and launches
+    // the FROZEN_OK instantiation from then on.  Only speed depends on it, never a result.
+    int32_t* frozen_seen;
 };
 
 // The kernels never touch their by-value `Cold` argument directly: they read it THROUGH the
@@ -336,13 +340,11 @@ __device__ __forceinline__ const WEDM_AS4 T* opaque_const(const T* p) {
 // first latch) hits the fresh cache and yields 60 A whatever `default_current_mode` is; that
 // parameter only serves modes outside currents.json.
 // After a reset with reset_semantics 1 (the reference's own: the module object lives on) the cache may hold a mode of the
-// previous episode: None then misses it and resolves through `default_current_mode` (flag WEDM_B_MODE_CACHED, read only
-// on this rare path).
+// previous episode: None then misses it and resolves through `default_current_mode`.  That None is encoded as mode -1
+// (written by the reset from flag WEDM_B_MODE_CACHED), so no step ever reads the flag.
 __device__ __forceinline__ double peak_current(const ColdRef cold, int32_t mode, int64_t e) {
-    if (mode == 0) {
-        const ColdPtr c = cold.get();
-        return c->s.i8[(int64_t)WEDM_B_MODE_CACHED * c->s.stride + e] ? opaque(c->p)->default_current : 60.0;
-    }
+    (void)e;
+    if (mode == 0) return 60.0;
     return (mode >= 1 && mode <= WEDM_MAX_MODE) ? cold->tb.mode_current[mode] : opaque(cold->p)->default_current;
 }
 
@@ -435,7 +437,8 @@ __device__ __forceinline__ void store_env(const ColdRef cold, int64_t e, const E
 // h64: when given, the two convection coefficients are handed back as loaded (float64) and v.h_base / v.h_zone are left for
 // the caller to convert LATER: the conversion is the first use of loaded data, and placed here it made the compiler wait
 // for the state rows (a whole memory round trip) before the single-microsecond kernel could request its wire rows.
-__device__ __forceinline__ void load_env_inputs(const ColdRef cold, int64_t e, Env& v, bool ignition_on, double* h64 = nullptr) {
+__device__ __forceinline__ void load_env_inputs(const ColdRef cold, int64_t e, Env& v, bool ignition_on, double* h64 = nullptr,
+                                                bool keep_stepping = false) {
     const ColdPtr c = cold.get();
     const int64_t stride = c->s.stride;
     const struct { const double* f64; const int32_t* i32; const int8_t* i8; } s{c->s.f64, c->s.i32, c->s.i8};
@@ -468,6 +471,9 @@ __device__ __forceinline__ void load_env_inputs(const ColdRef cold, int64_t e, E
         v.is_short = *WEDM_ROW(s.i8, WEDM_B_IS_SHORT);
     }
     v.last_crater = 0.0; v.cavity = 0.0; v.tmax = 0.0f; v.ctrl = 0;
+    // keep_stepping_terminated: a broken wire's temperature monitor stands still (wire.py:260-261), so the maximum is an
+    // input for such a lane (wave-uniform switch; the default mode never loads the row)
+    if (keep_stepping) v.tmax = (float)*WEDM_ROW(s.f64, WEDM_F_TMAX);
     v.ipk = 0.0;
 }
 
@@ -580,13 +586,14 @@ __device__ __forceinline__ int32_t env_i32_row(const Env& v, int row) {
     }
     return 0;
 }
-__device__ __forceinline__ int32_t env_i8_row(const Env& v, int row) {
+// (`keep_stepping`: wedm_params.keep_stepping_terminated -- row DONE is then `terminated` of the step, see done_row())
+__device__ __forceinline__ int32_t env_i8_row(const Env& v, int row, bool keep_stepping) {
     switch (row) {
         case WEDM_B_SPARK_STATE: return v.state;
         case WEDM_B_IS_SHORT: return v.is_short;
         case WEDM_B_WIRE_BROKEN: return v.broken;
         case WEDM_B_TARGET_REACHED: return v.reached;
-        case WEDM_B_DONE: return v.done;
+        case WEDM_B_DONE: return keep_stepping ? (v.broken | v.reached) : v.done;
         case WEDM_B_CTRL_STEP: return v.ctrl;
         case WEDM_B_ERROR: return v.err;
     }
@@ -600,7 +607,7 @@ __device__ __forceinline__ int64_t trace_column(const wedm_trace_desc& tr, int64
 }
 
 // The selected scalar rows of one environment into ring slot `slot` (one lane per environment).
-__device__ __forceinline__ void trace_scalars(const wedm_trace_desc& tr, int64_t col, const Env& v, int slot) {
+__device__ __forceinline__ void trace_scalars(const wedm_trace_desc& tr, int64_t col, const Env& v, int slot, bool keep_stepping) {
     const int64_t cnt = tr.env_count;
     const uint32_t mf = tr.f64_mask, mi = tr.i32_mask, mb = tr.i8_mask;
     // loop over the SET bits (wave-uniform): the cost follows the number of traced rows, not the 45
@@ -615,7 +622,7 @@ __device__ __forceinline__ void trace_scalars(const wedm_trace_desc& tr, int64_t
     }
     if (mb) {
         int8_t* dst = tr.i8 + (int64_t)slot * __builtin_popcount(mb) * cnt + col;
-        for (uint32_t m = mb; m; m &= m - 1u) { *dst = (int8_t)env_i8_row(v, __builtin_ctz(m)); dst += cnt; }
+        for (uint32_t m = mb; m; m &= m - 1u) { *dst = (int8_t)env_i8_row(v, __builtin_ctz(m), keep_stepping); dst += cnt; }
     }
 }
 
@@ -823,7 +830,7 @@ __device__ __forceinline__ Coef scalar_prelude(const Hot& p, const ColdRef cold,
         // `_get_peak_current` is called exactly where `burning` holds; with a latched mode it fills the module's current
         // cache (ignition.py:98-113).  The first such call after a mode was latched falls on an ignition, a short pulse
         // or the latch step itself, and every one of those runs this general prelude: flag WEDM_B_MODE_CACHED.
-        if (writer && burning && s.mode != 0 && (ign || to_pulse || s.ctrl))
+        if (writer && burning && s.mode > 0 && (ign || to_pulse || s.ctrl))
             cc0->s.i8[(int64_t)WEDM_B_MODE_CACHED * cc0->s.stride + e] = 1;
         if (ign) {  // rare: spark location, Generator.uniform(0, h)
             const double h = p.per_env_geometry ? cc0->g.f64[(int64_t)WEDM_G_HEIGHT * cc0->s.stride + e] : h_u;
@@ -839,7 +846,7 @@ __device__ __forceinline__ Coef scalar_prelude(const Hot& p, const ColdRef cold,
     if (fresh) {
         const ColdPtr cc = cc0;
         const Tables tb{cc->tb.mode_current, cc->tb.crater_mean, cc->tb.crater_std, cc->tb.crater_depth, cc->tb.crater_valid};
-        int m = s.mode == 0 ? 1 : s.mode;  // None -> "I1" (material.py:104-105)
+        int m = s.mode <= 0 ? 1 : s.mode;  // None (0, or -1: see peak_current) -> "I1" (material.py:104-105)
         const bool in_range = m >= 1 && m <= WEDM_MAX_MODE;
         if (!in_range) m = 1;
         // everything this branch reads from memory is requested here, before the crater normal (~230 instructions
@@ -1125,6 +1132,20 @@ __device__ __forceinline__ float stencil_cell_f64(int i, int n_seg, float tm1, f
     return (float)(t + (double)d * g.tuf64);
 }
 
+// An INTERIOR cell (1 <= i <= n - 2) in that typing, coefficients handed in (the fused kernel's tile code, stencil_mode 1):
+// the same sequence of float64 expressions and float32 roundings as stencil_cell_f64, with the Joule and advection terms
+// always applied -- their coefficient is 0.0 where the reference skips them, and (float)((double)d + 0.0 * x) == d.
+__device__ __forceinline__ float interior_cell_f64(float tm1, float tc, float tp1, double k64, double tuf64, double conv64,
+                                                   double tdiel64, double adv64, double jfe64, double alpha64, double tref64) {
+    const double m = (double)tm1, t = (double)tc;
+    float d = (float)(k64 * (m - 2.0 * t + (double)tp1));
+    const double rho_T = 1.0 + alpha64 * (t - tref64);
+    d = (float)((double)d + jfe64 * rho_T);
+    d = (float)((double)d - conv64 * (t - tdiel64));
+    d = (float)((double)d + adv64 * (m - t));
+    return (float)(t + (double)d * tuf64);
+}
+
 // ------------------------------------------- scalar epilogue (modules 4b, 5, env)
 // wire.py:376-388, wire_edm.py:129-146,172-179, mechanics.py:79-114
 __device__ __forceinline__ void scalar_epilogue(const Hot& p, Env& s, float tmax) {
@@ -1185,8 +1206,11 @@ __device__ __forceinline__ void scalar_epilogue(const Hot& p, Env& s, float tmax
 // flag (`freeze_wire`) and afterwards takes it out again (`unfreeze_wire`).  Without keep_stepping_terminated both are
 // no-ops (a broken wire is frozen anyway: done_value 1); with it they make the walk skip exactly the lanes whose wire
 // module would return at once (wire.py:260-261) while prelude and epilogue go on running.
+// Lanes past the end of the batch carry done = WEDM_DEAD_LANE (bit 1), which neither of the two ever clears: such a lane
+// never runs physics and never stores, in either mode.
+#define WEDM_DEAD_LANE 2
 __device__ __forceinline__ void freeze_wire(Env& s) { s.done |= s.broken; }
-__device__ __forceinline__ void unfreeze_wire(const Hot& p, Env& s) { s.done &= p.done_value; }
+__device__ __forceinline__ void unfreeze_wire(const Hot& p, Env& s) { s.done &= (p.done_value ? ~0 : WEDM_DEAD_LANE); }
 
 __device__ __forceinline__ void write_obs(const ColdRef cold, int64_t e, const Env& s) {
     const ColdPtr c = cold.get();
@@ -1236,7 +1260,9 @@ __device__ __forceinline__ void reinit_env(const ColdRef cold, int64_t e, Env& s
     s.vacc = 0.0;
     s.tmax = spool;
     s.time = 0; s.tss = 0; s.tsov = 0; s.tsi = 0; s.tse = 0; s.dur = 0; s.tcrit = 0;
-    s.mode = 0; s.episode = episode; s.key0 = k0; s.key1 = k1;
+    // state.current_mode = None: 0, or -1 where the module's surviving current cache names a mode (peak_current)
+    s.mode = (keep_modules && c->s.i8[(int64_t)WEDM_B_MODE_CACHED * c->s.stride + e]) ? -1 : 0;
+    s.episode = episode; s.key0 = k0; s.key1 = k1;
     s.state = 0; s.is_short = 0; s.broken = 0; s.reached = 0; s.done = 0; s.ctrl = 0; s.err = 0;
     if (!keep_modules) {
         s.prev_a = 0.0; s.debris = 0.0; s.flow = 0.0; s.last_gap = -1.0; s.last_rho = -1.0; s.wire_last_flow = 0.0;

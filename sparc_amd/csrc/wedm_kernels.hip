@@ -128,7 +128,7 @@ __device__ __forceinline__ ColdRef kernarg_cold() {
         const wedm_trace_desc& tr = (k).trace;                                                   \
         const int64_t tcol = trace_column(tr, (e));                                              \
         if (tcol >= 0) {                                                                         \
-            if (SCALAR_LANE) trace_scalars(tr, tcol, (s), trace_slot);                           \
+            if (SCALAR_LANE) trace_scalars(tr, tcol, (s), trace_slot, (k).hot.done_value == 0);  \
             if (tr.T) {                                                                          \
                 const int64_t tcnt = tr.env_count;                                               \
                 float* tT = tr.T + (int64_t)trace_slot * (k).n_seg_max * tcnt + tcol;            \
@@ -266,7 +266,7 @@ __global__ void __launch_bounds__(256) wedm_step_global(const KArgs k) {
         reinit_env(cold, e, s, true);
         for (int q = 0; q < WEDM_T_QUADS(k.n_seg_max); ++q) T.stq(q, f4v{k.hot.spool, k.hot.spool, k.hot.spool, k.hot.spool});
     }
-    s.done &= k.hot.done_value;  // keep_stepping_terminated: the DONE row is `terminated` of the last step and freezes nothing
+    unfreeze_wire(k.hot, s);  // keep_stepping_terminated: the DONE row is `terminated` of the last step and freezes nothing
     s.ipk = s.done ? 0.0 : peak_current(cold, s.mode, e);
     Geom g;
     load_geom(k.hot, cold, e, g);
@@ -346,9 +346,9 @@ __global__ void __launch_bounds__(256) wedm_step_split(const KArgs k) {
     bool frozen0 = true;
     if (c == 0) {
         if (live) load_env(cold, e, s);
-        else s.done = 1;
+        else s.done = WEDM_DEAD_LANE;
         if (reinit) reinit_env(cold, e, s, true);
-        s.done &= k.hot.done_value;  // keep_stepping_terminated: nothing is frozen
+        unfreeze_wire(k.hot, s);  // keep_stepping_terminated: nothing is frozen
         frozen0 = s.done;
         if (!s.done) {
             s.ipk = peak_current(cold, s.mode, e);
@@ -447,7 +447,7 @@ __global__ void __launch_bounds__(256) wedm_step_split(const KArgs k) {
             const wedm_trace_desc& tr = k.trace;
             const int64_t tcol = live ? trace_column(tr, e) : -1;
             if (tcol >= 0) {
-                if (c == 0) trace_scalars(tr, tcol, s, trace_slot);
+                if (c == 0) trace_scalars(tr, tcol, s, trace_slot, k.hot.done_value == 0);
                 if (tr.T) {
                     const int64_t tcnt = tr.env_count;
                     float* tT = tr.T + (int64_t)trace_slot * k.n_seg_max * tcnt + tcol;
@@ -577,12 +577,23 @@ __device__ __forceinline__ void tile8_staged(const V (&old)[10], V (&tn)[8], flo
         tile_staged<V, JOULE, PERCELL, W>(old, tn, o, k, tuf, conv, tdiel, adv, jfe, alpha, tref);
 }
 
+// A wave that starts with a terminated (frozen) environment in a kernel instantiation without the frozen-lane tile
+// code tells the host (Cold::frozen_seen, host-visible): the next launches of the handle take the FROZEN_OK instantiation.
+#define WEDM_REPORT_FROZEN(cond)                                                      \
+    do {                                                                              \
+        if (!kFrozenOk && __any(cond)) {                                              \
+            int32_t* const seen = cold->frozen_seen;                                  \
+            if (seen && (threadIdx.x & 63) == 0) *seen = 1;                           \
+        }                                                                             \
+    } while (0)
+
 // Any geometry (uniform or one row per environment), L lanes per environment, every cell on the
 // predicated formula with the lane's own n_seg / zone / contact indices.  LDS layout and halo
 // exchange as in the fused kernels; the chunk length is uniform, C = ceil(n_seg_max / L), so an
 // environment with a shorter wire simply leaves the tail of its last chunks unused.
 template <int L, bool TRACE, bool F64>
 __global__ void __launch_bounds__(256, 2) wedm_step_lanes(const KArgs k) {
+    constexpr bool kFrozenOk = true;  // (predicated cells: a frozen lane costs this kernel nothing extra)
     const ColdRef cold = kernarg_cold();
 #ifndef WEDM_NO_PIN_LANES
     Hot hv = k.hot;
@@ -610,15 +621,16 @@ __global__ void __launch_bounds__(256, 2) wedm_step_lanes(const KArgs k) {
     Persist ps{0.0f, 0.0f, 0.0f, 0};
     load_geom(k.hot, cold, live ? e : 0, g);
     if (live) load_env(cold, e, s);
-    else { s.done = 1; s.unwind = 0.0; s.h_base = 0.0f; s.h_zone = 0.0f; }
+    else { s.done = WEDM_DEAD_LANE; s.unwind = 0.0; s.h_base = 0.0f; s.h_zone = 0.0f; }
     float* col = lds + tid;
     const bool reinit = live && s.done && WEDM_AUTORESET(cold);  // next-step autoreset (all L lanes of the environment agree)
     if (reinit) {
         reinit_env(cold, e, s, c == 0);
         for (int j = 0; j < C; ++j) col[j * 256] = k.hot.spool;
     }
-    s.done &= k.hot.done_value;  // keep_stepping_terminated: the DONE row is `terminated` of the last step and freezes nothing
+    unfreeze_wire(k.hot, s);  // keep_stepping_terminated: the DONE row is `terminated` of the last step and freezes nothing
     const bool frozen0 = s.done;
+    WEDM_REPORT_FROZEN(frozen0 && live);
     if (!s.done) {
         s.ipk = peak_current(cold, s.mode, e);
         init_persist(k.hot, cold, e, s, ps);
@@ -808,8 +820,12 @@ __device__ __forceinline__ float interior_cell(float tm1, float tc, float tp1, f
 // FROZEN_OK: see wedm_step_packed.  N1: the instantiation for tile tables with a one-change tile that is a boundary tile in
 // every microsecond (4 096 x 400 over 16 lanes: the end of the workpiece zone falls inside tile 2 of 4): +4.7 % there; the
 // extra code costs tables without such a tile 1-1.5 %, so they run the instantiation without it.
-template <int L, bool TRACE, bool FROZEN_OK = false, bool N1 = false>
+// F64: wedm_params.stencil_mode 1 -- the stencil as Numba types wire.py:58-123 (float64 expressions rounded at each float32
+// store), on the tile walk: every tile takes the boundary-tile code (per-cell coefficients, interior formula, end cells
+// patched), which is exact for regular tiles too; no stage-major / packed form.  Instantiated with FROZEN_OK only.
+template <int L, bool TRACE, bool FROZEN_OK = false, bool N1 = false, bool F64 = false>
 __global__ void __launch_bounds__(256, 2) wedm_step_fused(const KArgs k) {
+    constexpr bool kFrozenOk = FROZEN_OK;
     const ColdRef cold = kernarg_cold();
     Hot hv = k.hot;
     pin_hot_in_vgprs(hv);  // 178 -> 225 VGPRs, SGPR spill traffic in the loop 111 -> 37 instructions: +8 %
@@ -836,15 +852,16 @@ __global__ void __launch_bounds__(256, 2) wedm_step_fused(const KArgs k) {
     Persist ps{0.0f, 0.0f, 0.0f, 0};
     load_geom(k.hot, cold, live ? e : 0, g);
     if (live) load_env(cold, e, s);
-    else { s.done = 1; s.unwind = 0.0; s.h_base = 0.0f; s.h_zone = 0.0f; }
+    else { s.done = WEDM_DEAD_LANE; s.unwind = 0.0; s.h_base = 0.0f; s.h_zone = 0.0f; }
     float* col = lds + tid;
     const bool reinit = live && s.done && WEDM_AUTORESET(cold);  // next-step autoreset (all L lanes of the environment agree)
     if (reinit) {
         reinit_env(cold, e, s, c == 0);
         for (int j = 0; j < C; ++j) col[j * 256] = k.hot.spool;
     }
-    s.done &= k.hot.done_value;  // keep_stepping_terminated: the DONE row is `terminated` of the last step and freezes nothing
+    unfreeze_wire(k.hot, s);  // keep_stepping_terminated: the DONE row is `terminated` of the last step and freezes nothing
     const bool frozen0 = s.done;
+    WEDM_REPORT_FROZEN(frozen0 && live);
     if (!s.done) {
         s.ipk = peak_current(cold, s.mode, e);
         init_persist(k.hot, cold, e, s, ps);
@@ -853,6 +870,22 @@ __global__ void __launch_bounds__(256, 2) wedm_step_fused(const KArgs k) {
 
     const int cbase = c * C;
     const float spool = k.hot.spool, tref = k.hot.tref, alpha = k.hot.alpha, tdiel = k.hot.tdiel;
+    StencilF64 f64c{0.0, 0.0, 0.0};
+    if (F64) { const wedm_params* pp = cold->p; f64c = StencilF64{pp->temp_ref, pp->alpha_rho, pp->dielectric_temperature}; }
+    // one cell by the full predicated formula / one interior cell with coefficients handed in, in the stencil's typing
+    // (zone / contacts: whether the cell lies in the workpiece zone / between the contacts)
+    auto cell_full = [&](int i, float tm, float tcc, float tp, const Coef& cf, const Persist& ps) -> float {
+        if (F64) return stencil_cell_f64(i, n, tm, tcc, tp, g, cf, ps, f64c, s.h_base, s.h_zone);
+        return stencil_cell(i, n, tm, tcc, tp, g, cf, ps, tref, alpha, tdiel);
+    };
+    auto cell_interior = [&](float tm, float tcc, float tp, bool zone, bool contacts, const Coef& cf, const Persist& ps,
+                             float jf_lane) -> float {
+        if (F64)
+            return interior_cell_f64(tm, tcc, tp, g.k64, g.tuf64, (double)(zone ? s.h_zone : s.h_base) * g.a64, f64c.tdiel, ps.adv64,
+                                     (contacts && cf.joule_on) ? cf.jf64 : 0.0, f64c.alpha, f64c.tref);
+        return interior_cell<true>(tm, tcc, tp, g.k, g.tuf, zone ? ps.conv_zone : ps.conv_base, tdiel, ps.adv,
+                                   contacts ? jf_lane : 0.0f, alpha, tref);
+    };
     const int n_tiles = wt->n_tiles;
     // per-lane tile membership, gathered ONCE so that walking a tile reads nothing but LDS
     // (scalar loads share lgkmcnt with LDS and would drain the prefetch every tile):
@@ -869,11 +902,11 @@ __global__ void __launch_bounds__(256, 2) wedm_step_fused(const KArgs k) {
         kind_n |= (kd == TILE_N ? 1u : 0u) << t;
         kind_s |= (kd == TILE_S ? 1u : 0u) << t;
     }
-    kind_n = __builtin_amdgcn_readfirstlane(kind_n);
+    kind_n = F64 ? 0u : __builtin_amdgcn_readfirstlane(kind_n);  // (F64: every tile on the boundary-tile code)
     kind_s = __builtin_amdgcn_readfirstlane(kind_s);
     // tiles that take the regular code although they hold a wire end cell / a contact-flag change (see WalkTable)
-    const uint32_t kind_ne = __builtin_amdgcn_readfirstlane(wt->kind_ne_mask), kind_nj = __builtin_amdgcn_readfirstlane(wt->kind_nj_mask);
-    const uint32_t kind_n1 = N1 ? (__builtin_amdgcn_readfirstlane(wt->kind_n1_mask) & 0x7fffffffu) : 0u;
+    const uint32_t kind_ne = F64 ? 0u : __builtin_amdgcn_readfirstlane(wt->kind_ne_mask), kind_nj = F64 ? 0u : __builtin_amdgcn_readfirstlane(wt->kind_nj_mask);
+    const uint32_t kind_n1 = (N1 && !F64) ? (__builtin_amdgcn_readfirstlane(wt->kind_n1_mask) & 0x7fffffffu) : 0u;
 #pragma unroll
     for (int q = 0; q < 3; ++q) split_pack[q] = __builtin_amdgcn_readfirstlane(split_pack[q]);
     if (c == 0) col[0] = spool;  // wire cell 0 is held at the spool temperature (wire.py:83)
@@ -886,7 +919,7 @@ __global__ void __launch_bounds__(256, 2) wedm_step_fused(const KArgs k) {
     // patched cells: by the interior formula from OLD values before the walk (their chains overlap those of the plasma /
     // last cell), written after it; the walk covers the full tiles only.  Bits per tail cell q: zone, contacts,
     // interior, valid (this lane's chunk).
-    const int tail = (C > 8 && (C & 7) >= 1 && (C & 7) <= 2) ? (C & 7) : 0;
+    const int tail = (!F64 && C > 8 && (C & 7) >= 1 && (C & 7) <= 2) ? (C & 7) : 0;
     uint32_t tail_bits = 0u;
     for (int q = 0; q < tail; ++q) {
         const uint32_t zj = wt->zj[C - tail + q], iv = wt->iv[C - tail + q];
@@ -931,14 +964,14 @@ __global__ void __launch_bounds__(256, 2) wedm_step_fused(const KArgs k) {
                 if (cf.pidx == 1) tm = spool;
                 const float tcc = col[jp * 256];
                 const float tp = jp < C - 1 ? col[(jp + 1) * 256] : halo_r;
-                tpl = stencil_cell(cf.pidx, n, tm, tcc, tp, g, cf, ps, tref, alpha, tdiel);
+                tpl = cell_full(cf.pidx, tm, tcc, tp, cf, ps);
             }
         }
         if (owns_last && !s.done) {
             const int jl = n - 1 - cbase;
             float tm = jl > 0 ? col[(jl - 1) * 256] : halo_l;
             if (n - 1 == 1) tm = spool;
-            tlast = stencil_cell(n - 1, n, tm, col[jl * 256], 0.0f, g, cf, ps, tref, alpha, tdiel);
+            tlast = cell_full(n - 1, tm, col[jl * 256], 0.0f, cf, ps);
         }
 
         // ---- tail cells (see `tail`): new values from OLD ones, now; not on the predicated path, whose last tile covers them
@@ -1059,7 +1092,10 @@ __global__ void __launch_bounds__(256, 2) wedm_step_fused(const KArgs k) {
                         if (u < cnt) {
                             const float conv = u < split ? conv_lo : conv_hi;
                             const float jfe = u < split ? jfe_lo : jfe_hi;
-                            float tn = interior_cell<true>(tm1, tc, cur[u], g.k, g.tuf, conv, tdiel, ps.adv, jfe, alpha, tref);
+                            float tn;
+                            if (F64) tn = cell_interior(tm1, tc, cur[u], ((u < split ? zone_lo : zone_hi) >> t) & 1u,
+                                                        ((u < split ? joule_lo : joule_hi) >> t) & 1u, cf, ps, jf_lane);
+                            else tn = interior_cell<true>(tm1, tc, cur[u], g.k, g.tuf, conv, tdiel, ps.adv, jfe, alpha, tref);
                             if (!FROZEN || !s.done) col[(j + u) * 256] = tn;
                             const bool inter = (n >= 3) && (im1 + (uint32_t)u <= span);
                             tmax = inter ? fmax_gt(tmax, tn) : tmax;
@@ -1078,11 +1114,11 @@ __global__ void __launch_bounds__(256, 2) wedm_step_fused(const KArgs k) {
                         const float conv = zbit ? ps.conv_zone : ps.conv_base;
                         const float jfe = jbit ? jf_lane : 0.0f;
                         const float tp1 = cur[0];
-                        float tn = interior_cell<true>(tm1, tc, tp1, g.k, g.tuf, conv, tdiel, ps.adv, jfe, alpha, tref);
+                        float tn = F64 ? cell_interior(tm1, tc, tp1, zbit, jbit, cf, ps, jf_lane)
+                                       : interior_cell<true>(tm1, tc, tp1, g.k, g.tuf, conv, tdiel, ps.adv, jfe, alpha, tref);
                         if (!inter && valid) {  // boundary cells and irregular waves: predicated formula
                             const int i = cbase + jj;
-                            tn = (i >= 1) ? stencil_cell(i, n, (i == 1) ? spool : tm1, tc, tp1, g, cf, ps, tref, alpha, tdiel)
-                                          : spool;
+                            tn = (i >= 1) ? cell_full(i, (i == 1) ? spool : tm1, tc, tp1, cf, ps) : spool;
                         }
                         if (valid) {
                             col[jj * 256] = tn;
@@ -1215,9 +1251,9 @@ __global__ void __launch_bounds__(256, 2) wedm_step_stream(const KArgs k) {
     double h64[2] = {0.0, 0.0};  // convection coefficients as loaded; converted after the wire rows are requested
     if (live) {
         if (TRACE) load_env(cold, e, s);  // frozen environments are sampled too: every row
-        else load_env_inputs(cold, e, s, !k.hot.disable_ignition, h64);
+        else load_env_inputs(cold, e, s, !k.hot.disable_ignition, h64, k.hot.done_value == 0);
     } else {
-        s.done = 1; s.unwind = 0.0; s.h_base = 0.0f; s.h_zone = 0.0f;
+        s.done = WEDM_DEAD_LANE; s.unwind = 0.0; s.h_base = 0.0f; s.h_zone = 0.0f;
     }
     // per-lane tile membership, gathered by the host (build_walk): requested with the rest
     const uint32_t zone_lo = wt->chunk_flags[c][0], joule_lo = wt->chunk_flags[c][1];
@@ -1266,7 +1302,7 @@ __global__ void __launch_bounds__(256, 2) wedm_step_stream(const KArgs k) {
     // next-step autoreset (all L lanes of the environment agree)
     const bool reinit = live && s.done && WEDM_AUTORESET_SCALAR(cold);
     if (reinit) reinit_env(cold, e, s, c == 0);
-    s.done &= k.hot.done_value;  // keep_stepping_terminated: the DONE row is `terminated` of the last step and freezes nothing
+    unfreeze_wire(k.hot, s);  // keep_stepping_terminated: the DONE row is `terminated` of the last step and freezes nothing
     const bool frozen0 = s.done;
     double wp0 = 0.0;  // workpiece position at the start of the launch (reward)
     if (WEDM_REWARD_ON_SCALAR(cold) && !frozen0) wp0 = s.wp;
@@ -1274,8 +1310,8 @@ __global__ void __launch_bounds__(256, 2) wedm_step_stream(const KArgs k) {
         const bool in_table = s.mode >= 1 && s.mode <= WEDM_MAX_MODE;
         const double from_table = __shfl(ipk_entry, in_table ? s.mode : 0, 64);  // every lane takes part
         if (!s.done) {
-            s.ipk = from_table;
-            if (!in_table) s.ipk = peak_current(cold, s.mode, e);  // mode None (the module's current cache) or unknown (default_current): cold path
+            s.ipk = s.mode == 0 ? 60.0 : from_table;
+            if (s.mode != 0 && !in_table) s.ipk = peak_current(cold, s.mode, e);  // unknown mode, or None over a stale cache (-1): default_current (cold parameter)
             init_persist<true>(k.hot, cold, e, s, ps);
         }
     }
@@ -1599,6 +1635,7 @@ __device__ __forceinline__ f2 interior2(f2 tm1, f2 tc, f2 tp1, float k, float tu
 // N1) and a chunk's 1- or 2-cell tail computed with the patched cells (virtual chunks of 25 cells: 400 segments over 8 lanes).
 template <int L, bool TRACE, bool FROZEN_OK = false, bool EXTRA = false>
 __global__ void __launch_bounds__(256, 2) wedm_step_packed(const KArgs k) {
+    constexpr bool kFrozenOk = FROZEN_OK;
     const ColdRef cold = kernarg_cold();
     Hot hv = k.hot;
     // the constants of the epilogue and of the quiet prelude: what fits in 256 VGPRs without a
@@ -1628,15 +1665,16 @@ __global__ void __launch_bounds__(256, 2) wedm_step_packed(const KArgs k) {
     Persist ps{0.0f, 0.0f, 0.0f, 0};
     load_geom(k.hot, cold, live ? e : 0, g);
     if (live) load_env(cold, e, s);
-    else { s.done = 1; s.unwind = 0.0; s.h_base = 0.0f; s.h_zone = 0.0f; }
+    else { s.done = WEDM_DEAD_LANE; s.unwind = 0.0; s.h_base = 0.0f; s.h_zone = 0.0f; }
     float* col = lds + tid;
     const bool reinit = live && s.done && WEDM_AUTORESET(cold);  // next-step autoreset (all L lanes of the environment agree)
     if (reinit) {
         reinit_env(cold, e, s, c == 0);
         for (int row = 0; row < R; ++row) col[row * 256] = k.hot.spool;
     }
-    s.done &= k.hot.done_value;  // keep_stepping_terminated: the DONE row is `terminated` of the last step and freezes nothing
+    unfreeze_wire(k.hot, s);  // keep_stepping_terminated: the DONE row is `terminated` of the last step and freezes nothing
     const bool frozen0 = s.done;
+    WEDM_REPORT_FROZEN(frozen0 && live);
     if (!s.done) {
         s.ipk = peak_current(cold, s.mode, e);
         init_persist(k.hot, cold, e, s, ps);
@@ -2015,16 +2053,22 @@ __global__ void __launch_bounds__(256, 2) wedm_step_packed(const KArgs k) {
 #define WEDM_FUSED_LIST(X) WEDM_BOOLS3(X, 1) WEDM_BOOLS3(X, 2) WEDM_BOOLS3(X, 4) WEDM_BOOLS3(X, 8) WEDM_BOOLS3(X, 16)
 #define WEDM_INST_PACKED(L, a, b, c) template __global__ void wedm_step_packed<L, a, b, c>(const KArgs);
 #define WEDM_INST_FUSED(L, a, b, c) template __global__ void wedm_step_fused<L, a, b, c>(const KArgs);
+// stencil_mode 1 on the tile walk: <L, TRACE, FROZEN_OK = true, N1 = false, F64 = true>
+#define WEDM_FUSED_F64_LIST(X) X(1, false) X(1, true) X(2, false) X(2, true) X(4, false) X(4, true) X(8, false) X(8, true) X(16, false) X(16, true)
+#define WEDM_INST_FUSED_F64(L, tr) template __global__ void wedm_step_fused<L, tr, true, false, true>(const KArgs);
+#define WEDM_EXT_FUSED_F64(L, tr) extern template __global__ void wedm_step_fused<L, tr, true, false, true>(const KArgs);
 #define WEDM_EXT_PACKED(L, a, b, c) extern template __global__ void wedm_step_packed<L, a, b, c>(const KArgs);
 #define WEDM_EXT_FUSED(L, a, b, c) extern template __global__ void wedm_step_fused<L, a, b, c>(const KArgs);
 #if defined(WEDM_PART) && WEDM_PART == 1
 WEDM_PACKED_LIST(WEDM_INST_PACKED)
 #elif defined(WEDM_PART) && WEDM_PART == 2
 WEDM_FUSED_LIST(WEDM_INST_FUSED)
+WEDM_FUSED_F64_LIST(WEDM_INST_FUSED_F64)
 #else
 #if defined(WEDM_PART)
 WEDM_PACKED_LIST(WEDM_EXT_PACKED)
 WEDM_FUSED_LIST(WEDM_EXT_FUSED)
+WEDM_FUSED_F64_LIST(WEDM_EXT_FUSED_F64)
 #endif
 
 __global__ void __launch_bounds__(256)
@@ -2065,6 +2109,9 @@ wedm_reset_kernel(const wedm_params p, const wedm_state_ptrs s, int32_t num_envs
         *WEDM_ROW(s.i32, WEDM_I_KEY_LO) = klo;
         *WEDM_ROW(s.i32, WEDM_I_KEY_HI) = khi;
     }
+    // state.current_mode = None: 0, or -1 where the surviving module's current cache names a mode (ignition.py:98-113:
+    // None then resolves through default_current_mode instead of the fresh cache's 60 A)
+    if (keep_modules && *WEDM_ROW(s.i8, WEDM_B_MODE_CACHED)) *WEDM_ROW(s.i32, WEDM_I_CURRENT_MODE) = -1;
     *WEDM_ROW(s.f64, WEDM_F_WORKPIECE_POS) = p.initial_gap;            // wire_edm.py:111
     *WEDM_ROW(s.f64, WEDM_F_TARGET_POS) = p.target_cutting_distance;   // wire_edm.py:112
     *WEDM_ROW(s.f64, WEDM_F_UNWIND_VEL) = 0.2;                         // state.py:55
@@ -2155,10 +2202,12 @@ struct wedm_ctx {
     int64_t trace_us = 0, trace_count = 0;
     std::string err;
     std::string last_kernel;
-    LaunchPlan plans[2][2];            // [single microsecond][trace point]: cached launch decisions
+    LaunchPlan plans[2][2][2];         // [single microsecond][trace point][frozen-lane tile code]: cached launch decisions
+    int32_t* frozen_seen = nullptr;    // pinned host word the kernels set (Cold::frozen_seen), and its device alias
+    int32_t* frozen_seen_dev = nullptr;
     const LaunchPlan* last_plan = nullptr;
     int32_t last_n_sub = 0;
-    void invalidate_plans() { for (auto& a : plans) for (auto& pl : a) pl.valid = false; }
+    void invalidate_plans() { for (auto& a : plans) for (auto& b : a) for (auto& pl : b) pl.valid = false; }
 };
 
 static int32_t fail(wedm_ctx* ctx, int32_t code, const std::string& msg) {
@@ -2267,6 +2316,15 @@ template <bool TR, bool FZ, bool N1> static const void* pick_fused(int L) {
 template <bool TR, bool FZ> static const void* pick_fused(int L, bool n1) {
     return n1 ? pick_fused<TR, FZ, true>(L) : pick_fused<TR, FZ, false>(L);
 }
+template <bool TR> static const void* pick_fused_f64(int L) {
+    switch (L) {
+        case 1: return (const void*)wedm_step_fused<1, TR, true, false, true>;
+        case 2: return (const void*)wedm_step_fused<2, TR, true, false, true>;
+        case 4: return (const void*)wedm_step_fused<4, TR, true, false, true>;
+        case 8: return (const void*)wedm_step_fused<8, TR, true, false, true>;
+        default: return (const void*)wedm_step_fused<16, TR, true, false, true>;
+    }
+}
 // rows a lane of the stream kernel holds in registers: 64 (128 segments over 2 lanes, 400 over 8) or 104 (400 over 4)
 template <bool TR, int CMAX> static const void* pick_stream(int L) {
     switch (L) {
@@ -2307,7 +2365,7 @@ static int lanes_index(int L) { return L == 1 ? 0 : L == 2 ? 1 : L == 4 ? 2 : L 
 // What wedm_step launches for (single microsecond?, trace point?) under the handle's current settings: decided once
 // and cached (the decision walks a cost model over five lane counts; on the one-launch-per-microsecond path that and
 // a hipFuncSetAttribute per call were a measurable part of the host time per launch).
-static int32_t plan_launch(wedm_ctx* ctx, bool single, bool tr, LaunchPlan& out) {
+static int32_t plan_launch(wedm_ctx* ctx, bool single, bool tr, bool frozen_ok, LaunchPlan& out) {
     const wedm_params& P = ctx->p;
     // kernel 3 (one chunk per lane) and kernel 4 (two packed chunks per lane, table of 2L chunks).
     // Auto-selection by a small cost model fitted to measurements:
@@ -2400,11 +2458,11 @@ static int32_t plan_launch(wedm_ctx* ctx, bool single, bool tr, LaunchPlan& out)
     }
     const bool f64 = P.stencil_mode != 0;
     if (f64) {
-        // Numba's typing of the stencil exists in the predicated kernels only (any geometry): LDS-staged when
-        // a chunk fits, else in place in global memory
-        if (variant != 0 && variant != 1 && variant != 2)
-            return fail(ctx, WEDM_ERR_UNSUPPORTED, "wedm_step: stencil_mode 1 (float64 stencil expressions) runs on kernels 1 and 2 only");
-        if (variant == 0) variant = lanes_ok ? 2 : 1;
+        // Numba's typing of the stencil: the fused tile walk (uniform geometry), the predicated LDS kernel (any geometry),
+        // or in place in global memory; no packed form, no single-microsecond kernels
+        if (variant != 0 && variant != 1 && variant != 2 && variant != 3)
+            return fail(ctx, WEDM_ERR_UNSUPPORTED, "wedm_step: stencil_mode 1 (float64 stencil expressions) runs on kernels 1, 2 and 3 only");
+        if (variant == 0) variant = (!single && fused_ok) ? 3 : (lanes_ok ? 2 : 1);
     }
     if (variant == 0) {
         // single-microsecond launches: the stream kernel where one round of blocks covers the batch with chunks of
@@ -2456,20 +2514,23 @@ static int32_t plan_launch(wedm_ctx* ctx, bool single, bool tr, LaunchPlan& out)
         grid = (ctx->num_envs + 256 / planes - 1) / (256 / planes);
         fl = (2 * (size_t)ctx->walk_C[pli] + 2) * 1024;
         out.walk = ctx->walk_dev + pli;
-        // handles with in-launch autoreset expect terminations: the instantiation that tolerates frozen lanes
+        // handles with in-launch autoreset expect terminations, and so do handles whose kernels have reported a frozen
+        // environment (wedm_ctx::frozen_seen): the instantiation that tolerates frozen lanes
         // tables with a one-change boundary tile or a 1- / 2-cell tail: the instantiation that handles them
         const bool extra = ((ctx->walk_n1z >> pli) & 1u) || ((ctx->walk_C[pli] > 8) && (ctx->walk_C[pli] & 7) >= 1 && (ctx->walk_C[pli] & 7) <= 2);
-        fn = P.autoreset ? (tr ? pick_packed<true, true>(planes, extra) : pick_packed<false, true>(planes, extra))
-                         : (tr ? pick_packed<true, false>(planes, extra) : pick_packed<false, false>(planes, extra));
-        std::snprintf(out.name, sizeof(out.name), "wedm_step_packed<%d><<<%d,256,%zuB>>>", planes, grid, fl);
+        fn = frozen_ok ? (tr ? pick_packed<true, true>(planes, extra) : pick_packed<false, true>(planes, extra))
+                       : (tr ? pick_packed<true, false>(planes, extra) : pick_packed<false, false>(planes, extra));
+        std::snprintf(out.name, sizeof(out.name), "wedm_step_packed<%d>%s<<<%d,256,%zuB>>>", planes, frozen_ok ? "[frozen lanes ok]" : "", grid, fl);
     } else {
         grid = (ctx->num_envs + 256 / lanes - 1) / (256 / lanes);
         fl = ((size_t)ctx->walk_C[li] + 1) * 1024;
         out.walk = ctx->walk_dev + li;
         const bool n1 = (ctx->walk_n1z >> li) & 1u;  // the table has a one-change tile that is a boundary tile in every microsecond
-        fn = P.autoreset ? (tr ? pick_fused<true, true>(lanes, n1) : pick_fused<false, true>(lanes, n1))
-                         : (tr ? pick_fused<true, false>(lanes, n1) : pick_fused<false, false>(lanes, n1));
-        std::snprintf(out.name, sizeof(out.name), "wedm_step_fused<%d><<<%d,256,%zuB>>>", lanes, grid, fl);
+        fn = f64 ? (tr ? pick_fused_f64<true>(lanes) : pick_fused_f64<false>(lanes))
+           : frozen_ok ? (tr ? pick_fused<true, true>(lanes, n1) : pick_fused<false, true>(lanes, n1))
+                       : (tr ? pick_fused<true, false>(lanes, n1) : pick_fused<false, false>(lanes, n1));
+        std::snprintf(out.name, sizeof(out.name), "wedm_step_fused<%d>%s<<<%d,256,%zuB>>>", lanes,
+                      f64 ? "[f64 stencil]" : frozen_ok ? "[frozen lanes ok]" : "", grid, fl);
     }
     if (fl) {
         // The attribute belongs to the kernel FUNCTION, not to this handle or plan: two live handles with different wire
@@ -2601,12 +2662,24 @@ int32_t wedm_create(const wedm_params* params, int32_t num_envs, int32_t n_seg_m
             return WEDM_ERR_HIP;
         }
     }
+    // (optional: without it every handle without autoreset simply keeps the instantiation without the frozen-lane code)
+    if (hipHostMalloc((void**)&ctx->frozen_seen, sizeof(int32_t), hipHostMallocMapped) == hipSuccess) {
+        *ctx->frozen_seen = 0;
+        if (hipHostGetDevicePointer((void**)&ctx->frozen_seen_dev, ctx->frozen_seen, 0) != hipSuccess) {
+            (void)hipHostFree(ctx->frozen_seen);
+            ctx->frozen_seen = ctx->frozen_seen_dev = nullptr;
+        }
+    } else {
+        (void)hipGetLastError();
+        ctx->frozen_seen = nullptr;
+    }
     *out = ctx;
     return WEDM_OK;
 }
 
 int32_t wedm_destroy(wedm_ctx* ctx) {
     if (!ctx) return WEDM_ERR_BAD_ARG;
+    if (ctx->frozen_seen) (void)hipHostFree(ctx->frozen_seen);
     if (ctx->tables_dev) (void)hipFree(ctx->tables_dev);
     if (ctx->walk_dev) (void)hipFree(ctx->walk_dev);
     if (ctx->params_dev) (void)hipFree(ctx->params_dev);
@@ -2710,6 +2783,7 @@ int32_t wedm_reset(wedm_ctx* ctx, const uint8_t* mask, uint64_t seed, int32_t re
                        ctx->num_envs, ctx->n_seg_max, mask, (uint32_t)seed, (uint32_t)(seed >> 32), reseed);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return hip_fail(ctx, e, "wedm_reset launch");
+    if (!mask && ctx->frozen_seen) *(volatile int32_t*)ctx->frozen_seen = 0;  // every environment reset: none is frozen
     return WEDM_OK;
 }
 
@@ -2755,6 +2829,7 @@ int32_t wedm_step(wedm_ctx* ctx, int32_t n_substeps, const wedm_action_ptrs* act
     k.cold.tb = ctx->tb;
     k.cold.replay = ctx->replay;
     k.cold.replay_steps = ctx->replay_steps;
+    k.cold.frozen_seen = ctx->frozen_seen_dev;
     k.num_envs = ctx->num_envs;
     k.n_substeps = n_substeps;
     k.n_seg_max = ctx->n_seg_max;
@@ -2770,9 +2845,12 @@ int32_t wedm_step(wedm_ctx* ctx, int32_t n_substeps, const wedm_action_ptrs* act
     }
 
     const bool tr = ctx->trace_on && k.trace_next < n_substeps;  // a sample falls into this launch
-    LaunchPlan& plan = ctx->plans[n_substeps <= 1 ? 1 : 0][tr ? 1 : 0];
+    // frozen-lane tile code: handles with in-launch autoreset, and any handle one of whose launches has found a terminated
+    // environment (the kernels set the host-visible word; a plain read, no synchronisation: a launch or two late at worst)
+    const bool frozen_ok = P.autoreset || (ctx->frozen_seen && *(volatile int32_t*)ctx->frozen_seen != 0);
+    LaunchPlan& plan = ctx->plans[n_substeps <= 1 ? 1 : 0][tr ? 1 : 0][frozen_ok ? 1 : 0];
     if (!plan.valid) {
-        if (int32_t rc = plan_launch(ctx, n_substeps <= 1, tr, plan)) return rc;
+        if (int32_t rc = plan_launch(ctx, n_substeps <= 1, tr, frozen_ok, plan)) return rc;
     }
     k.walk = plan.walk;
     void* kargs[] = {(void*)&k};
