@@ -218,12 +218,14 @@ def roofline_block(kernel_name, kernel_ms, n_envs, n_sub, n_seg, traffic_overrid
             # f64 instructions hold it twice as long as the 2-cycle f32 instruction the issue peak assumes);
             # SQ_WAVE_CYCLES counts the quad-cycles the launch's waves were resident.  Both from the SAME counter pass,
             # so their ratio is the pipe occupancy at the clock the chip really ran at, whatever that was.
-            waves_per_simd = max(1.0, valu["sq_waves"] / 1024.0)
-            simd_cycles = valu["sq_wave_cycles"] / waves_per_simd            # quad-cycles a SIMD was occupied by the launch
+            # waves RESIDENT per SIMD: every step kernel is built for at most 2 blocks of 4 waves per CU, and a launch with
+            # more waves than that runs them in rounds
+            resident = min(max(1.0, valu["sq_waves"] / 1024.0), 2.0)
+            simd_cycles = valu["sq_wave_cycles"] / resident                  # quad-cycles a SIMD was occupied by the launch
             scale = env_steps / valu["env_steps_per_launch"]
             out["valu_pipe_busy"] = {
                 "frac": valu["sq_active_inst_valu"] / simd_cycles,
-                "measured_clock_GHz": valu["sq_wave_cycles"] * scale * 4.0 / valu["sq_waves"] / t / 1e9,
+                "measured_clock_GHz": valu["sq_wave_cycles"] * scale * 4.0 / (1024.0 * resident) / t / 1e9,
                 "note": "SQ_ACTIVE_INST_VALU / (SQ_WAVE_CYCLES / resident waves per SIMD), one counter pass; the clock is "
                         "SQ_WAVE_CYCLES x 4 / waves / the live kernel duration (the 2.4 GHz of the issue peak is the "
                         "data-sheet maximum, under this load the chip runs lower)"}
@@ -446,6 +448,8 @@ def main():
     kernel_ms = sum(s.elapsed_time(e) for s, e in zip(starts, ends)) / args.steps
 
     done = int(env.state.done.sum().item())
+    broken = int(env.state.is_wire_broken.sum().item())
+    reached = int(env.state.is_target_distance_reached.sum().item())
     sparks = int(env.state.spark_count.sum().item())
     if rank == 0:
         total_env_steps = world * n_local * n_sub * args.steps
@@ -470,7 +474,12 @@ def main():
                 **({"initial_gap_um": args.gap} if args.gap is not None else {}),
             },
             "roofline": roofline_block(kname, kernel_ms, n_local, n_sub, S, args.traffic),
-            "check": {"envs_done": done, "sparks": sparks},
+            "check": {"envs_done": done, "envs_wire_broken": broken, "envs_target_reached": reached, "sparks": sparks,
+                      **({"note": "per-environment draws that pair the thinnest wires (0.10 mm) with the highest current modes "
+                                  "overheat the wire (Tmax > breaking temperature, wire.py:376-388) within the window: the "
+                                  "physics of those draws, not a bench artefact; such an environment is frozen from then on "
+                                  "and still counted in `value` (the kernel carries its lanes)"}
+                         if args.workload == "config5" and done else {})},
         }
         if world == 1 and not args.no_side and args.workload == "config3" and args.trace == "off" and args.gap is None \
                 and not args.num_envs and args.kernel == 0:

@@ -477,6 +477,83 @@ __device__ __forceinline__ void load_env_inputs(const ColdRef cold, int64_t e, E
     v.ipk = 0.0;
 }
 
+// ---- the same inputs with HALF the load instructions (stream kernel, an even number of lanes per environment): the
+// vector-memory front end of a CU handles one load instruction in ~16-18 cycles whatever it fetches, all 8 waves of the CU
+// queue their requests at the same moment, and ~45 of a wave's ~67 loads are state rows that both lanes of an
+// environment fetch redundantly.  Here the even lane of a pair loads row A and the odd lane row B IN ONE INSTRUCTION, and
+// the two swap through DPP once the data are there (quad_perm [1,0,3,2]: no LDS, no wait counter).
+__device__ __forceinline__ int32_t swap_with_neighbour(int32_t x) { return __builtin_amdgcn_update_dpp(0, x, 0xB1, 0xF, 0xF, false); }
+__device__ __forceinline__ double swap_with_neighbour(double x) {
+    const uint64_t u = d2bits(x);
+    const uint32_t lo = (uint32_t)swap_with_neighbour((int32_t)(uint32_t)u), hi = (uint32_t)swap_with_neighbour((int32_t)(uint32_t)(u >> 32));
+    return bits2d(((uint64_t)hi << 32) | lo);
+}
+struct PairRaw { double f[11]; int32_t i[7]; int32_t b[3]; double cur; int32_t shrt; };  // a lane's own row of every pair, as loaded
+
+#define WEDM_PAIR_F64(X) X(0, WEDM_F_WORKPIECE_POS, WEDM_F_WIRE_POS) X(1, WEDM_F_WIRE_VEL, WEDM_F_PREV_ACCEL) \
+    X(2, WEDM_F_DEBRIS_VOLUME, WEDM_F_DEBRIS_DENSITY) X(3, WEDM_F_FLOW, WEDM_F_LAST_GAP) X(4, WEDM_F_LAST_DENSITY, WEDM_F_WIRE_LAST_FLOW) \
+    X(5, WEDM_F_VOLTAGE, WEDM_F_SPARK_Y) X(6, WEDM_F_TARGET_DELTA, WEDM_F_TARGET_VOLTAGE) X(7, WEDM_F_ON_TIME, WEDM_F_OFF_TIME) \
+    X(8, WEDM_F_TARGET_POS, WEDM_F_UNWIND_VEL) X(9, WEDM_F_VOLT_ACC, WEDM_F_H_BASE) X(10, WEDM_F_H_ZONE, WEDM_F_TMAX)
+#define WEDM_PAIR_I32(X) X(0, WEDM_I_TIME, WEDM_I_SINCE_SERVO) X(1, WEDM_I_SINCE_OPEN_V, WEDM_I_SINCE_IGNITION) \
+    X(2, WEDM_I_SINCE_SPARK_END, WEDM_I_SPARK_DUR) X(3, WEDM_I_RANDOM_SHORT_REM, WEDM_I_DEBRIS_SHORT_REM) \
+    X(4, WEDM_I_TIME_CRITICAL, WEDM_I_CURRENT_MODE) X(5, WEDM_I_EPISODE, WEDM_I_KEY_LO) X(6, WEDM_I_KEY_HI, WEDM_I_SPARK_COUNT)
+#define WEDM_PAIR_I8(X) X(0, WEDM_B_SPARK_STATE, WEDM_B_WIRE_BROKEN) X(1, WEDM_B_TARGET_REACHED, WEDM_B_DONE) X(2, WEDM_B_ERROR, WEDM_B_ERROR)
+
+// requests: 21 loads (+ 2 when the caller forces the spark) instead of 40
+__device__ __forceinline__ void load_env_inputs_paired_issue(const ColdRef cold, int64_t e, bool odd, bool ignition_on, PairRaw& r) {
+    const ColdPtr c = cold.get();
+    const int64_t stride = c->s.stride;
+    const struct { const double* f64; const int32_t* i32; const int8_t* i8; } s{c->s.f64, c->s.i32, c->s.i8};
+#define WEDM_LD(k, A, B) r.f[k] = s.f64[(int64_t)(odd ? (int)(B) : (int)(A)) * stride + e];
+    WEDM_PAIR_F64(WEDM_LD)
+#undef WEDM_LD
+#define WEDM_LD(k, A, B) r.i[k] = s.i32[(int64_t)(odd ? (int)(B) : (int)(A)) * stride + e];
+    WEDM_PAIR_I32(WEDM_LD)
+#undef WEDM_LD
+#define WEDM_LD(k, A, B) r.b[k] = s.i8[(int64_t)(odd ? (int)(B) : (int)(A)) * stride + e];
+    WEDM_PAIR_I8(WEDM_LD)
+#undef WEDM_LD
+    r.cur = 0.0; r.shrt = 0;
+    if (!ignition_on) {  // the caller forces the spark (single_spark_animation.py): current and the short flag are inputs then
+        r.cur = *WEDM_ROW(s.f64, WEDM_F_CURRENT);
+        r.shrt = *WEDM_ROW(s.i8, WEDM_B_IS_SHORT);
+    }
+}
+
+// the wait for those loads, where the caller wants it (see env_loaded_here)
+__device__ __forceinline__ void pair_raw_loaded_here(PairRaw& r) {
+#pragma unroll
+    for (int k = 0; k < 11; ++k) asm volatile("" : "+v"(r.f[k]));
+#pragma unroll
+    for (int k = 0; k < 7; ++k) asm volatile("" : "+v"(r.i[k]));
+#pragma unroll
+    for (int k = 0; k < 3; ++k) asm volatile("" : "+v"(r.b[k]));
+    asm volatile("" : "+v"(r.cur), "+v"(r.shrt));
+}
+
+// the swap: every lane ends up with both rows of every pair (what load_env_inputs would have loaded)
+__device__ __forceinline__ void load_env_inputs_paired_finish(const PairRaw& r, bool odd, Env& v, bool keep_stepping, double* h64) {
+    double fa[11], fb[11];
+    int32_t ia[7], ib[7], ba[3], bb[3];
+#pragma unroll
+    for (int k = 0; k < 11; ++k) { const double o = swap_with_neighbour(r.f[k]); fa[k] = odd ? o : r.f[k]; fb[k] = odd ? r.f[k] : o; }
+#pragma unroll
+    for (int k = 0; k < 7; ++k) { const int32_t o = swap_with_neighbour(r.i[k]); ia[k] = odd ? o : r.i[k]; ib[k] = odd ? r.i[k] : o; }
+#pragma unroll
+    for (int k = 0; k < 3; ++k) { const int32_t o = swap_with_neighbour(r.b[k]); ba[k] = odd ? o : r.b[k]; bb[k] = odd ? r.b[k] : o; }
+    v.wp = fa[0]; v.x = fb[0]; v.v = fa[1]; v.prev_a = fb[1]; v.debris = fa[2]; v.rho = fb[2]; v.flow = fa[3]; v.last_gap = fb[3];
+    v.last_rho = fa[4]; v.wire_last_flow = fb[4]; v.V = fa[5]; v.y = fb[5]; v.tdelta = fa[6]; v.tvolt = fb[6]; v.on = fa[7]; v.off = fb[7];
+    v.tpos = fa[8]; v.unwind = fb[8]; v.vacc = fa[9];
+    h64[0] = fb[9]; h64[1] = fa[10]; v.h_base = 0.0f; v.h_zone = 0.0f;
+    v.tmax = keep_stepping ? (float)fb[10] : 0.0f;   // (an input only where a broken wire is stepped on: load_env_inputs)
+    v.time = ia[0]; v.tss = ib[0]; v.tsov = ia[1]; v.tsi = ib[1]; v.tse = ia[2]; v.dur = ib[2]; v.rnd_rem = ia[3]; v.deb_rem = ib[3];
+    v.tcrit = ia[4]; v.mode = ib[4]; v.episode = ia[5]; v.key0 = (uint32_t)ib[5]; v.key1 = (uint32_t)ia[6]; v.sparks = ib[6];
+    v.state = ba[0]; v.broken = bb[0]; v.reached = ba[1]; v.done = bb[1]; v.err = ba[2];
+    v.I = r.cur; v.is_short = r.shrt;
+    v.last_crater = 0.0; v.cavity = 0.0; v.ctrl = 0;
+    v.ipk = 0.0;
+}
+
 // Rows that are final once the scalar prelude has run (stored while the wire is being walked).
 // `quiet_only`: every step of the launch took quiet_prelude() for the whole wave, which never assigns the
 // second group (workpiece position, dielectric / convection caches, latched action, short timers,
@@ -648,10 +725,30 @@ __device__ __forceinline__ void load_geom(const Hot& hot, const ColdRef cold, in
     }
 }
 
+// The cold parameter block as scalar_prelude reads it: through the laundered GENERIC pointer (vector `flat_load`s: what
+// the fused kernels measured fastest, see opaque_const) or, SCOLD, through the constant address space (scalar loads).
+// The single-microsecond stream kernel needs the second: vector loads return in order, and its general prelude runs
+// while the lane's whole wire is still in flight -- a flat load issued there comes back only after every wire word.
+template <bool SCOLD> struct ColdParams;
+template <> struct ColdParams<false> {
+    typedef const wedm_params* type;
+    static __device__ __forceinline__ type get(const wedm_params* p) { return opaque(p); }
+};
+template <> struct ColdParams<true> {
+    typedef const WEDM_AS4 wedm_params* type;
+    static __device__ __forceinline__ type get(const wedm_params* p) { return opaque_const(p); }
+};
+
+// Entry `lane` of the per-mode crater tables in lane `lane` (the stream kernel requests them with its very first loads,
+// like the peak-current table): a lookup is then a cross-lane read instead of a vector load queued behind the wire.
+struct LaneTables { double mean, sd, depth; int32_t valid; };
+
 // wire.py:349-374: h_eff * A products the stencil uses (float32 x float32, wire.py:109)
+template <bool SCOLD = false>
 __device__ __forceinline__ void refresh_convection(const Hot& hot, const ColdRef cold, int64_t e, const Env& s,
                                                    Persist& ps) {
-    const float A = (float)WEDM_COLD_GEOM_F64(cold, hot, WEDM_G_A_SURF, a_surf);
+    const float A = (float)(hot.per_env_geometry ? cold->g.f64[(int64_t)WEDM_G_A_SURF * cold->s.stride + e]
+                                                 : ColdParams<SCOLD>::get(cold->p)->a_surf);
     ps.conv_base = s.h_base * A;
     ps.conv_zone = s.h_zone * A;
 }
@@ -708,16 +805,19 @@ struct QuietTry {  // what a failed quiet_prelude() hands on: the step's Philox 
 
 // REPLAY: the variates come from the caller's table (wedm_bind_rng_replay) instead of Philox — the reference's own
 // draws, so that a native-seed run of the reference can be followed on the device (validation mode, global kernel).
-template <bool REPLAY = false>
+// SCOLD / lt: the single-microsecond stream kernel's flavour -- cold parameters by scalar loads, crater tables from the
+// lanes' registers (ColdParams, LaneTables): no vector load on the path a fresh spark takes.
+template <bool REPLAY = false, bool SCOLD = false>
 __device__ __forceinline__ Coef scalar_prelude(const Hot& p, const ColdRef cold, const Geom& g, int64_t e,
                                                uint32_t gid, Env& s, Persist& ps, bool writer,
-                                               const QuietTry& qt = QuietTry{W4{0u, 0u, 0u, 0u}, false}) {
+                                               const QuietTry& qt = QuietTry{W4{0u, 0u, 0u, 0u}, false},
+                                               const LaneTables* lt = nullptr, const LaneTables* lt1 = nullptr) {
     double rv[WEDM_REPLAY_SLOTS] = {0.0, 0.0, 0.0, 0.0, 0.0};
     // The cold parameter block and the pointer block, fetched ONCE per call (laundered: nothing read through them can
     // be hoisted out of the microsecond loop).  Every rare branch below used to launder its own copy: two dependent
     // scalar loads (kernel-argument segment, then the field) and a wait at each of ~15 sites of a fresh-spark step.
     const ColdPtr cc0 = cold.get();
-    const ParamsPtr c0 = opaque(cc0->p);
+    const typename ColdParams<SCOLD>::type c0 = ColdParams<SCOLD>::get(cc0->p);
     // the uniform constants of the rare branches, requested in one batch (scalar loads: one wait at the first use)
     const double seg = c0->segment_len, eff = c0->plasma_efficiency, rho_elec = c0->rho_elec, jg_u = c0->joule_geom;
     const double h_u = c0->workpiece_height, kerf_u = c0->kerf_base;
@@ -770,7 +870,7 @@ __device__ __forceinline__ Coef scalar_prelude(const Hot& p, const ColdRef cold,
         if (!timers && !hard && ex <= (REPLAY ? 500.0 : 24.0) && ex >= -500) p_d = 1.0 / (1.0 + portable_exp(ex));
         double p_r = 0.0;
         if (p.has_random_short) {  // ignition.py:221-230; max_probability == 0 by default
-            const ParamsPtr c = c0;
+            const auto c = c0;
             if (gap >= c->random_short_max_gap) p_r = 0.0;
             else if (gap <= c->random_short_min_gap) p_r = c->random_short_max_probability;
             else
@@ -795,7 +895,7 @@ __device__ __forceinline__ Coef scalar_prelude(const Hot& p, const ColdRef cold,
             new_r = !timers && !new_d && ((REPLAY ? rv[WEDM_RS_RANDOM_ROLL] : u32_to_unit(w.y)) < p_r);
         }
         if (new_d || new_r) {  // rare: a short begins (durations are cold parameters)
-            const ParamsPtr c = c0;
+            const auto c = c0;
             if (new_d) s.deb_rem = c->debris_short_duration;
             else s.rnd_rem = c->random_short_duration;
         }
@@ -842,6 +942,10 @@ __device__ __forceinline__ Coef scalar_prelude(const Hot& p, const ColdRef cold,
     }  // !disable_ignition
     const bool fresh = (s.state == 1) && (s.dur == 0);  // material.py:83, dielectric.py:95
 
+    // `lt` / `lt1` (stream kernel): the crater-table entries of this lane's mode AS IT WAS BEFORE THIS STEP and of mode I1,
+    // looked up by the caller across lanes; a step that latches a new mode reads the tables in memory
+    const bool use_lt = lt != nullptr && !__any(s.ctrl != 0);
+
     // ---- material removal (material.py:79-174)
     if (fresh) {
         const ColdPtr cc = cc0;
@@ -851,8 +955,9 @@ __device__ __forceinline__ Coef scalar_prelude(const Hot& p, const ColdRef cold,
         if (!in_range) m = 1;
         // everything this branch reads from memory is requested here, before the crater normal (~230 instructions
         // with no memory access) is computed: one latency instead of a chain of them
-        const int32_t valid = tb.crater_valid[m];
-        double mean = tb.crater_mean[m], sd = tb.crater_std[m], depth = tb.crater_depth[m];
+        const int32_t valid = use_lt ? lt->valid : tb.crater_valid[m];
+        double mean = use_lt ? lt->mean : tb.crater_mean[m], sd = use_lt ? lt->sd : tb.crater_std[m],
+               depth = use_lt ? lt->depth : tb.crater_depth[m];
         const double kerf_base = p.per_env_geometry ? cc0->g.f64[(int64_t)WEDM_G_KERF_BASE * cc0->s.stride + e] : kerf_u;
         const double h = p.per_env_geometry ? cc0->g.f64[(int64_t)WEDM_G_HEIGHT * cc0->s.stride + e] : h_u;
         double* const clog = cc->s.crater_log;
@@ -860,7 +965,8 @@ __device__ __forceinline__ Coef scalar_prelude(const Hot& p, const ColdRef cold,
         double* const stats = cc->s.stats;
         if (!in_range || !valid) {  // unknown mode (the reference raises ValueError, material.py:108-113)
             s.err = 1;
-            mean = tb.crater_mean[1]; sd = tb.crater_std[1]; depth = tb.crater_depth[1];
+            if (use_lt) { mean = lt1->mean; sd = lt1->sd; depth = lt1->depth; }
+            else { mean = tb.crater_mean[1]; sd = tb.crater_std[1]; depth = tb.crater_depth[1]; }
         }
         double vol;
         if (REPLAY) {
@@ -922,7 +1028,7 @@ __device__ __forceinline__ Coef scalar_prelude(const Hot& p, const ColdRef cold,
     {
         const double I = s.I, I2 = I * I;
         if (__builtin_fabs(s.flow - s.wire_last_flow) > 0.01) {
-            const ParamsPtr c = c0;
+            const auto c = c0;
             double ve = c->convection_velocity_factor * s.unwind;
             ve = ve > -0.9 ? ve : -0.9;
             double hb = c->base_convection * (1.0 + ve);
@@ -932,7 +1038,7 @@ __device__ __forceinline__ Coef scalar_prelude(const Hot& p, const ColdRef cold,
             s.h_base = (float)hb;
             s.h_zone = (float)he;
             s.wire_last_flow = s.flow;
-            refresh_convection(p, cold, e, s, ps);
+            refresh_convection<SCOLD>(p, cold, e, s, ps);
         }
         cf.pidx = -1;
         cf.q = 0.0f;

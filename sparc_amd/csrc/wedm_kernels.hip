@@ -53,6 +53,19 @@ using namespace wedm;
 #ifndef WEDM_FUSED_DENSE
 #define WEDM_FUSED_DENSE false
 #endif
+// the fused kernel's N1 instantiation requests a tile's LDS rows one tile ahead (see PREFETCH there)
+#ifndef WEDM_FUSED_MIN_BLOCKS
+#define WEDM_FUSED_MIN_BLOCKS 2
+#endif
+#ifndef WEDM_PACKED_MIN_BLOCKS
+#define WEDM_PACKED_MIN_BLOCKS 2
+#endif
+#ifndef WEDM_STREAM_PAIRED_LOADS
+#define WEDM_STREAM_PAIRED_LOADS 1
+#endif
+#ifndef WEDM_PREFETCH_N1
+#define WEDM_PREFETCH_N1 0
+#endif
 
 // Wave-uniform description of one step's walk over a chunk of C cells (see build_walk()).
 // Cell j of chunk c is wire segment i = c*C + j.  The chunk is walked in ceil(C/8) tiles of 8
@@ -824,8 +837,10 @@ __device__ __forceinline__ float interior_cell(float tm1, float tc, float tp1, f
 // store), on the tile walk: every tile takes the boundary-tile code (per-cell coefficients, interior formula, end cells
 // patched), which is exact for regular tiles too; no stage-major / packed form.  Instantiated with FROZEN_OK only.
 template <int L, bool TRACE, bool FROZEN_OK = false, bool N1 = false, bool F64 = false>
-__global__ void __launch_bounds__(256, 2) wedm_step_fused(const KArgs k) {
+__global__ void __launch_bounds__(256, WEDM_FUSED_MIN_BLOCKS) wedm_step_fused(const KArgs k) {
     constexpr bool kFrozenOk = FROZEN_OK;
+    // (the N1 instantiation serves small batches with one wave per SIMD: 4 096 x 400 over 16 lanes)
+    constexpr bool PREFETCH = N1 && !F64 && WEDM_PREFETCH_N1;
     const ColdRef cold = kernarg_cold();
     Hot hv = k.hot;
     pin_hot_in_vgprs(hv);  // 178 -> 225 VGPRs, SGPR spill traffic in the loop 111 -> 37 instructions: +8 %
@@ -1016,8 +1031,11 @@ __global__ void __launch_bounds__(256, 2) wedm_step_fused(const KArgs k) {
             auto tile = [&](auto frozen, int t, float (&cur)[8], float (&nxt)[8]) {
                 constexpr bool FROZEN = decltype(frozen)::value;  // the copy for a wave with frozen lanes: they do not store
                 const int j = 8 * t;
-                (void)nxt;
-                load8(std::true_type{}, cur, j);  // (an unclamped variant for full tiles pays in the packed kernel only)
+                // PREFETCH (a lone wave per SIMD: nothing else hides the LDS round trip): the NEXT tile's eight rows are
+                // requested before this tile is computed -- rows this tile does not store (it stores j .. j + 7, they are
+                // j + 9 .. j + 16), so they are still the old values the explicit scheme needs
+                if (PREFETCH) { if (t + 1 < n_walk) load8(std::true_type{}, nxt, j + 8); }
+                else load8(std::true_type{}, cur, j);  // (an unclamped variant for full tiles pays in the packed kernel only)
                 const float conv_lo = ((zone_lo >> t) & 1u) ? ps.conv_zone : ps.conv_base;
                 const float jfe_lo = ((joule_lo >> t) & 1u) ? jf_lane : 0.0f;
 #ifdef WEDM_STAMPS_TILES
@@ -1140,7 +1158,21 @@ __global__ void __launch_bounds__(256, 2) wedm_step_fused(const KArgs k) {
 #endif
             };
             float bufA[8];
-            if (!FROZEN_OK || !frozen_wave) {
+            if (PREFETCH) {
+                float bufB[8];
+                load8(std::true_type{}, bufA, 0);
+                if (!FROZEN_OK || !frozen_wave) {
+                    for (int t = 0; t < n_walk; t += 2) {
+                        tile(std::false_type{}, t, bufA, bufB);
+                        if (t + 1 < n_walk) tile(std::false_type{}, t + 1, bufB, bufA);
+                    }
+                } else {
+                    for (int t = 0; t < n_walk; t += 2) {
+                        tile(std::true_type{}, t, bufA, bufB);
+                        if (t + 1 < n_walk) tile(std::true_type{}, t + 1, bufB, bufA);
+                    }
+                }
+            } else if (!FROZEN_OK || !frozen_wave) {
                 for (int t = 0; t < n_walk; ++t) tile(std::false_type{}, t, bufA, bufA);
             } else {
                 for (int t = 0; t < n_walk; ++t) tile(std::true_type{}, t, bufA, bufA);
@@ -1241,7 +1273,10 @@ __global__ void __launch_bounds__(256, 2) wedm_step_stream(const KArgs k) {
     // the lookup by the latched mode further down is a cross-lane read of a register that arrived long ago instead of a
     // load queued behind the whole wire (vector loads return in order: the first prelude would wait for every row)
     WEDM_S2_STAMP(10);  // kernel arguments here
-    const double ipk_entry = cold->tb.mode_current[(tid & 63) <= WEDM_MAX_MODE ? (tid & 63) : WEDM_MAX_MODE];
+    const int tab_i = (tid & 63) <= WEDM_MAX_MODE ? (tid & 63) : WEDM_MAX_MODE;
+    const double ipk_entry = cold->tb.mode_current[tab_i];
+    // (the same for the crater tables a fresh spark looks up: material.py:98-138)
+    const LaneTables ltab{cold->tb.crater_mean[tab_i], cold->tb.crater_std[tab_i], cold->tb.crater_depth[tab_i], cold->tb.crater_valid[tab_i]};
     // (1) the state rows a microsecond reads: requested first, so that the first prelude runs while the wire is in flight
     Env s;
     Geom g;
@@ -1249,8 +1284,12 @@ __global__ void __launch_bounds__(256, 2) wedm_step_stream(const KArgs k) {
     load_geom(k.hot, cold, live ? e : 0, g);
     WEDM_S2_STAMP(11);  // geometry constants here (two dependent scalar loads)
     double h64[2] = {0.0, 0.0};  // convection coefficients as loaded; converted after the wire rows are requested
+    // with an even number of lanes per environment the two lanes of a pair each request ONE row of a pair of rows
+    constexpr bool PAIRED = !TRACE && (L % 2 == 0) && WEDM_STREAM_PAIRED_LOADS;
+    PairRaw raw;
     if (live) {
         if (TRACE) load_env(cold, e, s);  // frozen environments are sampled too: every row
+        else if (PAIRED) load_env_inputs_paired_issue(cold, e, (c & 1) != 0, !k.hot.disable_ignition, raw);
         else load_env_inputs(cold, e, s, !k.hot.disable_ignition, h64, k.hot.done_value == 0);
     } else {
         s.done = WEDM_DEAD_LANE; s.unwind = 0.0; s.h_base = 0.0f; s.h_zone = 0.0f;
@@ -1274,8 +1313,8 @@ __global__ void __launch_bounds__(256, 2) wedm_step_stream(const KArgs k) {
     // short round trip (the state alone is back within ~1.5 us) and puts the first prelude, the general one of an
     // igniting wave included, underneath the arrival of the wire.
     if (!TRACE) {
-        env_loaded_here(s);
-        asm volatile("" : "+v"(h64[0]), "+v"(h64[1]));
+        if (PAIRED) { pair_raw_loaded_here(raw); }
+        else { env_loaded_here(s); asm volatile("" : "+v"(h64[0]), "+v"(h64[1])); }
         __builtin_amdgcn_sched_barrier(0);
     }
 #endif
@@ -1297,6 +1336,7 @@ __global__ void __launch_bounds__(256, 2) wedm_step_stream(const KArgs k) {
     // the test of the DONE flag) made the wave wait for the state rows -- a whole memory round trip -- before it had
     // requested its wire rows
     __builtin_amdgcn_sched_barrier(0);
+    if (PAIRED && live) load_env_inputs_paired_finish(raw, (c & 1) != 0, s, k.hot.done_value == 0, h64);
     if (!TRACE && live) { s.h_base = (float)h64[0]; s.h_zone = (float)h64[1]; }
     WEDM_S2_STAMP(0);  // everything requested
     // next-step autoreset (all L lanes of the environment agree)
@@ -1345,8 +1385,19 @@ __global__ void __launch_bounds__(256, 2) wedm_step_stream(const KArgs k) {
     auto prelude = [&](Coef& cf) {
         QuietTry qt;
         if (!quiet_prelude(hv, g, gid, s, qt)) {
+#ifndef WEDM_STREAM_NO_SETPRIO
+            // A launch ends with its slowest wave, and the slowest waves are the ~2 % whose prelude is the general one (a lane
+            // ignites: crater normal, a dozen float64 divisions).  Such a wave takes the issue priority over the other wave of
+            // its SIMD, which is not on the launch's critical path, for the rest of its life.
+            __builtin_amdgcn_s_setprio(3);
+#endif
             quiet_only = false;
-            if (!s.done) cf = scalar_prelude(hv, cold, g, e, gid, s, ps, c == 0, qt);
+            // the crater-table entries of every lane's mode (None / unknown -> I1, material.py:104-113) and of I1, read across
+            // lanes from the registers that hold the tables (every lane of the wave is here: the quiet test is wave-uniform)
+            const int mm = (s.mode >= 1 && s.mode <= WEDM_MAX_MODE) ? s.mode : 1;
+            const LaneTables mine{__shfl(ltab.mean, mm, 64), __shfl(ltab.sd, mm, 64), __shfl(ltab.depth, mm, 64), __shfl(ltab.valid, mm, 64)};
+            const LaneTables one{__shfl(ltab.mean, 1, 64), __shfl(ltab.sd, 1, 64), __shfl(ltab.depth, 1, 64), __shfl(ltab.valid, 1, 64)};
+            if (!s.done) cf = scalar_prelude<false, true>(hv, cold, g, e, gid, s, ps, c == 0, qt, &mine, &one);
         }
     };
     auto rest = [&](const int it, Coef& cf) {
@@ -1634,7 +1685,7 @@ __device__ __forceinline__ f2 interior2(f2 tm1, f2 tc, f2 tp1, float k, float tu
 // EXTRA: the instantiation for tile tables that need them: one-change tiles on the stage-major code (see wedm_step_fused's
 // N1) and a chunk's 1- or 2-cell tail computed with the patched cells (virtual chunks of 25 cells: 400 segments over 8 lanes).
 template <int L, bool TRACE, bool FROZEN_OK = false, bool EXTRA = false>
-__global__ void __launch_bounds__(256, 2) wedm_step_packed(const KArgs k) {
+__global__ void __launch_bounds__(256, WEDM_PACKED_MIN_BLOCKS) wedm_step_packed(const KArgs k) {
     constexpr bool kFrozenOk = FROZEN_OK;
     const ColdRef cold = kernarg_cold();
     Hot hv = k.hot;

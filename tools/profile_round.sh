@@ -1,10 +1,10 @@
 #!/bin/bash
 # Measurement pass of one round, run ON THE GPU BOX from the repository root:
-#     gpurun --timeout 1100 -- 'bash tools/profile_round.sh r2'
+#     gpurun --timeout 1100 -- 'bash tools/profile_round.sh r3'
 # Writes raw output under gpurun_out/<round>/ and the summaries the DESIGN.md tables quote
 # under gpurun_out/<round>/summary/ (copy those into profiles/<round>/ and commit them).
 set -o pipefail
-R=${1:-r2}
+R=${1:-r3}
 OUT=gpurun_out/$R
 S=$OUT/summary
 mkdir -p $S
