@@ -78,6 +78,8 @@ def parse_args():
                          "'voltage' = the 1 ms ring the voltage controller needs, 'signals' = the 11 scalar signals "
                          "of the reference's logger")
     ap.add_argument("--trace-every", type=int, default=1, help="sample period of --trace in microseconds")
+    ap.add_argument("--stencil-dtype", choices=["float32", "float64"], default="float32",
+                    help="side measurement: the wire stencil as Numba types it (float64 expressions rounded at each float32 store)")
     ap.add_argument("--traffic", type=float, default=None,
                     help="measured HBM bytes per launch from a separate rocprofv3 --pmc pass (else null)")
     return ap.parse_args()
@@ -383,7 +385,8 @@ def main():
                          config=EnvironmentConfig(target_cutting_distance=5000.0))
     else:
         mode = 5
-        env = WireEDMEnv(num_envs=n_local, device=device, wire_params=wire, env_id_offset=rank * n_local)
+        env = WireEDMEnv(num_envs=n_local, device=device, wire_params=wire, env_id_offset=rank * n_local,
+                         stencil_dtype=args.stencil_dtype)
     env.set_kernel(args.kernel, args.lanes)
     if args.trace == "voltage":
         env.bind_trace(["voltage"], every=args.trace_every, capacity=1001)
@@ -471,6 +474,7 @@ def main():
                 "ranks": world, "env_id_offsets": [r * n_local for r in range(world)],
                 "kernel": kname, "build_id": env._backend.build_id(),
                 **({"trace": args.trace} if args.trace != "off" else {}),
+                **({"stencil_dtype": args.stencil_dtype} if args.stencil_dtype != "float32" else {}),
                 **({"initial_gap_um": args.gap} if args.gap is not None else {}),
             },
             "roofline": roofline_block(kname, kernel_ms, n_local, n_sub, S, args.traffic),
@@ -482,7 +486,7 @@ def main():
                          if args.workload == "config5" and done else {})},
         }
         if world == 1 and not args.no_side and args.workload == "config3" and args.trace == "off" and args.gap is None \
-                and not args.num_envs and args.kernel == 0:
+                and not args.num_envs and args.kernel == 0 and args.stencil_dtype == "float32":
             out["side"] = side_measurements(n_local, wire, S, device)
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(wire, n_local, n_sub, args.cpu_seconds)

@@ -10,7 +10,7 @@ from pathlib import Path
 import pytest
 
 ROOT = Path(__file__).resolve().parents[1]
-R = ROOT / "profiles" / "r2"
+R = ROOT / "profiles" / "r3"
 
 
 def bench(name):
@@ -43,6 +43,9 @@ def test_headline_roofline_recomputes_from_profiles():
     valu = recorded("valu.json", kernel)
     traffic = recorded("traffic.json", kernel)
     assert valu is not None and traffic is not None
+    # the counter rows are bound to the build they were counted on: the bench line that carries them names the same
+    # `wedm_build_id()` (sha256 over the kernel sources and flags), and bench.py prices nothing across builds
+    assert valu["build_id"] == traffic["build_id"] == b["config"]["build_id"] and len(valu["build_id"]) == 16
     # the PMC summaries the two JSON files were made from
     sq = {l.split("\t")[2]: float(l.split("\t")[3]) for l in (R / "rocprofv3_pmc_sq_config3.txt").read_text().splitlines()}
     hbm = {l.split("\t")[2]: float(l.split("\t")[3]) for l in (R / "rocprofv3_pmc_hbm_config3.txt").read_text().splitlines()}
@@ -63,7 +66,16 @@ def test_headline_roofline_recomputes_from_profiles():
     # traffic well above the algorithmic minimum would mean wasted re-reads: T + state in and out + obs = ~102 MB
     assert traffic["hbm_bytes_per_launch"] < 1.2 * 102e6
     assert b["cpu_baseline"]["kind"] == "port" and b["cpu_baseline"]["cores"] >= 1
-    assert len(b["side"]) == 4 and b["side"][3]["resets_per_env_per_launch"] > 0.05
+    assert len(b["side"]) == 5 and b["side"][3]["resets_per_env_per_launch"] > 0.05
+    # a handle WITHOUT autoreset whose batch holds terminated (frozen) environments: its launches take as long as the quiet
+    # headline's to within 5 % (the handle moved to the frozen-lane tile code by itself)
+    frozen = b["side"][4]
+    assert frozen["frozen_fraction"] > 0.1 and "[frozen lanes ok]" in frozen["kernel"]
+    assert frozen["kernel_ms"] == pytest.approx(rf["kernel_ms"], rel=0.05)
+    # the VALU pipe's occupancy, from one counter pass (SQ_ACTIVE_INST_VALU / SQ_WAVE_CYCLES per resident wave)
+    sqv = {l.split("\t")[2]: float(l.split("\t")[3]) for l in (R / "rocprofv3_pmc_sq_config3.txt").read_text().splitlines()}
+    assert rf["valu_pipe_busy"]["frac"] == pytest.approx(sqv["SQ_ACTIVE_INST_VALU"] / (sqv["SQ_WAVE_CYCLES"] / 2.0), rel=1e-6)
+    assert 0.5 < rf["valu_pipe_busy"]["frac"] < 1.0 and 1.5 < rf["valu_pipe_busy"]["measured_clock_GHz"] < 2.5
 
 
 def test_single_microsecond_line_is_priced_against_hbm():
@@ -80,6 +92,9 @@ def test_single_microsecond_line_is_priced_against_hbm():
     assert calls >= 400 and avg_ms == pytest.approx(rf["kernel_ms"], rel=0.05)
     traffic = recorded("traffic.json", b["config"]["kernel"])
     assert traffic is not None and traffic["hbm_bytes_per_launch"] < 1.15 * alg       # counter bytes within 1.15 x B(S)
+    # ABI v4's quad-interleaved wire block: about half the vector-memory instructions of round 2 (210 per wave)
+    sq = {l.split("\t")[2]: float(l.split("\t")[3]) for l in (R / "rocprofv3_pmc_sq_config3_1us.txt").read_text().splitlines()}
+    assert sq["SQ_INSTS_VMEM"] / sq["SQ_WAVES"] < 110
 
 
 @pytest.mark.parametrize("name,bound", [("bench_config2.json", "valu-issue"), ("bench_config4_shard.json", "valu-issue"),

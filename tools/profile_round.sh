@@ -46,6 +46,8 @@ cp profiles/traffic.json profiles/valu.json $S/
 
 echo "[profile] bench lines, final pass (roofline objects use the counters just recorded)"; date +%T
 bench_lines ""
+python bench.py --steps 5 --warmup 1 --stencil-dtype float64 --no-cpu-baseline > $S/bench_config3_f64.json 2>/dev/null
+python bench.py --steps 5 --warmup 1 --stencil-dtype float64 --workload config2 --no-cpu-baseline > $S/bench_config2_f64.json 2>/dev/null
 WEDM_BENCH_FORCE_DIST=1 MASTER_ADDR=127.0.0.1 MASTER_PORT=29533 RANK=0 WORLD_SIZE=1 LOCAL_RANK=0 \
     python bench.py --steps 10 --warmup 2 --no-cpu-baseline --no-side > $S/bench_config3_rccl_world1.json 2>/dev/null
 
