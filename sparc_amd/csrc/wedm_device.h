@@ -1027,7 +1027,9 @@ __device__ __forceinline__ Coef scalar_prelude(const Hot& p, const ColdRef cold,
     Coef cf;
     {
         const double I = s.I, I2 = I * I;
-        if (__builtin_fabs(s.flow - s.wire_last_flow) > 0.01) {
+        // (`!s.broken`: with keep_stepping_terminated a broken wire's module returns before it looks at its convection cache,
+        // wire.py:260-261; elsewhere a broken wire never gets here)
+        if (!s.broken && __builtin_fabs(s.flow - s.wire_last_flow) > 0.01) {
             const auto c = c0;
             double ve = c->convection_velocity_factor * s.unwind;
             ve = ve > -0.9 ? ve : -0.9;

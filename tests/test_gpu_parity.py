@@ -813,6 +813,11 @@ def test_randomized_configurations_all_kernels_bit_exact(case):
         kw["wire_diameter"] = rng.choice([0.1, 0.15, 0.25], n)
     if case >= 10 and case % 2:   # the cases with terminations: reset inside the launch + kernel-side reward + crater log
         kw.update(autoreset=True, reward="progress", crater_log_capacity=8)
+    # the reference-compatible modes in a part of the cases: the reference's own reset (module state carries over, also
+    # through the in-launch autoreset) and / or stepping on after `terminated`, with a masked reset between the kernels
+    compat = case % 5 in (3, 4)
+    if compat:
+        kw.update(reset_semantics="reference", freeze_terminated=(case % 5 == 3))
     gpu, cpu = make_pair(n, **kw)
     seed = int(rng.integers(1, 1 << 40))
     gaps, debris = rng.uniform(6, 30, n), rng.uniform(0, 0.01, n)
@@ -850,9 +855,15 @@ def test_randomized_configurations_all_kernels_bit_exact(case):
             "\n".join(diffs[:12])
         if gpu.state.crater_log is not None:
             G, Cc = gpu.state.crater_log[:, :n].cpu(), cpu.state.crater_log[:, :n]
-            filled = torch.arange(G.shape[0])[:, None] < gpu.state.spark_count.cpu()[None, :]   # slots written since the reset
+            cnt = gpu.state.spark_count.cpu()[None, :]   # slots written so far (a ring: all of them once the count passes the capacity)
+            filled = torch.arange(G.shape[0])[:, None] < cnt
             assert torch.equal(torch.where(filled, G, 0), torch.where(filled, Cc, 0)), f"case {case}: crater log differs"
         ran += 1
+        if compat:   # a second episode for a third of the environments: EDMState only, what the modules hold lives on
+            for env in (gpu, cpu):
+                env.reset(seed=seed + ran, options={"mask": np.arange(n) % 3 == ran % 3})
+                wp = env.state.workpiece_position.cpu().numpy()
+                env.state.wire_position = torch.as_tensor(np.where(np.arange(n) % 3 == ran % 3, wp - gaps, env.state.wire_position.cpu().numpy()))
     assert ran >= (2 if case < 20 else 1)   # (a widened hunt may draw three kernels that do not fit the geometry)
 
 
