@@ -112,6 +112,8 @@ class WireTemperature:
         return a if dtype is None else a.astype(dtype)
 
     def __getattr__(self, name):  # everything else (cpu, numpy, clone, max, mean, ...) on the gathered tensor
+        if name.startswith("_"):
+            raise AttributeError(name)
         return getattr(self.tensor(), name)
 
     @classmethod

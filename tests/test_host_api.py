@@ -304,3 +304,34 @@ def test_foreign_device_action_is_rejected():
     b = WireEDMEnv(num_envs=9, device="cpu", backend=OracleBackend)
     with pytest.raises(ValueError, match="another environment"):
         b.step(a.make_action())
+
+
+def test_wire_temperature_proxy_reads_gather_and_assignments_write_through():
+    """ABI v4 stores the wire quad-interleaved (`T[seg >> 2][env][seg & 3]`); `state.wire_temperature` keeps the
+    reference's `[env, segment]` face: reads gather, every form of assignment writes through to the block the kernels
+    step, and the padding cells of the last 16-byte word are never touched."""
+    import numpy as np
+    import torch
+
+    from tests._oracle_backend import OracleBackend
+    from sparc_amd import WireEDMEnv, WireModuleParameters
+
+    env = WireEDMEnv(num_envs=5, device="cpu", backend=OracleBackend, wire_params=WireModuleParameters(segment_len=80.0 / 129.5))
+    env.reset(seed=1)
+    n = env.n_segments
+    assert n == 129 and env.state.T.shape == (33, 64, 4)               # 129 segments -> 33 words, the last with 3 padding cells
+    wt = env.state.wire_temperature
+    assert wt.shape == (5, n) and len(wt) == 5 and wt.dtype == torch.float32
+    assert torch.equal(wt.tensor(), torch.full((5, n), 293.15, dtype=torch.float32))
+    wt[2, 100:104] = 400.0                                              # slice assignment
+    wt[:, 0] = torch.arange(5, dtype=torch.float32)                     # tensor assignment
+    assert env.state.T[25, 2, 0] == 400.0 and env.state.T[25, 2, 3] == 400.0 and env.state.T[26, 2, 0] == 293.15
+    assert env.state.T[0, :5, 0].tolist() == [0.0, 1.0, 2.0, 3.0, 4.0]
+    assert float(wt[2].max()) == 400.0 and float(torch.max(wt)) == 400.0 and float((wt - 1.0)[2, 101]) == 399.0
+    assert np.asarray(wt).shape == (5, n) and wt.quads.shape == (5, 33, 4)
+    env.state.wire_temperature = np.full(n, 300.0, dtype=np.float32)    # whole-array assignment, broadcast over environments
+    assert bool((env.state.wire_temperature == 300.0).all())
+    pad = env.state.T[32, :5, 1:]                                       # cells 129..131: padding, still what the reset wrote
+    assert bool((pad == np.float32(293.15)).all())
+    env.step_many(env.make_action(), 3)                                 # and the kernels' view is the same memory
+    assert abs(float(env.state.wire_temperature[0, 64]) - 300.0) < 1.0 and float(env.state.wire_temperature[0, 0]) == np.float32(293.15)
