@@ -63,6 +63,9 @@ using namespace wedm;
 #ifndef WEDM_STREAM_PAIRED_LOADS
 #define WEDM_STREAM_PAIRED_LOADS 1
 #endif
+#ifndef WEDM_PIN_STAGE
+#define WEDM_PIN_STAGE 0
+#endif
 #ifndef WEDM_PREFETCH_N1
 #define WEDM_PREFETCH_N1 0
 #endif
@@ -542,6 +545,11 @@ __device__ __forceinline__ void tile_staged(const V (&old)[10], V (&tn)[8], cons
         e[u] = (PERCELL ? conv[o + u] : conv[0]) * e[u];
         f[u] = adv * f[u];
         if (JOULE) r[u] = alpha * r[u];
+#if WEDM_PIN_STAGE
+        // (the optimiser otherwise sinks this product down to its only use, `a - e`, where it folds the negation into the
+        // multiply and leaves a three-deep dependent chain with wait states in the stage that was meant to be one add)
+        asm volatile("" : "+v"(e[u]));
+#endif
     }
     WEDM_STAGE_FENCE();
 #pragma unroll
