@@ -1,4 +1,4 @@
-"""world_size-2 test of the sharded environment on CPU (gloo): shards reproduce the
+"""world_size-2 and world_size-8 tests of the sharded environment on CPU (gloo): shards reproduce the
 single-process batch exactly and the observation all-gather returns the whole batch."""
 from __future__ import annotations
 
@@ -66,8 +66,9 @@ def _worker(rank, world, port, out):
 
 
 @pytest.mark.timeout(300)
-def test_two_rank_sharding_matches_single_process():
-    world, port = 2, _free_port()
+@pytest.mark.parametrize("world", [2, 8])   # 8: the rank layout of the driver's one-node scaling run
+def test_sharding_matches_single_process(world):
+    port = _free_port()
     with mp.Manager() as mgr:
         out = mgr.dict()
         mp.spawn(_worker, args=(world, port, out), nprocs=world, join=True)
