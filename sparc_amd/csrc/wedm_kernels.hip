@@ -63,6 +63,10 @@ using namespace wedm;
 #ifndef WEDM_STREAM_PAIRED_LOADS
 #define WEDM_STREAM_PAIRED_LOADS 1
 #endif
+// the stream kernel walks a launch of ONE microsecond out of the registers the wire was loaded into (see rest_single)
+#ifndef WEDM_STREAM_REGWALK
+#define WEDM_STREAM_REGWALK 1
+#endif
 #ifndef WEDM_PIN_STAGE
 #define WEDM_PIN_STAGE 0
 #endif
@@ -596,6 +600,72 @@ __device__ __forceinline__ void tile8_staged(const V (&old)[10], V (&tn)[8], flo
 #pragma unroll
     for (int o = 0; o < 8; o += W)
         tile_staged<V, JOULE, PERCELL, W>(old, tn, o, k, tuf, conv, tdiel, adv, jfe, alpha, tref);
+}
+
+// Eight ADJACENT cells of one chunk as four packed pairs (cells 2m, 2m+1), stage-major like tile_staged: tm / tc / tp are
+// the OLD (T[i-1], T[i], T[i+1]) of both cells of pair m -- tm and tp are the chunk's registers shifted by one cell
+// (one v_pk_mov_b32 or two v_mov_b32 each), which is what a register-resident walk pays instead of LDS round trips.
+// Operation order and rounding are those of interior_cell().
+#ifndef WEDM_QUAD_STAGE_W
+#define WEDM_QUAD_STAGE_W 2
+#endif
+template <bool JOULE, bool PERCELL, int W>
+__device__ __forceinline__ void quad_stage_group(const f2 (&tm)[4], const f2 (&tc)[4], const f2 (&tp)[4], f2 (&tn)[4], const int o,
+                                                 float k, float tuf, const f2 (&conv)[4], float tdiel, float adv,
+                                                 const f2 (&jfe)[4], float alpha, float tref) {
+    f2 a[W], e[W], f[W], r[W];
+#pragma unroll
+    for (int u = 0; u < W; ++u) {
+        a[u] = sub_twice(tm[o + u], tc[o + u]);
+        e[u] = tc[o + u] - tdiel;
+        f[u] = tm[o + u] - tc[o + u];
+        if (JOULE) r[u] = tc[o + u] - tref;
+    }
+    WEDM_STAGE_FENCE();
+#pragma unroll
+    for (int u = 0; u < W; ++u) {
+        e[u] = (PERCELL ? conv[o + u] : conv[0]) * e[u];
+        f[u] = adv * f[u];
+        if (JOULE) r[u] = alpha * r[u];
+    }
+    WEDM_STAGE_FENCE();
+#pragma unroll
+    for (int u = 0; u < W; ++u) {
+        a[u] = a[u] + tp[o + u];
+        if (JOULE) r[u] = 1.0f + r[u];
+    }
+    WEDM_STAGE_FENCE();
+#pragma unroll
+    for (int u = 0; u < W; ++u) {
+        a[u] = k * a[u];
+        if (JOULE) r[u] = (PERCELL ? jfe[o + u] : jfe[0]) * r[u];
+    }
+    WEDM_STAGE_FENCE();
+    if (JOULE) {
+#pragma unroll
+        for (int u = 0; u < W; ++u) a[u] = a[u] + r[u];
+        WEDM_STAGE_FENCE();
+    }
+#pragma unroll
+    for (int u = 0; u < W; ++u) a[u] = a[u] - e[u];
+    WEDM_STAGE_FENCE();
+#pragma unroll
+    for (int u = 0; u < W; ++u) a[u] = a[u] + f[u];
+    WEDM_STAGE_FENCE();
+#pragma unroll
+    for (int u = 0; u < W; ++u) a[u] = a[u] * tuf;
+    WEDM_STAGE_FENCE();
+#pragma unroll
+    for (int u = 0; u < W; ++u) tn[o + u] = tc[o + u] + a[u];
+    WEDM_STAGE_FENCE();
+}
+template <bool JOULE, bool PERCELL>
+__device__ __forceinline__ void quad_staged(const f2 (&tm)[4], const f2 (&tc)[4], const f2 (&tp)[4], f2 (&tn)[4], float k,
+                                            float tuf, const f2 (&conv)[4], float tdiel, float adv, const f2 (&jfe)[4],
+                                            float alpha, float tref) {
+#pragma unroll
+    for (int o = 0; o < 4; o += WEDM_QUAD_STAGE_W)
+        quad_stage_group<JOULE, PERCELL, WEDM_QUAD_STAGE_W>(tm, tc, tp, tn, o, k, tuf, conv, tdiel, adv, jfe, alpha, tref);
 }
 
 // A wave that starts with a terminated (frozen) environment in a kernel instantiation without the frozen-lane tile
@@ -1256,7 +1326,9 @@ __global__ void __launch_bounds__(256, WEDM_FUSED_MIN_BLOCKS) wedm_step_fused(co
 // Every wave is its own pipeline, so the loads, arithmetic and stores of different waves overlap by themselves.
 #define WEDM_LDS __attribute__((address_space(3)))
 #define WEDM_GLOBAL __attribute__((address_space(1)))
-template <int L, bool TRACE, int CMAX>
+// ONE: the instantiation for launches of exactly one microsecond (the host picks it; no loop over further microseconds,
+// and a walk out of registers for the waves that can take it: rest_single below)
+template <int L, bool TRACE, int CMAX, bool ONE = false>
 __global__ void __launch_bounds__(256, 2) wedm_step_stream(const KArgs k) {
     const ColdRef cold = kernarg_cold();
     Hot hv = k.hot;
@@ -1363,7 +1435,9 @@ __global__ void __launch_bounds__(256, 2) wedm_step_stream(const KArgs k) {
             init_persist<true>(k.hot, cold, e, s, ps);
         }
     }
+#ifndef WEDM_STREAM_NO_PIN
     pin_hot_in_vgprs(hv);
+#endif
     const uint32_t gid = k.hot.env_id_offset + (uint32_t)e;
 
     const float spool = k.hot.spool, tref = k.hot.tref, alpha = k.hot.alpha, tdiel = k.hot.tdiel;
@@ -1409,7 +1483,7 @@ __global__ void __launch_bounds__(256, 2) wedm_step_stream(const KArgs k) {
         }
     };
     auto rest = [&](const int it, Coef& cf) {
-        const bool last = it + 1 == k.n_substeps;
+        const bool last = ONE || it + 1 == k.n_substeps;
         freeze_wire(s);
         // ---- halos: OLD neighbour values, read before any lane of this wave stores.  The right
         // halo goes into the chunk's extra LDS row C, so cell C-1 is walked like any other.
@@ -1596,55 +1670,211 @@ __global__ void __launch_bounds__(256, 2) wedm_step_stream(const KArgs k) {
         WEDM_TRACE_POINT(k, it, e, s, c == 0,
                          for (int j = 0; j < C && cbase + j < n; ++j) tT[(int64_t)(cbase + j) * tcnt] = col[j * 256]);
     };
+    // A launch of ONE microsecond (the reference's cadence) whose wave has nothing frozen and no tile on the predicated
+    // path never reads a NEW temperature again, so the walk runs out of the registers the wire was loaded into: no LDS
+    // read, no LDS write of a result, two cells per packed operation (adjacent cells; the shifted neighbour pairs cost a
+    // move each), every tile stored to global memory where it is computed.  The OLD chunk still goes to LDS -- one
+    // 16-byte write per word -- for the few cells read by a DYNAMIC index: the halos and the neighbours of the patched
+    // cells (plasma cell, last cell).
+    constexpr bool REGWALK = ONE && !TRACE && CMAX <= 64 && WEDM_STREAM_REGWALK;
+    auto rest_single = [&](Coef& cf) {
+        if (__any(reinit)) {
+#pragma unroll
+            for (int q = 0; q < CMAX / 4; ++q) w4[q] = reinit ? f4v{spool, spool, spool, spool} : w4[q];
+        }
+        if (c == 0) w4[0][0] = spool;  // wire cell 0 is held at the spool temperature (wire.py:83)
+        {
+            // word q of lane l of this wave -> row 4 q + l / 16 of the wave's own 64 columns, at (l % 16) * 4: the floats a
+            // wave touches are the ones of its columns in the [cell][lane] layout, so the other waves of the block may be
+            // on either path
+            typedef f4v __attribute__((may_alias)) f4v_any;  // (read back below as single floats)
+            float* const mine = lds + ((tid >> 4) & 3) * 256 + (tid & ~63) + (tid & 15) * 4;
+#pragma unroll
+            for (int q = 0; q < CMAX / 4; ++q)
+                if (4 * q < C) *(f4v_any*)(mine + q * 1024) = w4[q];
+        }
+        WEDM_S2_STAMP(1);  // wire in LDS
+        // OLD value of cell j of the lane `d` lanes away (same wave: LDS operations of a wave complete in order)
+        const auto old_at = [&](int j, int d) -> float {
+            const int l = (tid & 63) + d;
+            return lds[((j >> 2) * 4 + (l >> 4)) * 256 + (tid & ~63) + (l & 15) * 4 + (j & 3)];
+        };
+        const float halo_l = (c > 0) ? old_at(C - 1, -1) : spool;
+        const float halo_r = (c < L - 1) ? old_at(0, 1) : 0.0f;
+        // regular tiles of THIS microsecond: a contact-flag change inside a tile only matters while current flows
+        const uint32_t n_now = kind_n | kind_ne | (__any(cf.joule_on && cf.jf != 0.0f) ? 0u : kind_nj);
+        // ---- patched cells: full predicated formula from OLD values, stored after the walk
+        const bool owns_pl = cf.pidx >= 1 && cf.pidx >= cbase && cf.pidx < cbase + C;
+        float tpl = 0.0f, tlast = 0.0f;
+        if (__any(owns_pl)) {
+            if (owns_pl) {
+                const int jp = cf.pidx - cbase;
+                float tm = jp > 0 ? old_at(jp - 1, 0) : halo_l;
+                if (cf.pidx == 1) tm = spool;
+                const float tp = jp < C - 1 ? old_at(jp + 1, 0) : halo_r;
+                tpl = stencil_cell(cf.pidx, n, tm, old_at(jp, 0), tp, g, cf, ps, tref, alpha, tdiel);
+            }
+        }
+        if (owns_last) {
+            const int jl = n - 1 - cbase;
+            float tm = jl > 0 ? old_at(jl - 1, 0) : halo_l;
+            if (n - 1 == 1) tm = spool;
+            tlast = stencil_cell(n - 1, n, tm, old_at(jl, 0), 0.0f, g, cf, ps, tref, alpha, tdiel);
+        }
+        float tmax = spool;
+        const float jf_lane = cf.joule_on ? cf.jf : 0.0f;
+        const bool joule_wave = __any(jf_lane != 0.0f);
+        char* const Tw = (char*)cold->s.T;
+#pragma unroll
+        for (int t = 0; t < CMAX / 8; ++t) {
+            const int j = 8 * t;
+            if (j < C) {
+                // o[0..9]: OLD T of cells j-1 .. j+8 (a 4-cell last tile: its cells j+4.. do not exist and are not used)
+                float o[10];
+                o[0] = t == 0 ? halo_l : w4[t > 0 ? 2 * t - 1 : 0][3];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) { o[1 + u] = w4[2 * t][u]; o[5 + u] = w4[2 * t + 1][u]; }
+                o[5] = (j + 4 == C) ? halo_r : o[5];
+                o[9] = (2 * t + 2 < CMAX / 4 && j + 8 != C) ? w4[2 * t + 2 < CMAX / 4 ? 2 * t + 2 : 0][0] : halo_r;
+                f2 tm[4], tc[4], tp[4], tn[4], cv[4], jv[4];
+#pragma unroll
+                for (int m = 0; m < 4; ++m) {
+                    tm[m] = f2{o[2 * m], o[2 * m + 1]};
+                    tc[m] = f2{o[2 * m + 1], o[2 * m + 2]};
+                    tp[m] = f2{o[2 * m + 2], o[2 * m + 3]};
+                }
+                const float conv_lo = ((zone_lo >> t) & 1u) ? ps.conv_zone : ps.conv_base;
+                const float jfe_lo = ((joule_lo >> t) & 1u) ? jf_lane : 0.0f;
+                const uint32_t off = offc + (uint32_t)(j >> 2) * rowb;
+                if ((n_now >> t) & 1u) {
+                    cv[0] = f2{conv_lo, conv_lo}; jv[0] = f2{jfe_lo, jfe_lo};
+                    if (joule_wave && __any(jfe_lo != 0.0f))
+                        quad_staged<true, false>(tm, tc, tp, tn, g.k, g.tuf, cv, tdiel, ps.adv, jv, alpha, tref);
+                    else
+                        quad_staged<false, false>(tm, tc, tp, tn, g.k, g.tuf, cv, tdiel, ps.adv, jv, alpha, tref);
+                    // the wire's end cells, where a regular tile holds one (kind_ne / kind_nj): cell 0 stays at the spool
+                    // temperature; the last cell is kept out of the maximum here and patched after the walk
+                    tn[0].x = (c == 0 && t == 0) ? spool : tn[0].x;
+                    const float last_v = (owns_last && t == t_last) ? spool : tn[3].y;
+                    *(f4v*)(Tw + off) = f4v{tn[0].x, tn[0].y, tn[1].x, tn[1].y};
+                    *(f4v*)(Tw + off + rowb) = f4v{tn[2].x, tn[2].y, tn[3].x, tn[3].y};
+                    float m0 = fmax_gt(tn[0].x, tn[0].y), m1 = fmax_gt(tn[1].x, tn[1].y);
+                    m0 = fmax_gt(m0, fmax_gt(tn[2].x, tn[2].y));
+                    m1 = fmax_gt(m1, fmax_gt(tn[3].x, last_v));
+                    tmax = fmax_gt(tmax, fmax_gt(m0, m1));
+                } else {
+                    // TILE_B: interior formula everywhere, one flag change at `split`; boundary and out-of-wire cells
+                    // stay out of the maximum (patched after the walk / never stored)
+                    const int split = (int)((split_pack[t >> 3] >> ((t & 7) * 4)) & 15u);
+                    const int cnt = (C - j) < 8 ? (C - j) : 8;
+                    const float conv_hi = ((zone_hi >> t) & 1u) ? ps.conv_zone : ps.conv_base;
+                    const float jfe_hi = ((joule_hi >> t) & 1u) ? jf_lane : 0.0f;
+                    const uint32_t im1 = (uint32_t)(cbase + j - 1);  // (i - 1) of the tile's first cell
+                    const uint32_t span = (uint32_t)(n - 3);         // interior <=> (i - 1) <= n - 3 (unsigned)
+#pragma unroll
+                    for (int m = 0; m < 4; ++m) {
+                        cv[m] = f2{2 * m < split ? conv_lo : conv_hi, 2 * m + 1 < split ? conv_lo : conv_hi};
+                        jv[m] = f2{2 * m < split ? jfe_lo : jfe_hi, 2 * m + 1 < split ? jfe_lo : jfe_hi};
+                    }
+                    if (joule_wave) quad_staged<true, true>(tm, tc, tp, tn, g.k, g.tuf, cv, tdiel, ps.adv, jv, alpha, tref);
+                    else quad_staged<false, true>(tm, tc, tp, tn, g.k, g.tuf, cv, tdiel, ps.adv, jv, alpha, tref);
+                    float tnv[8];
+#pragma unroll
+                    for (int m = 0; m < 4; ++m) { tnv[2 * m] = tn[m].x; tnv[2 * m + 1] = tn[m].y; }
+#pragma unroll
+                    for (int u = 0; u < 8; ++u) {
+                        const bool inter = u < cnt && (n >= 3) && (im1 + (uint32_t)u <= span);
+                        tmax = inter ? fmax_gt(tmax, tnv[u]) : tmax;
+                    }
+                    if (no_ragged && cnt == 8) {  // every cell of every lane exists: two unconditional 16-byte stores
+                        tnv[0] = (im1 == 0xffffffffu) ? spool : tnv[0];  // wire cell 0
+                        *(f4v*)(Tw + off) = f4v{tnv[0], tnv[1], tnv[2], tnv[3]};
+                        *(f4v*)(Tw + off + rowb) = f4v{tnv[4], tnv[5], tnv[6], tnv[7]};
+                    } else {
+#pragma unroll
+                        for (int u = 0; u < 8; ++u)
+                            if (u < cnt && im1 + (uint32_t)u < (uint32_t)(n - 1)) *(float*)(Tw + off + cell_off(u)) = tnv[u];
+                    }
+                }
+            }
+        }
+        WEDM_S2_STAMP(3);  // walk done
+        // ---- patches, behind the walk's stores (same lane, same address: in order): last cell, then plasma cell
+        if (owns_last) {
+            *(float*)(Tw + offc + cell_off(n - 1 - cbase)) = tlast;
+            tmax = fmax_gt(tmax, tlast);
+        }
+        if (owns_pl) {
+            *(float*)(Tw + offc + cell_off(cf.pidx - cbase)) = tpl;
+            tmax = fmax_gt(tmax, tpl);
+        }
+#pragma unroll
+        for (int m = 1; m < L; m <<= 1) tmax = fmax_gt(tmax, __shfl_xor(tmax, m));
+        unfreeze_wire(hv, s);
+        scalar_epilogue(hv, s, tmax);
+        if (s.ctrl) control_step_outputs(cold, e, s, c == 0);
+    };
     const bool idle = __all(s.done) && !tracing;  // nothing to advance and nothing to sample
     {
         Coef cf{0.0f, 0.0f, 0, -1};
         if (!idle) prelude(cf);
         WEDM_S2_STAMP(2);  // prelude done (first microsecond)
-        // (3) the chunk into the lane's LDS column (each word is waited for where it is written: one round trip in all)
+        bool single = false;
+        if (REGWALK && !idle && kind_s == 0u) {
+            freeze_wire(s);
+            single = !__any(s.done) && !__any(cf.q < 0.0f);  // (a lane past the batch counts as frozen)
+        }
+        if (REGWALK && single) {
+            // (a branch of its own down to the state stores: what only further microseconds need -- the prelude's pinned
+            // constants above all -- is dead during the register walk)
+            rest_single(cf);
+            WEDM_S2_STAMP(4);
+        } else {
+            // (3) the chunk into the lane's LDS column (each word is waited for where it is written: one round trip in all)
 #pragma unroll
-        for (int j = 0; j < CMAX; ++j)
-            if (j < C) col[j * 256] = reinit ? k.hot.spool : w4[j >> 2][j & 3];
-        if (c == 0) col[0] = k.hot.spool;  // wire cell 0 is held at the spool temperature (wire.py:83)
-        WEDM_S2_STAMP(1);  // wire in LDS
-        if (!idle) rest(0, cf);
-    }
-    for (int it = 1; it < k.n_substeps && !idle; ++it) {
-        if (__all(s.done) && !tracing) break;
-        Coef cf{0.0f, 0.0f, 0, -1};
-        prelude(cf);
-        rest(it, cf);
-    }
+            for (int j = 0; j < CMAX; ++j)
+                if (j < C) col[j * 256] = reinit ? k.hot.spool : w4[j >> 2][j & 3];
+            if (c == 0) col[0] = k.hot.spool;  // wire cell 0 is held at the spool temperature (wire.py:83)
+            WEDM_S2_STAMP(1);  // wire in LDS
+            if (!idle) rest(0, cf);
+            for (int it = 1; !ONE && it < k.n_substeps && !idle; ++it) {
+                if (__all(s.done) && !tracing) break;
+                Coef cf{0.0f, 0.0f, 0, -1};
+                prelude(cf);
+                rest(it, cf);
+            }
 
-    WEDM_S2_STAMP(4);  // walk + epilogue done
-    // ---- write-back of what the walk did not store itself (boundary / irregular tiles, and the cells patched
-    // after the walk: wire cell 0, the last cell, the plasma cell), a tile of 8 rows at a time: 8 LDS reads in
-    // flight, then 8 stores, fire and forget; the L lanes of an environment are in one wave: nothing to wait for
-    if (!frozen0) {
-        char* const Tw = (char*)cold->s.T;
-        stored = __builtin_amdgcn_readfirstlane(stored);
+            WEDM_S2_STAMP(4);  // walk + epilogue done
+            // ---- write-back of what the walk did not store itself (boundary / irregular tiles, and the cells patched
+            // after the walk: wire cell 0, the last cell, the plasma cell), a tile of 8 rows at a time: 8 LDS reads in
+            // flight, then 8 stores, fire and forget; the L lanes of an environment are in one wave: nothing to wait for
+            if (!frozen0) {
+                char* const Tw = (char*)cold->s.T;
+                stored = __builtin_amdgcn_readfirstlane(stored);
 #pragma unroll
-        for (int t = 0; t < (CMAX + 7) / 8; ++t) {
-            if (8 * t < C && !((stored >> t) & 1u)) {
-                float v[8];
+                for (int t = 0; t < (CMAX + 7) / 8; ++t) {
+                    if (8 * t < C && !((stored >> t) & 1u)) {
+                        float v[8];
 #pragma unroll
-                for (int u = 0; u < 8; ++u) v[u] = col[((8 * t + u < C) ? 8 * t + u : C - 1) * 256];
+                        for (int u = 0; u < 8; ++u) v[u] = col[((8 * t + u < C) ? 8 * t + u : C - 1) * 256];
 #pragma unroll
-                for (int h = 0; h < 2; ++h) {
-                    const int j = 8 * t + 4 * h;
-                    if (j + 3 < jn) {  // a whole word of cells that exist
-                        *(f4v*)(Tw + offc + (uint32_t)(j >> 2) * rowb) = f4v{v[4 * h], v[4 * h + 1], v[4 * h + 2], v[4 * h + 3]};
-                    } else {  // the wire's last, partial word: the cells past the end are padding and keep their value
+                        for (int h = 0; h < 2; ++h) {
+                            const int j = 8 * t + 4 * h;
+                            if (j + 3 < jn) {  // a whole word of cells that exist
+                                *(f4v*)(Tw + offc + (uint32_t)(j >> 2) * rowb) = f4v{v[4 * h], v[4 * h + 1], v[4 * h + 2], v[4 * h + 3]};
+                            } else {  // the wire's last, partial word: the cells past the end are padding and keep their value
 #pragma unroll
-                        for (int u = 0; u < 4; ++u)
-                            if (j + u < jn) *(float*)(Tw + offc + cell_off(j + u)) = v[4 * h + u];
+                                for (int u = 0; u < 4; ++u)
+                                    if (j + u < jn) *(float*)(Tw + offc + cell_off(j + u)) = v[4 * h + u];
+                            }
+                        }
                     }
                 }
+                // cells patched after the walk inside a tile that was already stored
+                if (patch0 >= 0 && patch0 < jn && ((stored >> (patch0 >> 3)) & 1u)) *(float*)(Tw + offc + cell_off(patch0)) = col[patch0 * 256];
+                if (patch1 >= 0 && patch1 < jn && ((stored >> (patch1 >> 3)) & 1u)) *(float*)(Tw + offc + cell_off(patch1)) = col[patch1 * 256];
             }
         }
-        // cells patched after the walk inside a tile that was already stored
-        if (patch0 >= 0 && patch0 < jn && ((stored >> (patch0 >> 3)) & 1u)) *(float*)(Tw + offc + cell_off(patch0)) = col[patch0 * 256];
-        if (patch1 >= 0 && patch1 < jn && ((stored >> (patch1 >> 3)) & 1u)) *(float*)(Tw + offc + cell_off(patch1)) = col[patch1 * 256];
     }
     if (live && c == 0 && frozen0 && WEDM_REWARD_ON_SCALAR(cold)) cold->s.reward[e] = 0.0f;  // a frozen environment earns nothing
     if (live && c == 0 && !frozen0) {
@@ -2385,13 +2615,13 @@ template <bool TR> static const void* pick_fused_f64(int L) {
     }
 }
 // rows a lane of the stream kernel holds in registers: 64 (128 segments over 2 lanes, 400 over 8) or 104 (400 over 4)
-template <bool TR, int CMAX> static const void* pick_stream(int L) {
+template <bool TR, int CMAX, bool ONE = false> static const void* pick_stream(int L) {
     switch (L) {
-        case 1: return (const void*)wedm_step_stream<1, TR, CMAX>;
-        case 2: return (const void*)wedm_step_stream<2, TR, CMAX>;
-        case 4: return (const void*)wedm_step_stream<4, TR, CMAX>;
-        case 8: return (const void*)wedm_step_stream<8, TR, CMAX>;
-        default: return (const void*)wedm_step_stream<16, TR, CMAX>;
+        case 1: return (const void*)wedm_step_stream<1, TR, CMAX, ONE>;
+        case 2: return (const void*)wedm_step_stream<2, TR, CMAX, ONE>;
+        case 4: return (const void*)wedm_step_stream<4, TR, CMAX, ONE>;
+        case 8: return (const void*)wedm_step_stream<8, TR, CMAX, ONE>;
+        default: return (const void*)wedm_step_stream<16, TR, CMAX, ONE>;
     }
 }
 template <bool TR, bool FZ, bool EX> static const void* pick_packed(int L) {
@@ -2560,8 +2790,11 @@ static int32_t plan_launch(wedm_ctx* ctx, bool single, bool tr, bool frozen_ok, 
         grid = (ctx->num_envs + 256 / slanes - 1) / (256 / slanes);
         fl = ((size_t)ctx->walk4_C[sli] + 1) * 1024;
         out.walk = ctx->walk_dev + 5 + sli;
-        fn = ctx->walk4_C[sli] <= 64 ? (tr ? pick_stream<true, 64>(slanes) : pick_stream<false, 64>(slanes))
-                                    : (tr ? pick_stream<true, 104>(slanes) : pick_stream<false, 104>(slanes));
+        // launches of one microsecond without a trace sample, chunks of at most 64 cells: the instantiation without the loop
+        const bool one = WEDM_STREAM_REGWALK && single && !tr && ctx->walk4_C[sli] <= 64;
+        fn = one ? pick_stream<false, 64, true>(slanes)
+           : ctx->walk4_C[sli] <= 64 ? (tr ? pick_stream<true, 64>(slanes) : pick_stream<false, 64>(slanes))
+                                     : (tr ? pick_stream<true, 104>(slanes) : pick_stream<false, 104>(slanes));
         std::snprintf(out.name, sizeof(out.name), "wedm_step_stream<%d><<<%d,256,%zuB>>>", slanes, grid, fl);
     } else if (variant == 2) {
         grid = (ctx->num_envs + 256 / glanes - 1) / (256 / glanes);
