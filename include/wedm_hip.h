@@ -396,8 +396,10 @@ int64_t wedm_trace_samples(wedm_ctx* ctx);
  * 5 = global-memory stencil with the wire split over the four waves of a block (single
  * microseconds, any geometry), 6 = stream kernel (single microseconds, uniform geometry: the whole
  * chunk of a lane requested up front, tile walk in LDS, no barrier; the automatic choice for
- * n_substeps == 1 where one round of blocks covers the batch).  All variants produce bit-identical
- * results.  With wedm_params.stencil_mode 1 only 0, 1, 2 and 3 are accepted (3: the tile walk with
+ * n_substeps == 1 where one round of blocks covers the batch), 7 = register kernel (one environment per
+ * lane with its whole wire in registers: no LDS, the scalar physics once per environment; uniform geometry,
+ * at most 128 segments, float32 stencil; launches with a trace sample take the LDS kernels).  All variants
+ * produce bit-identical results.  With wedm_params.stencil_mode 1 only 0, 1, 2 and 3 are accepted (3: the tile walk with
  * per-cell coefficients, no stage-major / packed form).                                          */
 int32_t wedm_set_kernel(wedm_ctx* ctx, int32_t variant);
 

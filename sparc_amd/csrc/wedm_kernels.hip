@@ -64,6 +64,9 @@ using namespace wedm;
 #define WEDM_STREAM_PAIRED_LOADS 1
 #endif
 // the stream kernel walks a launch of ONE microsecond out of the registers the wire was loaded into (see rest_single)
+#ifndef WEDM_STREAM_DENSE_QUIET
+#define WEDM_STREAM_DENSE_QUIET 1
+#endif
 #ifndef WEDM_STREAM_REGWALK
 #define WEDM_STREAM_REGWALK 1
 #endif
@@ -659,13 +662,15 @@ __device__ __forceinline__ void quad_stage_group(const f2 (&tm)[4], const f2 (&t
     for (int u = 0; u < W; ++u) tn[o + u] = tc[o + u] + a[u];
     WEDM_STAGE_FENCE();
 }
-template <bool JOULE, bool PERCELL>
+// W pairs per stage: 2 where registers are short (the stream kernel, two waves per SIMD: the other wave fills the gaps),
+// 4 where a wave is alone on its SIMD and a dependent packed operation two instructions later would wait (register kernel)
+template <bool JOULE, bool PERCELL, int W = WEDM_QUAD_STAGE_W>
 __device__ __forceinline__ void quad_staged(const f2 (&tm)[4], const f2 (&tc)[4], const f2 (&tp)[4], f2 (&tn)[4], float k,
                                             float tuf, const f2 (&conv)[4], float tdiel, float adv, const f2 (&jfe)[4],
                                             float alpha, float tref) {
 #pragma unroll
-    for (int o = 0; o < 4; o += WEDM_QUAD_STAGE_W)
-        quad_stage_group<JOULE, PERCELL, WEDM_QUAD_STAGE_W>(tm, tc, tp, tn, o, k, tuf, conv, tdiel, adv, jfe, alpha, tref);
+    for (int o = 0; o < 4; o += W)
+        quad_stage_group<JOULE, PERCELL, W>(tm, tc, tp, tn, o, k, tuf, conv, tdiel, adv, jfe, alpha, tref);
 }
 
 // A wave that starts with a terminated (frozen) environment in a kernel instantiation without the frozen-lane tile
@@ -1466,7 +1471,13 @@ __global__ void __launch_bounds__(256, 2) wedm_step_stream(const KArgs k) {
     // prelude runs BEFORE the chunk is dropped into LDS: the wire's rows are still in flight then.
     auto prelude = [&](Coef& cf) {
         QuietTry qt;
+#if WEDM_STREAM_DENSE_QUIET
+        // (the quiet line also carries sparks that ignited earlier and keep burning or end now: only ignitions, shorts and
+        // control-step latches take the general path -- and the issue priority)
+        if (!quiet_prelude_t<ONE>(hv, cold, g, e, gid, s, qt, cf)) {
+#else
         if (!quiet_prelude(hv, g, gid, s, qt)) {
+#endif
 #ifndef WEDM_STREAM_NO_SETPRIO
             // A launch ends with its slowest wave, and the slowest waves are the ~2 % whose prelude is the general one (a lane
             // ignites: crater normal, a dozen float64 divisions).  Such a wave takes the issue priority over the other wave of
@@ -1820,6 +1831,9 @@ __global__ void __launch_bounds__(256, 2) wedm_step_stream(const KArgs k) {
         if (!idle) prelude(cf);
         WEDM_S2_STAMP(2);  // prelude done (first microsecond)
         bool single = false;
+        // (a table with a tile of several flag changes stays on the LDS walk: the predicated per-cell code inside the
+        // register walk -- tried before, after and instead of it -- spills the registers that hold the wire:
+        // 4 096 x 400 over 16 lanes 19.4 instead of 14.4 us, and 29.7 instead of 20.5 us at 65 536 x 128, which has no such tile)
         if (REGWALK && !idle && kind_s == 0u) {
             freeze_wire(s);
             single = !__any(s.done) && !__any(cf.q < 0.0f);  // (a lane past the batch counts as frozen)
@@ -1882,6 +1896,8 @@ __global__ void __launch_bounds__(256, 2) wedm_step_stream(const KArgs k) {
             const double pen = opaque(cold->p)->reward_break_penalty;
             cold->s.reward[e] = (float)(s.wp - wp0) - (float)pen * (s.broken ? 1.0f : 0.0f);
         }
+        // (two lanes of an environment storing one row each per instruction -- 13 vector stores instead of 25 -- changes
+        // nothing: 20.5 us either way; what a launch's last stores cost is their landing, not their number)
         store_env_after_prelude(cold, e, s, quiet_only);
         store_time_hi(cold, e, s, (uint32_t)k.n_substeps * (uint32_t)k.hot.dt_us);
         store_env_after_epilogue(cold, e, s);
@@ -1889,6 +1905,280 @@ __global__ void __launch_bounds__(256, 2) wedm_step_stream(const KArgs k) {
     WEDM_S2_STAMP(5);     // stores issued
     WEDM_S2_STAMP_VM(6);  // stores landed
     WEDM_S2_STAMP_OUT();
+}
+
+
+// ============================================ register kernel: one environment per lane, the whole wire in VGPRs
+// Wires of at most CELLS (128) segments, uniform geometry, float32 stencil, launches without a trace sample.
+// A lane owns ONE environment and keeps its whole wire in registers from the launch's first microsecond to its last: no
+// LDS, no halo exchange, no barrier, and the float64 scalar physics runs once per environment (the LDS kernels run it in
+// every lane that shares an environment: 2 at 65 536 x 128).  One wave per SIMD at a 512-register budget.
+//   * The wire is held as H = CELLS / 2 packed pairs P[m] = (T[m], T[H + m]) -- the two virtual chunks of the packed LDS
+//     kernel -- so the neighbour pairs of P[m] are P[m - 1] and P[m + 1]: no shifted copies.  The table is the one built
+//     for two chunks of exactly H cells (build_walk(p, 2, t, H)).
+//   * A tile is 8 pairs, updated in place (the OLD pair before the tile is carried along; the OLD T[H - 1] and T[H], the
+//     two chunks' halos, are taken at the step's start).
+//   * Per microsecond ONE wave-uniform mask says which tiles need more than the regular code without a Joule term: not
+//     regular in this microsecond, current in some lane between the contacts, a lane's plasma cell, the wire's last cell.
+//     Every other tile is 88 packed operations and a running maximum behind one scalar branch.  The general code of a
+//     tile recomputes the odd cells with the predicated formula (compile-time cell index, uniform geometry: scalar
+//     predicates), or every cell of a tile that is not regular.
+//   * A terminated environment keeps its registers: the walk runs under the mask of the live lanes.
+// max(a, b, c) in one instruction.  The compiler cannot see that the halves of a packed result are canonical and puts a
+// v_max_f32 x, x in front of every maximum it builds from fmaxf(); for the finite temperatures of a wire the values agree.
+__device__ __forceinline__ float max3_raw(float a, float b, float c) {
+    float r;
+    asm("v_max3_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+    return r;
+}
+
+template <int CELLS>
+__global__ void __launch_bounds__(256, 1) wedm_step_regs(const KArgs k) {
+    constexpr int H = CELLS / 2;
+    static_assert(H % 8 == 0 && H / 8 <= 16, "whole tiles");
+    const ColdRef cold = kernarg_cold();
+    Hot hv = k.hot;
+#ifndef WEDM_REGS_PIN
+#define WEDM_REGS_PIN 2
+#endif
+#if WEDM_REGS_PIN == 2
+    pin_hot_in_vgprs(hv);
+#elif WEDM_REGS_PIN == 1
+    pin_mechanics_in_vgprs(hv);
+    pin_quiet_in_vgprs(hv);
+#endif
+    const int tid = threadIdx.x;
+    const int64_t e = (int64_t)blockIdx.x * 256 + tid;
+    const bool live = e < k.num_envs;
+    const WalkTable* __restrict__ wt = k.walk;  // two chunks of H cells
+    const int n = k.hot.n_seg;
+    const int64_t stride = cold->s.stride;
+
+    Env s;
+    Geom g;
+    Persist ps{0.0f, 0.0f, 0.0f, 0};
+    load_geom(k.hot, cold, live ? e : 0, g);
+    if (live) load_env(cold, e, s);
+    else { s.done = WEDM_DEAD_LANE; s.unwind = 0.0; s.h_base = 0.0f; s.h_zone = 0.0f; }
+    // the wire: word q = cells 4 q .. 4 q + 3 of this environment, 16 bytes per lane, consecutive lanes consecutive words
+    const int nq = (n + 3) >> 2;
+    float* const Te = cold->s.T + (live ? e : 0) * 4;
+    f2 P[H];
+#pragma unroll
+    for (int q = 0; q < H / 4; ++q) {
+        const f4v a = (q < nq) ? *(const f4v*)(Te + (int64_t)q * stride * 4) : f4v{0.0f, 0.0f, 0.0f, 0.0f};
+        const f4v b = (H / 4 + q < nq) ? *(const f4v*)(Te + (int64_t)(H / 4 + q) * stride * 4) : f4v{0.0f, 0.0f, 0.0f, 0.0f};
+#pragma unroll
+        for (int u = 0; u < 4; ++u) P[4 * q + u] = f2{a[u], b[u]};
+    }
+    const float spool = k.hot.spool, tref = k.hot.tref, alpha = k.hot.alpha, tdiel = k.hot.tdiel;
+    const bool reinit = live && s.done && WEDM_AUTORESET(cold);  // next-step autoreset
+    if (reinit) reinit_env(cold, e, s, true);
+    if (__any(reinit)) {
+#pragma unroll
+        for (int m = 0; m < H; ++m) P[m] = reinit ? f2{spool, spool} : P[m];
+    }
+    P[0].x = spool;  // wire cell 0 is held at the spool temperature (wire.py:83)
+    unfreeze_wire(k.hot, s);  // keep_stepping_terminated: the DONE row is `terminated` of the last step and freezes nothing
+    const bool frozen0 = s.done;
+    if (!s.done) {
+        s.ipk = peak_current(cold, s.mode, e);
+        init_persist(k.hot, cold, e, s, ps);
+    }
+    const uint32_t gid = k.hot.env_id_offset + (uint32_t)e;
+
+    // wave-uniform tile flags of the two chunks (bit t: the tile's first cell lies in the workpiece zone / between the contacts)
+    const int n_tiles = wt->n_tiles;
+    uint32_t zoneA = 0u, zoneB = 0u, jouleA = 0u, jouleB = 0u;
+    for (int t = 0; t < n_tiles; ++t) {
+        const uint32_t lo = wt->zj[8 * t];
+        zoneA |= (lo & 1u) << t;          zoneB |= ((lo >> 1) & 1u) << t;
+        jouleA |= ((lo >> 16) & 1u) << t; jouleB |= ((lo >> 17) & 1u) << t;
+    }
+    zoneA = __builtin_amdgcn_readfirstlane(zoneA); zoneB = __builtin_amdgcn_readfirstlane(zoneB);
+    jouleA = __builtin_amdgcn_readfirstlane(jouleA); jouleB = __builtin_amdgcn_readfirstlane(jouleB);
+    const uint32_t kind_n = __builtin_amdgcn_readfirstlane(wt->kind_n_mask);
+    const uint32_t kind_ne = __builtin_amdgcn_readfirstlane(wt->kind_ne_mask), kind_nj = __builtin_amdgcn_readfirstlane(wt->kind_nj_mask);
+    // the wire's last cell: where a regular tile holds it, it is the last cell of chunk B's tile t_last
+    const uint32_t last_tile = (n > H) ? (1u << ((n - 1 - H) >> 3)) : 0u;
+
+    // the convection coefficient pair (chunk A, chunk B) of every tile: rebuilt where the general prelude may have refreshed
+    // the lane's coefficients (the quiet one never does)
+    f2 convp[H / 8];
+    auto build_conv = [&]() {
+#pragma unroll
+        for (int t = 0; t < H / 8; ++t)
+            convp[t] = f2{((zoneA >> t) & 1u) ? ps.conv_zone : ps.conv_base, ((zoneB >> t) & 1u) ? ps.conv_zone : ps.conv_base};
+    };
+    build_conv();
+
+    for (int it = 0; it < k.n_substeps; ++it) {
+        if (__all(s.done)) break;
+        Coef cf{0.0f, 0.0f, 0, -1};
+        QuietTry qt;
+        const bool was_quiet = quiet_prelude_t<WEDM_PACKED_DENSE>(hv, cold, g, e, gid, s, qt, cf);
+        if (!was_quiet) {
+            if (!s.done) cf = scalar_prelude(hv, cold, g, e, gid, s, ps, true, qt);
+            build_conv();
+        }
+        freeze_wire(s);
+        const bool act = !s.done;
+        float tmax = spool;
+        // (what the rare code of a tile derives from these -- a lane mask per uniform predicate, one per tile or per cell
+        // -- would otherwise be computed once before the loop and kept: a thousand scalar registers spilled into vector
+        // lanes and read back on the hot path too.  Opaque per microsecond, the predicates are scalar compares where used.)
+        asm volatile("" : "+s"(zoneA), "+s"(zoneB), "+s"(jouleA), "+s"(jouleB));
+        Geom gw = g;  // (uniform geometry: the same in every lane)
+        gw.n_seg = __builtin_amdgcn_readfirstlane(g.n_seg); gw.az_start = __builtin_amdgcn_readfirstlane(g.az_start);
+        gw.az_end = __builtin_amdgcn_readfirstlane(g.az_end); gw.cb = __builtin_amdgcn_readfirstlane(g.cb);
+        gw.ct = __builtin_amdgcn_readfirstlane(g.ct);
+        asm volatile("" : "+s"(gw.n_seg), "+s"(gw.az_start), "+s"(gw.az_end), "+s"(gw.cb), "+s"(gw.ct));
+        int nw = __builtin_amdgcn_readfirstlane(n);
+        asm volatile("" : "+s"(nw));
+        if (act) {  // (the lanes of terminated environments sit the walk out: their registers stay)
+            // a wave with a negative plasma heat walks every cell on the predicated formula (identical results, slower)
+            const bool all_slow = __any(cf.q < 0.0f);
+            // regular tiles of THIS microsecond: a contact-flag change inside a tile only matters while current flows
+            const float jf_lane = cf.joule_on ? cf.jf : 0.0f;
+            const bool joule_wave = __any(jf_lane != 0.0f);
+            const uint32_t n_now = all_slow ? 0u : (kind_n | kind_ne | (joule_wave ? 0u : kind_nj));
+            // the tiles that hold some lane's plasma cell
+            const int pcell = (cf.pidx >= 1) ? cf.pidx : -1;
+            uint32_t ptiles = 0u;
+            if (__any(pcell >= 0)) {
+                const int pt = pcell >= 0 ? ((pcell & (H - 1)) >> 3) : -1;
+#pragma unroll
+                for (int t = 0; t < H / 8; ++t) ptiles |= __any(pt == t) ? (1u << t) : 0u;
+            }
+            // tiles that need more than the regular code without a Joule term
+            const uint32_t general = ~n_now | (joule_wave ? (jouleA | jouleB) : 0u) | ptiles | last_tile;
+            const float a_last = P[H - 1].x, b_first = P[0].y;  // OLD T[H - 1] (left of chunk B) and T[H] (right of chunk A)
+            f2 leftp = f2{spool, a_last};                         // OLD pair before the tile
+#pragma unroll
+            for (int t = 0; t < H / 8; ++t) {
+                if (t < n_tiles) {
+                    const int j = 8 * t;
+                    f2 tm[8], tc[8], tp[8], pn[8];
+#pragma unroll
+                    for (int u = 0; u < 8; ++u) {
+                        tc[u] = P[j + u];
+                        tm[u] = u == 0 ? leftp : P[j + u - 1];
+                        tp[u] = (j + u + 1 < H) ? P[j + u + 1 < H ? j + u + 1 : 0] : f2{b_first, 0.0f};
+                    }
+                    leftp = tc[7];
+                    f2 cv[4], jv[4];
+                    cv[0] = convp[t];
+                    f2 tmA[4], tcA[4], tpA[4], pnA[4], tmB[4], tcB[4], tpB[4], pnB[4];
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) { tmA[u] = tm[u]; tcA[u] = tc[u]; tpA[u] = tp[u]; tmB[u] = tm[4 + u]; tcB[u] = tc[4 + u]; tpB[u] = tp[4 + u]; }
+                    if (!((general >> t) & 1u)) {
+                        jv[0] = f2{0.0f, 0.0f};
+                        quad_staged<false, false, 4>(tmA, tcA, tpA, pnA, g.k, g.tuf, cv, tdiel, ps.adv, jv, alpha, tref);
+                        quad_staged<false, false, 4>(tmB, tcB, tpB, pnB, g.k, g.tuf, cv, tdiel, ps.adv, jv, alpha, tref);
+#pragma unroll
+                        for (int u = 0; u < 4; ++u) { pn[u] = pnA[u]; pn[4 + u] = pnB[u]; }
+                        if (t == 0) pn[0].x = spool;  // wire cell 0
+                        float m0 = max3_raw(tmax, pn[0].x, pn[0].y), m1 = max3_raw(pn[1].x, pn[1].y, pn[2].x);
+                        m0 = max3_raw(m0, pn[2].y, pn[3].x); m1 = max3_raw(m1, pn[3].y, pn[4].x);
+                        m0 = max3_raw(m0, pn[4].y, pn[5].x); m1 = max3_raw(m1, pn[5].y, pn[6].x);
+                        m0 = max3_raw(m0, pn[6].y, pn[7].x);
+                        tmax = max3_raw(m0, m1, pn[7].y);
+                    } else if ((n_now >> t) & 1u) {
+                        // regular, with odd cells: a Joule term, the wire's last cell, plasma cells
+                        jv[0] = f2{((jouleA >> t) & 1u) ? jf_lane : 0.0f, ((jouleB >> t) & 1u) ? jf_lane : 0.0f};
+                        if (joule_wave && (((jouleA | jouleB) >> t) & 1u)) {
+                            quad_staged<true, false, 4>(tmA, tcA, tpA, pnA, g.k, g.tuf, cv, tdiel, ps.adv, jv, alpha, tref);
+                            quad_staged<true, false, 4>(tmB, tcB, tpB, pnB, g.k, g.tuf, cv, tdiel, ps.adv, jv, alpha, tref);
+                        } else {
+                            quad_staged<false, false, 4>(tmA, tcA, tpA, pnA, g.k, g.tuf, cv, tdiel, ps.adv, jv, alpha, tref);
+                            quad_staged<false, false, 4>(tmB, tcB, tpB, pnB, g.k, g.tuf, cv, tdiel, ps.adv, jv, alpha, tref);
+                        }
+#pragma unroll
+                        for (int u = 0; u < 4; ++u) { pn[u] = pnA[u]; pn[4 + u] = pnB[u]; }
+                        if (t == 0) pn[0].x = spool;  // wire cell 0
+                        // the last cell (last position of chunk B's tile): out of the regular maximum, predicated formula
+                        const bool has_last = (last_tile >> t) & 1u;
+                        float m0 = fmax_gt(pn[0].x, pn[0].y), m1 = fmax_gt(pn[1].x, pn[1].y);
+#pragma unroll
+                        for (int u = 2; u < 6; u += 2) {
+                            m0 = fmax_gt(m0, fmax_gt(pn[u].x, pn[u].y));
+                            m1 = fmax_gt(m1, fmax_gt(pn[u + 1].x, pn[u + 1].y));
+                        }
+                        m0 = fmax_gt(m0, fmax_gt(pn[6].x, pn[6].y));
+                        m1 = fmax_gt(m1, fmax_gt(pn[7].x, has_last ? spool : pn[7].y));
+                        tmax = fmax_gt(tmax, fmax_gt(m0, m1));
+                        if (has_last) {
+                            pn[7].y = stencil_cell(H + j + 7, nw, (H + j + 7 == 1) ? spool : tm[7].y, tc[7].y, 0.0f, gw, cf, ps, tref, alpha, tdiel);
+                            tmax = fmax_gt(tmax, pn[7].y);
+                        }
+                        // plasma cells of the lanes that have one in this tile: the predicated formula from the same OLD values
+                        // (the regular value stays in the maximum, as where the LDS kernels patch the cell after the walk)
+                        if ((ptiles >> t) & 1u) {
+#pragma unroll
+                            for (int u = 0; u < 8; ++u) {
+                                if (__any(pcell == j + u)) {
+                                    const float x = stencil_cell(j + u, nw, (j + u == 1) ? spool : tm[u].x, tc[u].x, tp[u].x, gw, cf, ps, tref, alpha, tdiel);
+                                    pn[u].x = (pcell == j + u) ? x : pn[u].x;
+                                    tmax = (pcell == j + u) ? fmax_gt(tmax, x) : tmax;
+                                }
+                                if (__any(pcell == H + j + u)) {
+                                    const float x = stencil_cell(H + j + u, nw, tm[u].y, tc[u].y, tp[u].y, gw, cf, ps, tref, alpha, tdiel);
+                                    pn[u].y = (pcell == H + j + u) ? x : pn[u].y;
+                                    tmax = (pcell == H + j + u) ? fmax_gt(tmax, x) : tmax;
+                                }
+                            }
+                        }
+                    } else {
+                        // not regular in this microsecond: every cell that exists on the predicated formula
+#pragma unroll
+                        for (int u = 0; u < 8; ++u) {
+                            pn[u] = tc[u];
+                            const int ia = j + u, ib = H + j + u;
+                            if (ia < nw) {
+                                const float x = (ia >= 1) ? stencil_cell(ia, nw, (ia == 1) ? spool : tm[u].x, tc[u].x, tp[u].x, gw, cf, ps, tref, alpha, tdiel) : spool;
+                                pn[u].x = x;
+                                tmax = fmax_gt(tmax, x);
+                            }
+                            if (ib < nw) {
+                                const float x = stencil_cell(ib, nw, tm[u].y, tc[u].y, tp[u].y, gw, cf, ps, tref, alpha, tdiel);
+                                pn[u].y = x;
+                                tmax = fmax_gt(tmax, x);
+                            }
+                        }
+                    }
+#pragma unroll
+                    for (int u = 0; u < 8; ++u) P[j + u] = pn[u];
+                }
+            }
+        }
+        unfreeze_wire(hv, s);
+        if (!s.done) {
+            scalar_epilogue(hv, s, tmax);
+            if (s.ctrl) control_step_outputs(cold, e, s, true);
+        }
+    }
+
+    if (live) {
+#pragma unroll
+        for (int q = 0; q < CELLS / 4; ++q) {
+            const int m = (q % (H / 4)) * 4;
+            const bool hi = q >= H / 4;
+            const f4v w = hi ? f4v{P[m].y, P[m + 1].y, P[m + 2].y, P[m + 3].y} : f4v{P[m].x, P[m + 1].x, P[m + 2].x, P[m + 3].x};
+            if (4 * q + 3 < n) {
+                *(f4v*)(Te + (int64_t)q * stride * 4) = w;
+            } else {  // the wire's last, partial word: the cells past the end are padding and keep their value
+#pragma unroll
+                for (int u = 0; u < 4; ++u)
+                    if (4 * q + u < n) Te[(int64_t)q * stride * 4 + u] = w[u];
+            }
+        }
+        if (WEDM_REWARD_ON(cold)) {
+            if (!frozen0) write_reward(cold, e, s);
+            else cold->s.reward[e] = 0.0f;  // a frozen environment earns nothing (not the previous launch's reward)
+        }
+        store_time_hi(cold, e, s, (uint32_t)k.n_substeps * (uint32_t)k.hot.dt_us);
+        store_env(cold, e, s);
+    }
 }
 
 
@@ -2477,10 +2767,11 @@ struct wedm_ctx {
     bool auto_prefers_packed = true;
     unsigned long long* dbg = nullptr; // diagnostic builds: phase stamp buffer
     int lds_limit = 0;
-    WalkTable* walk_dev = nullptr;     // [10] tables for L = 1, 2, 4, 8, 16; then the same with chunks of whole 16-byte words (stream kernel)
+    WalkTable* walk_dev = nullptr;     // [11] tables for L = 1, 2, 4, 8, 16; the same with chunks of whole 16-byte words (stream kernel); two chunks of 64 cells (register kernel)
     bool walk_ok[5] = {false, false, false, false, false};
     int32_t walk_C[5] = {0, 0, 0, 0, 0};
     bool walk4_ok[5] = {false, false, false, false, false};
+    bool walk_regs_ok = false;
     int32_t walk4_C[5] = {0, 0, 0, 0, 0};
     uint32_t walk_n1z = 0;             // bit i: table i has a one-change tile with a zone change (see WalkTable::kind_n1_mask)
     // signal trace (wedm_bind_trace): descriptor, microseconds stepped and samples written since the bind
@@ -2721,16 +3012,21 @@ static int32_t plan_launch(wedm_ctx* ctx, bool single, bool tr, bool frozen_ok, 
         }
     }
     const bool lanes_ok = glanes > 0;
-    // kernel 6 (stream, single microseconds, uniform geometry): the caller's lane count, else the smallest L whose
-    // chunk has at most 64 cells (the registers a lane holds its chunk in; failing that at most 104)
+    // kernel 6 (stream, single microseconds, uniform geometry): the caller's lane count, else -- among the L whose chunk
+    // has at most 64 cells (the registers a lane holds its chunk in) -- the largest one whose blocks are all resident at
+    // once (2 048 waves): a launch of one microsecond is one dependent chain per wave, and a shorter chunk is a shorter
+    // chain (4 096 x 400: 26.3 / 18.8 / 14.4 us with 4 / 8 / 16 lanes); a batch too large for one round takes the
+    // smallest such L (65 536 x 128: 2 lanes); failing all that a chunk of at most 104 cells
     int slanes = 0;
     if (uniform && (uint64_t)WEDM_T_QUADS(ctx->n_seg_max) * (uint64_t)ctx->s.stride * 16ull < (1ull << 32)) {
         const int Ls[5] = {1, 2, 4, 8, 16};
         for (int pass = 0; pass < 2 && !slanes; ++pass)
-            for (int i = 0; i < 5 && !slanes; ++i) {
+            for (int i = 0; i < 5; ++i) {
                 if (!ctx->walk4_ok[i] || ctx->walk4_C[i] > (pass ? 104 : 64) ||
                     ((size_t)ctx->walk4_C[i] + 1) * 1024 > (size_t)ctx->lds_limit) continue;
                 if (ctx->lanes && Ls[i] != ctx->lanes) continue;
+                const long waves = (long)((ctx->num_envs + (256 / Ls[i]) - 1) / (256 / Ls[i])) * 4;
+                if (slanes && (pass || waves > 2048)) break;
                 slanes = Ls[i];
             }
     }
@@ -2762,6 +3058,12 @@ static int32_t plan_launch(wedm_ctx* ctx, bool single, bool tr, bool frozen_ok, 
         else if (fused_ok) variant = 3;
         else variant = lanes_ok ? 2 : 1;
     }
+    // kernel 7 (register kernel): one environment per lane, wires of at most 128 segments, uniform geometry, float32 stencil;
+    // it has no trace point: a launch with a trace sample takes the LDS kernels
+    const bool regs_ok = uniform && ctx->walk_regs_ok && ctx->n_seg_max <= 128 && !f64 && !ctx->replay;
+    if (variant == 7 && !regs_ok)
+        return fail(ctx, WEDM_ERR_UNSUPPORTED, "wedm_step: register kernel needs uniform geometry, at most 128 segments and the float32 stencil");
+    if (variant == 7 && tr) variant = packed_ok ? 4 : fused_ok ? 3 : lanes_ok ? 2 : 1;
     if (variant == 3 && !fused_ok)
         return fail(ctx, WEDM_ERR_UNSUPPORTED, "wedm_step: fused kernel needs uniform geometry and a chunk that fits in LDS");
     if (variant == 4 && !packed_ok)
@@ -2781,6 +3083,11 @@ static int32_t plan_launch(wedm_ctx* ctx, bool single, bool tr, bool frozen_ok, 
            : f64 ? (tr ? (const void*)wedm_step_global<true, true, false> : (const void*)wedm_step_global<false, true, false>)
                  : (tr ? (const void*)wedm_step_global<true, false, false> : (const void*)wedm_step_global<false, false, false>);
         std::snprintf(out.name, sizeof(out.name), "wedm_step_global%s<<<%d,256>>>", ctx->replay ? "[injected variates]" : f64 ? "[f64 stencil]" : "", grid);
+    } else if (variant == 7) {
+        grid = (ctx->num_envs + 255) / 256;
+        out.walk = ctx->walk_dev + 10;  // the table of two chunks of 64 cells
+        fn = (const void*)wedm_step_regs<128>;
+        std::snprintf(out.name, sizeof(out.name), "wedm_step_regs<128><<<%d,256>>>", grid);
     } else if (variant == 5) {
         grid = (ctx->num_envs + 63) / 64;
         fn = tr ? (const void*)wedm_step_split<true> : (const void*)wedm_step_split<false>;
@@ -2934,7 +3241,7 @@ int32_t wedm_create(const wedm_params* params, int32_t num_envs, int32_t n_seg_m
         return WEDM_ERR_HIP;
     }
     if (!params->per_env_geometry) {
-        std::vector<WalkTable> host_tabs(10);
+        std::vector<WalkTable> host_tabs(11);  // [10]: two chunks of exactly 64 cells (register kernel)
         const int Ls[5] = {1, 2, 4, 8, 16};
         for (int i = 0; i < 5; ++i) {
             ctx->walk_ok[i] = build_walk(*params, Ls[i], host_tabs[i]);
@@ -2942,6 +3249,7 @@ int32_t wedm_create(const wedm_params* params, int32_t num_envs, int32_t n_seg_m
             if (ctx->walk_ok[i] && (host_tabs[i].kind_n1_mask & 0x80000000u)) ctx->walk_n1z |= 1u << i;
             ctx->walk4_ok[i] = build_walk(*params, Ls[i], host_tabs[5 + i], 4);
             ctx->walk4_C[i] = host_tabs[5 + i].C;
+            if (i == 0) ctx->walk_regs_ok = params->n_seg <= 128 && build_walk(*params, 2, host_tabs[10], 64) && host_tabs[10].C == 64;
         }
         const size_t tab_bytes = host_tabs.size() * sizeof(WalkTable);
         if ((e = hipMalloc((void**)&ctx->walk_dev, tab_bytes)) != hipSuccess ||
@@ -3040,7 +3348,7 @@ int32_t wedm_bind_rng_replay(wedm_ctx* ctx, const double* table, int64_t n_steps
 
 int32_t wedm_set_kernel(wedm_ctx* ctx, int32_t variant) {
     if (!ctx) return WEDM_ERR_BAD_ARG;
-    if (variant < 0 || variant > 6) return fail(ctx, WEDM_ERR_BAD_ARG, "wedm_set_kernel: variant must be 0..6");
+    if (variant < 0 || variant > 7) return fail(ctx, WEDM_ERR_BAD_ARG, "wedm_set_kernel: variant must be 0..7");
     ctx->variant = variant;
     ctx->invalidate_plans();
     return WEDM_OK;

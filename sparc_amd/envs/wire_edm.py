@@ -373,8 +373,10 @@ class WireEDMEnv:
     def set_kernel(self, variant: int, lanes: int = 0) -> None:
         """0 = auto, 1 = global-memory stencil, 2 = LDS predicated, 3 = LDS fused, 4 = LDS
         fused with packed float32 math, 5 = global-memory stencil split over four waves, 6 =
-        stream kernel (5 / 6: single microseconds; auto picks between them by shape); ``lanes``
-        lanes per environment for 2/3/4/6 (0 = auto).  All variants are bit-identical."""
+        stream kernel (5 / 6: single microseconds; auto picks between them by shape), 7 = register
+        kernel (one environment per lane, its whole wire in registers: wires of at most 128 segments,
+        uniform geometry); ``lanes`` lanes per environment for 2/3/4/6 (0 = auto).  All variants are
+        bit-identical."""
         self._backend.set_kernel(variant)
         if hasattr(self._backend, "set_lanes"):
             self._backend.set_lanes(lanes)

@@ -177,7 +177,7 @@ def test_single_microsecond_steps_with_changing_actions():
     assert torch.equal(tg.cpu(), tc)
 
 
-@pytest.mark.parametrize("variant,lanes", KERNELS)
+@pytest.mark.parametrize("variant,lanes", KERNELS + [(7, 0)])
 def test_config3_grid_128_segments(variant, lanes):
     """BASELINE config 3: segment_len 0.625 -> 128 segments."""
     n = 1024
@@ -510,7 +510,7 @@ def test_tiny_wires_all_kernels(segment_len, n_seg):
     from sparc_amd._lib import WedmError
 
     ran = 0
-    for variant, lanes in KERNELS:
+    for variant, lanes in KERNELS + [(7, 0)]:
         gpu.set_kernel(variant, lanes)
         a_g, a_c = gpu.make_action(0.1, 80.0, 9, 3.0, 30.0), cpu.make_action(0.1, 80.0, 9, 3.0, 30.0)
         try:
@@ -831,7 +831,7 @@ def test_randomized_configurations_all_kernels_bit_exact(case):
         env.state.workpiece_position = torch.as_tensor(10.0 + gaps)
         env.state.target_position = torch.as_tensor(np.where(np.arange(n) % 7 == 3, 10.0 + gaps + 0.01, 5000.0)) if extreme else 5000.0
         env.state.debris_volume = torch.as_tensor(debris) if (case % 2 or extreme) else 0.0
-    variants = [(0, 0), (1, 0), (5, 0), (2, 4), (2, 8)] if per_env else KERNELS + [(0, 0)]
+    variants = [(0, 0), (1, 0), (5, 0), (2, 4), (2, 8)] if per_env else KERNELS + [(0, 0), (7, 0)]
     servo = rng.uniform(50, 300, n) if kw["mechanics_control_mode"] == "velocity" else rng.uniform(-0.05, 0.3, n)
     if extreme:
         servo = servo * rng.choice([1.0, 1.0, 20.0, -3.0], n)
@@ -867,13 +867,15 @@ def test_randomized_configurations_all_kernels_bit_exact(case):
     assert ran >= (2 if case < 20 else 1)   # (a widened hunt may draw three kernels that do not fit the geometry)
 
 
-@pytest.mark.parametrize("variant,lanes", [(1, 0), (2, 4), (3, 8), (4, 4), (5, 0), (6, 8)])
+@pytest.mark.parametrize("variant,lanes", [(1, 0), (2, 4), (3, 8), (4, 4), (5, 0), (6, 8), (7, 0)])
 def test_clock_high_word_across_the_32_bit_wrap_matches_oracle(variant, lanes):
     """`state.time` past 2**31 and 2**32 us: the kernels carry the low word (also the Philox counter word) through the
     launch and bump row TIME_HI when it wrapped inside it; every kernel == the oracle on every byte, in fused and in
     single-microsecond launches, with autoreset (a re-initialised environment starts again at 0 / 0)."""
     n = 192
     kw = dict(autoreset=True, config=EnvironmentConfig(target_cutting_distance=5000.0))
+    if variant == 7:   # (the register kernel holds wires of at most 128 segments)
+        kw["wire_params"] = WireModuleParameters(segment_len=0.625)
     gpu, cpu = make_pair(n, **kw)
     start = torch.tensor([2**31 - 300, 2**32 - 300, 2**32 - 1, 5 * 2**32 - 40] * (n // 4))
     for env in (gpu, cpu):
@@ -968,8 +970,8 @@ SWEEP_N = list(range(9, 171))
 
 @pytest.mark.parametrize("n_lo", SWEEP_N[::18])
 def test_tile_geometry_sweep_every_wire_length_every_lane_count(n_lo):
-    """Every wire length from 9 to 170 segments x every lane count x the three tile-table kernels (fused, packed, stream)
-    against the oracle, on poisoned LDS.  The one real bug of round 2 lived exactly in `n_seg mod (8 L)` (a last cell
+    """Every wire length from 9 to 170 segments x every lane count x the tile-table kernels (fused, packed, stream; the
+    register kernel up to 128 segments) against the oracle, on poisoned LDS.  The one real bug of round 2 lived exactly in `n_seg mod (8 L)` (a last cell
     closing a tile that a partial tile of cells past the wire's end follows): this walks through all of those residues --
     chunk lengths, tails of 1..7 cells, chunks wholly past the end, zone / contact boundaries at every tile offset -- with
     sparks (plasma patch), current (Joule tiles) and a wire break in the batch."""
@@ -997,9 +999,9 @@ def test_tile_geometry_sweep_every_wire_length_every_lane_count(n_lo):
             cpu.step(act)
         want = cpu.state.clone_blocks()
         assert int(cpu.state.spark_count.sum()) > n_envs and bool(cpu.state.is_wire_broken[5])
-        for variant in (3, 4, 6):
+        for variant in (3, 4, 6, 7):
             for lanes in (1, 2, 4, 8, 16):
-                if variant == 4 and lanes == 16:
+                if (variant == 4 and lanes == 16) or (variant == 7 and lanes != 1):   # (the register kernel: one lane per environment)
                     continue
                 act = scenario(gpu)
                 gpu.set_kernel(variant, lanes)
@@ -1016,7 +1018,7 @@ def test_tile_geometry_sweep_every_wire_length_every_lane_count(n_lo):
                 assert not diffs, f"n_seg {n_seg}, kernel {gpu._backend.last_kernel()}:\n" + "\n".join(diffs[:10])
                 ran += 1
         gpu.close()
-    assert ran >= 18 * 11 and refused <= 18 * 3, (ran, refused)   # (one lane per environment: wires over ~104 / ~159 cells do not fit)
+    assert ran >= 18 * 11 and refused <= 18 * 4, (ran, refused)   # (one lane per environment: wires over ~104 / 128 / ~159 cells do not fit)
 
 
 @pytest.mark.parametrize("segment_len,expect", [(0.05, "wedm_step_fused<16>"), (0.02, "wedm_step_global")])
@@ -1417,3 +1419,57 @@ def test_densely_sparking_batch_on_the_packed_kernel_matches_oracle():
     assert "wedm_step_packed<2>" in gpu._backend.last_kernel(), gpu._backend.last_kernel()
     check(gpu, cpu, n)
     assert int(gpu.state.spark_count.sum()) / n / 2.777 > 5.0          # densely sparking indeed
+
+
+@pytest.mark.parametrize("mode", ["default", "autoreset", "reference"])
+def test_register_kernel_one_environment_per_lane_matches_oracle(mode):
+    """Kernel 7 (the whole wire of an environment in one lane's registers, no LDS) at the headline grid (128 segments)
+    against the oracle batch, every byte: sparks in every tile of the workpiece zone (plasma cell recomputed inside its
+    tile), current through the contact tile, wire breaks by temperature (frozen lanes inside live waves) and by
+    collision, reached targets; launches of 1, 2, 1000 and 1300 us; in-launch autoreset with the progress reward; the
+    reference's reset semantics with stepping past `terminated`; a batch that does not fill its last wave."""
+    n = 333
+    kw = dict(wire_params=WireModuleParameters(segment_len=0.625), config=EnvironmentConfig(target_cutting_distance=5000.0))
+    if mode == "autoreset":
+        kw.update(autoreset=True, reward="progress", crater_log_capacity=8)
+    if mode == "reference":
+        kw.update(reset_semantics="reference", freeze_terminated=False, ignition_params=IgnitionModuleParameters(default_current_mode="I13"))
+    gpu, cpu = make_pair(n, **kw)
+    assert gpu.n_segments == 128
+    gpu.set_kernel(7)
+    idx = torch.arange(n)
+    for env in (gpu, cpu):
+        env.reset(seed=77)
+        close_gap(env, 21.0, 10.0)
+        env.state.workpiece_position = torch.where(idx % 9 == 2, 11.2, 21.0)          # hard shorts
+        env.state.target_position = torch.where(idx % 4 == 1, 21.0005, 5000.0)        # reached after the first craters
+        env.state.wire_position = torch.where(idx % 11 == 5, 125.0, 10.0)             # collision: wire > workpiece + 100
+        hot = env.state.wire_temperature
+        hot[7::13, 60:64] = 1600.0                                                    # breaks at the first step
+        hot[70, 127] = 900.0                                                          # a hot last cell (Neumann end)
+        hot[71, 1] = 900.0                                                            # a hot first interior cell
+        a = env.make_action(0.1, 80.0, 17, 3.0, 20.0)
+        for k in (1, 2, 1000, 1, 1300):
+            env.step_many(a, k)
+        env.reset(seed=78, options={"mask": idx % 3 == 0})
+        env.state.wire_position = torch.where(idx % 3 == 0, 35.0, env.state.wire_position.cpu())
+        env.state.wire_unwinding_velocity[::7] = 0.0                                  # mixed advection inside a wave
+        for k in (1, 900, 600):
+            env.step_many(a, k)
+    assert "wedm_step_regs<128>" in gpu._backend.last_kernel()
+    check(gpu, cpu, n)
+    st = gpu.state
+    assert int(st.spark_count.sum()) > 10 * n
+    if mode == "default":
+        assert bool(st.is_wire_broken.any()) and bool(st.is_target_distance_reached.any())
+    if mode == "autoreset":
+        assert int(st.episode.max()) >= 1
+    if mode == "autoreset":
+        return   # (the oracle seam samples a trace after single microseconds, and every launch boundary is an episode boundary here)
+    # a launch with a trace sample has no register-kernel form: the LDS kernels take it, results unchanged
+    traces = [e.bind_trace(["voltage", "wire_max_temperature"], every=1, capacity=64, envs=(0, 64)) for e in (gpu, cpu)]
+    for env in (gpu, cpu):
+        env.step_many(env.make_action(0.1, 80.0, 17, 3.0, 20.0), 40)
+    assert "wedm_step_regs" not in gpu._backend.last_kernel()
+    assert_rings_equal(*traces)
+    check(gpu, cpu, n)
