@@ -1924,6 +1924,11 @@ __global__ void __launch_bounds__(256, 2) wedm_step_stream(const KArgs k) {
 //     tile recomputes the odd cells with the predicated formula (compile-time cell index, uniform geometry: scalar
 //     predicates), or every cell of a tile that is not regular.
 //   * A terminated environment keeps its registers: the walk runs under the mask of the live lanes.
+struct cv4 {  // one coefficient pair for the four pairs of a quad (quad_staged with per-cell operands)
+    f2 v[4];
+    __device__ __forceinline__ explicit cv4(f2 x) : v{x, x, x, x} {}
+};
+
 // max(a, b, c) in one instruction.  The compiler cannot see that the halves of a packed result are canonical and puts a
 // v_max_f32 x, x in front of every maximum it builds from fmaxf(); for the finite temperatures of a wire the values agree.
 __device__ __forceinline__ float max3_raw(float a, float b, float c) {
@@ -1932,27 +1937,41 @@ __device__ __forceinline__ float max3_raw(float a, float b, float c) {
     return r;
 }
 
-template <int CELLS>
-__global__ void __launch_bounds__(256, 1) wedm_step_regs(const KArgs k) {
-    constexpr int H = CELLS / 2;
+#ifndef WEDM_REGS_SW2
+#define WEDM_REGS_SW2 2
+#endif
+#ifndef WEDM_REGS_PIN2
+#define WEDM_REGS_PIN2 1
+#endif
+template <int CELLS, int L>
+__global__ void __launch_bounds__(256, L) wedm_step_regs(const KArgs k) {
+    // L = 1: one environment per lane (H = 64 pairs, one wave per SIMD at a 512-register budget);
+    // L = 2: two lanes per environment, each with half of the wire (H = 32 pairs, two waves per SIMD, the scalar physics
+    //        in both lanes as in the LDS kernels; the halves' halos cross by DPP)
+    constexpr int H = CELLS / (2 * L);  // pairs per lane: P[m] = (T[base + m], T[base + H + m])
+    static_assert(L == 1 || L == 2, "one or two lanes per environment");
     static_assert(H % 8 == 0 && H / 8 <= 16, "whole tiles");
+    constexpr int EPB = 256 / L;
+    // pairs per stage of the packed walk: a wave that is alone on its SIMD needs the distance between dependent operations
+    constexpr int SW = L == 1 ? 4 : WEDM_REGS_SW2;
     const ColdRef cold = kernarg_cold();
     Hot hv = k.hot;
-#ifndef WEDM_REGS_PIN
-#define WEDM_REGS_PIN 2
-#endif
-#if WEDM_REGS_PIN == 2
-    pin_hot_in_vgprs(hv);
-#elif WEDM_REGS_PIN == 1
-    pin_mechanics_in_vgprs(hv);
-    pin_quiet_in_vgprs(hv);
-#endif
+    // every-step float64 constants in VGPRs: all of them with 512 registers, the epilogue's and the quiet prelude's with 256
+    if (L == 1 || WEDM_REGS_PIN2 == 2) {
+        pin_hot_in_vgprs(hv);
+    } else if (WEDM_REGS_PIN2 == 1) {
+        pin_mechanics_in_vgprs(hv);
+        pin_quiet_in_vgprs(hv);
+    }
     const int tid = threadIdx.x;
-    const int64_t e = (int64_t)blockIdx.x * 256 + tid;
+    const int c = tid % L;  // this lane's part of the wire
+    const int64_t e = (int64_t)blockIdx.x * EPB + tid / L;
     const bool live = e < k.num_envs;
-    const WalkTable* __restrict__ wt = k.walk;  // two chunks of H cells
+    const bool writer = c == 0;
+    const WalkTable* __restrict__ wt = k.walk;  // 2 L chunks of H cells
     const int n = k.hot.n_seg;
     const int64_t stride = cold->s.stride;
+    const int base = c * 2 * H;  // this lane's first cell
 
     Env s;
     Geom g;
@@ -1960,25 +1979,26 @@ __global__ void __launch_bounds__(256, 1) wedm_step_regs(const KArgs k) {
     load_geom(k.hot, cold, live ? e : 0, g);
     if (live) load_env(cold, e, s);
     else { s.done = WEDM_DEAD_LANE; s.unwind = 0.0; s.h_base = 0.0f; s.h_zone = 0.0f; }
-    // the wire: word q = cells 4 q .. 4 q + 3 of this environment, 16 bytes per lane, consecutive lanes consecutive words
+    // the wire: word q = cells 4 q .. 4 q + 3 of this environment, 16 bytes per lane
     const int nq = (n + 3) >> 2;
     float* const Te = cold->s.T + (live ? e : 0) * 4;
+    const int q0 = base / 4;  // this lane's first word
     f2 P[H];
 #pragma unroll
     for (int q = 0; q < H / 4; ++q) {
-        const f4v a = (q < nq) ? *(const f4v*)(Te + (int64_t)q * stride * 4) : f4v{0.0f, 0.0f, 0.0f, 0.0f};
-        const f4v b = (H / 4 + q < nq) ? *(const f4v*)(Te + (int64_t)(H / 4 + q) * stride * 4) : f4v{0.0f, 0.0f, 0.0f, 0.0f};
+        const f4v a = (q0 + q < nq) ? *(const f4v*)(Te + (int64_t)(q0 + q) * stride * 4) : f4v{0.0f, 0.0f, 0.0f, 0.0f};
+        const f4v b = (q0 + H / 4 + q < nq) ? *(const f4v*)(Te + (int64_t)(q0 + H / 4 + q) * stride * 4) : f4v{0.0f, 0.0f, 0.0f, 0.0f};
 #pragma unroll
         for (int u = 0; u < 4; ++u) P[4 * q + u] = f2{a[u], b[u]};
     }
     const float spool = k.hot.spool, tref = k.hot.tref, alpha = k.hot.alpha, tdiel = k.hot.tdiel;
-    const bool reinit = live && s.done && WEDM_AUTORESET(cold);  // next-step autoreset
-    if (reinit) reinit_env(cold, e, s, true);
+    const bool reinit = live && s.done && WEDM_AUTORESET(cold);  // next-step autoreset (all lanes of the environment agree)
+    if (reinit) reinit_env(cold, e, s, writer);
     if (__any(reinit)) {
 #pragma unroll
         for (int m = 0; m < H; ++m) P[m] = reinit ? f2{spool, spool} : P[m];
     }
-    P[0].x = spool;  // wire cell 0 is held at the spool temperature (wire.py:83)
+    if (c == 0) P[0].x = spool;  // wire cell 0 is held at the spool temperature (wire.py:83)
     unfreeze_wire(k.hot, s);  // keep_stepping_terminated: the DONE row is `terminated` of the last step and freezes nothing
     const bool frozen0 = s.done;
     if (!s.done) {
@@ -1987,20 +2007,28 @@ __global__ void __launch_bounds__(256, 1) wedm_step_regs(const KArgs k) {
     }
     const uint32_t gid = k.hot.env_id_offset + (uint32_t)e;
 
-    // wave-uniform tile flags of the two chunks (bit t: the tile's first cell lies in the workpiece zone / between the contacts)
+    // tile flags of this lane's two chunks (bit t: the tile's first cell lies in the workpiece zone / between the contacts);
+    // wave-uniform with one lane per environment
     const int n_tiles = wt->n_tiles;
-    uint32_t zoneA = 0u, zoneB = 0u, jouleA = 0u, jouleB = 0u;
+    uint32_t zoneA = 0u, zoneB = 0u, jouleA = 0u, jouleB = 0u, joule_any = 0u;
     for (int t = 0; t < n_tiles; ++t) {
         const uint32_t lo = wt->zj[8 * t];
-        zoneA |= (lo & 1u) << t;          zoneB |= ((lo >> 1) & 1u) << t;
-        jouleA |= ((lo >> 16) & 1u) << t; jouleB |= ((lo >> 17) & 1u) << t;
+        zoneA |= ((lo >> (2 * c)) & 1u) << t;       zoneB |= ((lo >> (2 * c + 1)) & 1u) << t;
+        jouleA |= ((lo >> (16 + 2 * c)) & 1u) << t; jouleB |= ((lo >> (17 + 2 * c)) & 1u) << t;
+        joule_any |= ((lo >> 16) != 0u ? 1u : 0u) << t;
     }
-    zoneA = __builtin_amdgcn_readfirstlane(zoneA); zoneB = __builtin_amdgcn_readfirstlane(zoneB);
-    jouleA = __builtin_amdgcn_readfirstlane(jouleA); jouleB = __builtin_amdgcn_readfirstlane(jouleB);
+    if (L == 1) {
+        zoneA = __builtin_amdgcn_readfirstlane(zoneA); zoneB = __builtin_amdgcn_readfirstlane(zoneB);
+        jouleA = __builtin_amdgcn_readfirstlane(jouleA); jouleB = __builtin_amdgcn_readfirstlane(jouleB);
+    }
+    joule_any = __builtin_amdgcn_readfirstlane(joule_any);
     const uint32_t kind_n = __builtin_amdgcn_readfirstlane(wt->kind_n_mask);
     const uint32_t kind_ne = __builtin_amdgcn_readfirstlane(wt->kind_ne_mask), kind_nj = __builtin_amdgcn_readfirstlane(wt->kind_nj_mask);
-    // the wire's last cell: where a regular tile holds it, it is the last cell of chunk B's tile t_last
-    const uint32_t last_tile = (n > H) ? (1u << ((n - 1 - H) >> 3)) : 0u;
+    // the wire's last cell: where a regular tile holds it, it is the last cell of the LAST chunk's tile t_last (chunk B of
+    // the environment's last lane)
+    const int last_base = (2 * L - 1) * H;
+    const uint32_t last_tile = (n > last_base) ? (1u << ((n - 1 - last_base) >> 3)) : 0u;
+    const bool owns_last = c == L - 1;
 
     // the convection coefficient pair (chunk A, chunk B) of every tile: rebuilt where the general prelude may have refreshed
     // the lane's coefficients (the quiet one never does)
@@ -2018,7 +2046,7 @@ __global__ void __launch_bounds__(256, 1) wedm_step_regs(const KArgs k) {
         QuietTry qt;
         const bool was_quiet = quiet_prelude_t<WEDM_PACKED_DENSE>(hv, cold, g, e, gid, s, qt, cf);
         if (!was_quiet) {
-            if (!s.done) cf = scalar_prelude(hv, cold, g, e, gid, s, ps, true, qt);
+            if (!s.done) cf = scalar_prelude(hv, cold, g, e, gid, s, ps, writer, qt);
             build_conv();
         }
         freeze_wire(s);
@@ -2027,7 +2055,8 @@ __global__ void __launch_bounds__(256, 1) wedm_step_regs(const KArgs k) {
         // (what the rare code of a tile derives from these -- a lane mask per uniform predicate, one per tile or per cell
         // -- would otherwise be computed once before the loop and kept: a thousand scalar registers spilled into vector
         // lanes and read back on the hot path too.  Opaque per microsecond, the predicates are scalar compares where used.)
-        asm volatile("" : "+s"(zoneA), "+s"(zoneB), "+s"(jouleA), "+s"(jouleB));
+        if (L == 1) asm volatile("" : "+s"(zoneA), "+s"(zoneB), "+s"(jouleA), "+s"(jouleB));
+        else asm volatile("" : "+v"(zoneA), "+v"(zoneB), "+v"(jouleA), "+v"(jouleB));
         Geom gw = g;  // (uniform geometry: the same in every lane)
         gw.n_seg = __builtin_amdgcn_readfirstlane(g.n_seg); gw.az_start = __builtin_amdgcn_readfirstlane(g.az_start);
         gw.az_end = __builtin_amdgcn_readfirstlane(g.az_end); gw.cb = __builtin_amdgcn_readfirstlane(g.cb);
@@ -2035,6 +2064,18 @@ __global__ void __launch_bounds__(256, 1) wedm_step_regs(const KArgs k) {
         asm volatile("" : "+s"(gw.n_seg), "+s"(gw.az_start), "+s"(gw.az_end), "+s"(gw.cb), "+s"(gw.ct));
         int nw = __builtin_amdgcn_readfirstlane(n);
         asm volatile("" : "+s"(nw));
+        // the halos of this lane's two chunks, OLD values: T[base + H - 1] (left of chunk B) and T[base + H] (right of
+        // chunk A) are the lane's own; across lanes: the left of chunk A is the previous lane's last cell, the right of
+        // chunk B the next lane's first (every lane takes part in the exchange, frozen environments included)
+        const float a_last = P[H - 1].x, b_first = P[0].y;
+        float halo_l = spool, halo_r = 0.0f;
+        if (L == 2) {
+            // lane 0 needs lane 1's first cell (its P[0].x); lane 1 needs lane 0's last cell (its P[H - 1].y)
+            const float give = c == 0 ? P[H - 1].y : P[0].x;
+            const float got = __int_as_float(swap_with_neighbour(__float_as_int(give)));
+            halo_l = c == 0 ? spool : got;
+            halo_r = c == 0 ? got : 0.0f;
+        }
         if (act) {  // (the lanes of terminated environments sit the walk out: their registers stay)
             // a wave with a negative plasma heat walks every cell on the predicated formula (identical results, slower)
             const bool all_slow = __any(cf.q < 0.0f);
@@ -2042,8 +2083,8 @@ __global__ void __launch_bounds__(256, 1) wedm_step_regs(const KArgs k) {
             const float jf_lane = cf.joule_on ? cf.jf : 0.0f;
             const bool joule_wave = __any(jf_lane != 0.0f);
             const uint32_t n_now = all_slow ? 0u : (kind_n | kind_ne | (joule_wave ? 0u : kind_nj));
-            // the tiles that hold some lane's plasma cell
-            const int pcell = (cf.pidx >= 1) ? cf.pidx : -1;
+            // the tiles that hold some lane's plasma cell (a lane's own cells only)
+            const int pcell = (cf.pidx >= 1 && cf.pidx >= base && cf.pidx < base + 2 * H) ? cf.pidx - base : -1;  // lane-local
             uint32_t ptiles = 0u;
             if (__any(pcell >= 0)) {
                 const int pt = pcell >= 0 ? ((pcell & (H - 1)) >> 3) : -1;
@@ -2051,9 +2092,8 @@ __global__ void __launch_bounds__(256, 1) wedm_step_regs(const KArgs k) {
                 for (int t = 0; t < H / 8; ++t) ptiles |= __any(pt == t) ? (1u << t) : 0u;
             }
             // tiles that need more than the regular code without a Joule term
-            const uint32_t general = ~n_now | (joule_wave ? (jouleA | jouleB) : 0u) | ptiles | last_tile;
-            const float a_last = P[H - 1].x, b_first = P[0].y;  // OLD T[H - 1] (left of chunk B) and T[H] (right of chunk A)
-            f2 leftp = f2{spool, a_last};                         // OLD pair before the tile
+            const uint32_t general = ~n_now | (joule_wave ? joule_any : 0u) | ptiles | last_tile;
+            f2 leftp = f2{halo_l, a_last};  // OLD pair before the tile
 #pragma unroll
             for (int t = 0; t < H / 8; ++t) {
                 if (t < n_tiles) {
@@ -2063,7 +2103,7 @@ __global__ void __launch_bounds__(256, 1) wedm_step_regs(const KArgs k) {
                     for (int u = 0; u < 8; ++u) {
                         tc[u] = P[j + u];
                         tm[u] = u == 0 ? leftp : P[j + u - 1];
-                        tp[u] = (j + u + 1 < H) ? P[j + u + 1 < H ? j + u + 1 : 0] : f2{b_first, 0.0f};
+                        tp[u] = (j + u + 1 < H) ? P[j + u + 1 < H ? j + u + 1 : 0] : f2{b_first, halo_r};
                     }
                     leftp = tc[7];
                     f2 cv[4], jv[4];
@@ -2073,43 +2113,54 @@ __global__ void __launch_bounds__(256, 1) wedm_step_regs(const KArgs k) {
                     for (int u = 0; u < 4; ++u) { tmA[u] = tm[u]; tcA[u] = tc[u]; tpA[u] = tp[u]; tmB[u] = tm[4 + u]; tcB[u] = tc[4 + u]; tpB[u] = tp[4 + u]; }
                     if (!((general >> t) & 1u)) {
                         jv[0] = f2{0.0f, 0.0f};
-                        quad_staged<false, false, 4>(tmA, tcA, tpA, pnA, g.k, g.tuf, cv, tdiel, ps.adv, jv, alpha, tref);
-                        quad_staged<false, false, 4>(tmB, tcB, tpB, pnB, g.k, g.tuf, cv, tdiel, ps.adv, jv, alpha, tref);
+                        quad_staged<false, false, SW>(tmA, tcA, tpA, pnA, g.k, g.tuf, cv, tdiel, ps.adv, jv, alpha, tref);
+                        quad_staged<false, false, SW>(tmB, tcB, tpB, pnB, g.k, g.tuf, cv, tdiel, ps.adv, jv, alpha, tref);
 #pragma unroll
                         for (int u = 0; u < 4; ++u) { pn[u] = pnA[u]; pn[4 + u] = pnB[u]; }
-                        if (t == 0) pn[0].x = spool;  // wire cell 0
+                        if (t == 0) pn[0].x = (c == 0) ? spool : pn[0].x;  // wire cell 0
                         float m0 = max3_raw(tmax, pn[0].x, pn[0].y), m1 = max3_raw(pn[1].x, pn[1].y, pn[2].x);
                         m0 = max3_raw(m0, pn[2].y, pn[3].x); m1 = max3_raw(m1, pn[3].y, pn[4].x);
                         m0 = max3_raw(m0, pn[4].y, pn[5].x); m1 = max3_raw(m1, pn[5].y, pn[6].x);
                         m0 = max3_raw(m0, pn[6].y, pn[7].x);
                         tmax = max3_raw(m0, m1, pn[7].y);
-                    } else if ((n_now >> t) & 1u) {
+                    } else if (((n_now | (all_slow ? 0u : kind_nj)) >> t) & 1u) {
                         // regular, with odd cells: a Joule term, the wire's last cell, plasma cells
                         jv[0] = f2{((jouleA >> t) & 1u) ? jf_lane : 0.0f, ((jouleB >> t) & 1u) ? jf_lane : 0.0f};
-                        if (joule_wave && (((jouleA | jouleB) >> t) & 1u)) {
-                            quad_staged<true, false, 4>(tmA, tcA, tpA, pnA, g.k, g.tuf, cv, tdiel, ps.adv, jv, alpha, tref);
-                            quad_staged<true, false, 4>(tmB, tcB, tpB, pnB, g.k, g.tuf, cv, tdiel, ps.adv, jv, alpha, tref);
+                        if (!((n_now >> t) & 1u)) {
+                            // a contact index inside the tile while current flows (kind_nj; the zone flag is uniform): the Joule
+                            // coefficient cell by cell from the table
+                            f2 jq[8];
+#pragma unroll
+                            for (int u = 0; u < 8; ++u) {
+                                const uint32_t zj = wt->zj[j + u];
+                                jq[u] = f2{((zj >> (16 + 2 * c)) & 1u) ? jf_lane : 0.0f, ((zj >> (17 + 2 * c)) & 1u) ? jf_lane : 0.0f};
+                            }
+                            f2 jvA[4], jvB[4];
+#pragma unroll
+                            for (int u = 0; u < 4; ++u) { jvA[u] = jq[u]; jvB[u] = jq[4 + u]; }
+                            quad_staged<true, true, SW>(tmA, tcA, tpA, pnA, g.k, g.tuf, cv4(cv[0]).v, tdiel, ps.adv, jvA, alpha, tref);
+                            quad_staged<true, true, SW>(tmB, tcB, tpB, pnB, g.k, g.tuf, cv4(cv[0]).v, tdiel, ps.adv, jvB, alpha, tref);
+                        } else if (joule_wave && ((joule_any >> t) & 1u)) {
+                            quad_staged<true, false, SW>(tmA, tcA, tpA, pnA, g.k, g.tuf, cv, tdiel, ps.adv, jv, alpha, tref);
+                            quad_staged<true, false, SW>(tmB, tcB, tpB, pnB, g.k, g.tuf, cv, tdiel, ps.adv, jv, alpha, tref);
                         } else {
-                            quad_staged<false, false, 4>(tmA, tcA, tpA, pnA, g.k, g.tuf, cv, tdiel, ps.adv, jv, alpha, tref);
-                            quad_staged<false, false, 4>(tmB, tcB, tpB, pnB, g.k, g.tuf, cv, tdiel, ps.adv, jv, alpha, tref);
+                            quad_staged<false, false, SW>(tmA, tcA, tpA, pnA, g.k, g.tuf, cv, tdiel, ps.adv, jv, alpha, tref);
+                            quad_staged<false, false, SW>(tmB, tcB, tpB, pnB, g.k, g.tuf, cv, tdiel, ps.adv, jv, alpha, tref);
                         }
 #pragma unroll
                         for (int u = 0; u < 4; ++u) { pn[u] = pnA[u]; pn[4 + u] = pnB[u]; }
-                        if (t == 0) pn[0].x = spool;  // wire cell 0
-                        // the last cell (last position of chunk B's tile): out of the regular maximum, predicated formula
-                        const bool has_last = (last_tile >> t) & 1u;
-                        float m0 = fmax_gt(pn[0].x, pn[0].y), m1 = fmax_gt(pn[1].x, pn[1].y);
-#pragma unroll
-                        for (int u = 2; u < 6; u += 2) {
-                            m0 = fmax_gt(m0, fmax_gt(pn[u].x, pn[u].y));
-                            m1 = fmax_gt(m1, fmax_gt(pn[u + 1].x, pn[u + 1].y));
-                        }
-                        m0 = fmax_gt(m0, fmax_gt(pn[6].x, pn[6].y));
-                        m1 = fmax_gt(m1, fmax_gt(pn[7].x, has_last ? spool : pn[7].y));
-                        tmax = fmax_gt(tmax, fmax_gt(m0, m1));
-                        if (has_last) {
-                            pn[7].y = stencil_cell(H + j + 7, nw, (H + j + 7 == 1) ? spool : tm[7].y, tc[7].y, 0.0f, gw, cf, ps, tref, alpha, tdiel);
-                            tmax = fmax_gt(tmax, pn[7].y);
+                        if (t == 0) pn[0].x = (c == 0) ? spool : pn[0].x;  // wire cell 0
+                        // the last cell (last position of the last chunk's tile): out of the regular maximum, predicated formula
+                        const bool has_last = ((last_tile >> t) & 1u) && owns_last;
+                        float m0 = max3_raw(tmax, pn[0].x, pn[0].y), m1 = max3_raw(pn[1].x, pn[1].y, pn[2].x);
+                        m0 = max3_raw(m0, pn[2].y, pn[3].x); m1 = max3_raw(m1, pn[3].y, pn[4].x);
+                        m0 = max3_raw(m0, pn[4].y, pn[5].x); m1 = max3_raw(m1, pn[5].y, pn[6].x);
+                        m0 = max3_raw(m0, pn[6].y, pn[7].x);
+                        tmax = max3_raw(m0, m1, has_last ? spool : pn[7].y);
+                        if ((last_tile >> t) & 1u) {
+                            const float x = stencil_cell(base + H + j + 7, nw, tm[7].y, tc[7].y, 0.0f, gw, cf, ps, tref, alpha, tdiel);
+                            pn[7].y = has_last ? x : pn[7].y;
+                            tmax = has_last ? fmax_gt(tmax, x) : tmax;
                         }
                         // plasma cells of the lanes that have one in this tile: the predicated formula from the same OLD values
                         // (the regular value stays in the maximum, as where the LDS kernels patch the cell after the walk)
@@ -2117,12 +2168,12 @@ __global__ void __launch_bounds__(256, 1) wedm_step_regs(const KArgs k) {
 #pragma unroll
                             for (int u = 0; u < 8; ++u) {
                                 if (__any(pcell == j + u)) {
-                                    const float x = stencil_cell(j + u, nw, (j + u == 1) ? spool : tm[u].x, tc[u].x, tp[u].x, gw, cf, ps, tref, alpha, tdiel);
+                                    const float x = stencil_cell(base + j + u, nw, (base + j + u == 1) ? spool : tm[u].x, tc[u].x, tp[u].x, gw, cf, ps, tref, alpha, tdiel);
                                     pn[u].x = (pcell == j + u) ? x : pn[u].x;
                                     tmax = (pcell == j + u) ? fmax_gt(tmax, x) : tmax;
                                 }
                                 if (__any(pcell == H + j + u)) {
-                                    const float x = stencil_cell(H + j + u, nw, tm[u].y, tc[u].y, tp[u].y, gw, cf, ps, tref, alpha, tdiel);
+                                    const float x = stencil_cell(base + H + j + u, nw, tm[u].y, tc[u].y, tp[u].y, gw, cf, ps, tref, alpha, tdiel);
                                     pn[u].y = (pcell == H + j + u) ? x : pn[u].y;
                                     tmax = (pcell == H + j + u) ? fmax_gt(tmax, x) : tmax;
                                 }
@@ -2133,16 +2184,16 @@ __global__ void __launch_bounds__(256, 1) wedm_step_regs(const KArgs k) {
 #pragma unroll
                         for (int u = 0; u < 8; ++u) {
                             pn[u] = tc[u];
-                            const int ia = j + u, ib = H + j + u;
-                            if (ia < nw) {
+                            const int ia = base + j + u, ib = base + H + j + u;
+                            {
                                 const float x = (ia >= 1) ? stencil_cell(ia, nw, (ia == 1) ? spool : tm[u].x, tc[u].x, tp[u].x, gw, cf, ps, tref, alpha, tdiel) : spool;
-                                pn[u].x = x;
-                                tmax = fmax_gt(tmax, x);
+                                pn[u].x = ia < nw ? x : pn[u].x;
+                                tmax = ia < nw ? fmax_gt(tmax, x) : tmax;
                             }
-                            if (ib < nw) {
+                            {
                                 const float x = stencil_cell(ib, nw, tm[u].y, tc[u].y, tp[u].y, gw, cf, ps, tref, alpha, tdiel);
-                                pn[u].y = x;
-                                tmax = fmax_gt(tmax, x);
+                                pn[u].y = ib < nw ? x : pn[u].y;
+                                tmax = ib < nw ? fmax_gt(tmax, x) : tmax;
                             }
                         }
                     }
@@ -2151,27 +2202,31 @@ __global__ void __launch_bounds__(256, 1) wedm_step_regs(const KArgs k) {
                 }
             }
         }
+        if (L == 2) tmax = fmax_gt(tmax, __int_as_float(swap_with_neighbour(__float_as_int(tmax))));
         unfreeze_wire(hv, s);
         if (!s.done) {
             scalar_epilogue(hv, s, tmax);
-            if (s.ctrl) control_step_outputs(cold, e, s, true);
+            if (s.ctrl) control_step_outputs(cold, e, s, writer);
         }
     }
 
     if (live) {
 #pragma unroll
-        for (int q = 0; q < CELLS / 4; ++q) {
+        for (int q = 0; q < 2 * H / 4; ++q) {
             const int m = (q % (H / 4)) * 4;
             const bool hi = q >= H / 4;
             const f4v w = hi ? f4v{P[m].y, P[m + 1].y, P[m + 2].y, P[m + 3].y} : f4v{P[m].x, P[m + 1].x, P[m + 2].x, P[m + 3].x};
-            if (4 * q + 3 < n) {
-                *(f4v*)(Te + (int64_t)q * stride * 4) = w;
+            const int cell = base + 4 * q;
+            if (cell + 3 < n) {
+                *(f4v*)(Te + (int64_t)(q0 + q) * stride * 4) = w;
             } else {  // the wire's last, partial word: the cells past the end are padding and keep their value
 #pragma unroll
                 for (int u = 0; u < 4; ++u)
-                    if (4 * q + u < n) Te[(int64_t)q * stride * 4 + u] = w[u];
+                    if (cell + u < n) Te[(int64_t)(q0 + q) * stride * 4 + u] = w[u];
             }
         }
+    }
+    if (live && writer) {
         if (WEDM_REWARD_ON(cold)) {
             if (!frozen0) write_reward(cold, e, s);
             else cold->s.reward[e] = 0.0f;  // a frozen environment earns nothing (not the previous launch's reward)
@@ -3049,6 +3104,15 @@ static int32_t plan_launch(wedm_ctx* ctx, bool single, bool tr, bool frozen_ok, 
             return fail(ctx, WEDM_ERR_UNSUPPORTED, "wedm_step: stencil_mode 1 (float64 stencil expressions) runs on kernels 1, 2 and 3 only");
         if (variant == 0) variant = (!single && fused_ok) ? 3 : (lanes_ok ? 2 : 1);
     }
+    // kernel 7 (register kernel): one or two lanes per environment with the wire in their registers; wires of at most 128
+    // segments, uniform geometry, float32 stencil; it has no trace point: a launch with a trace sample takes the LDS kernels
+    const bool regs_ok = uniform && ctx->walk_regs_ok && ctx->n_seg_max <= 128 && !f64 && !ctx->replay;
+    if (variant == 0) {
+        // fused launches of a batch that gives every CU a block of the register kernel (measured, 128 segments, two lanes
+        // per environment against the best LDS kernel: 8 192 environments 2.8e9 vs 3.5e9, 16 384: 5.6e9 vs 6.1e9,
+        // 32 768: 1.10e10 vs 9.8e9, 65 536: 1.67e10 vs 1.44e10, 131 072: 1.76e10 vs 1.50e10)
+        if (!single && !tr && regs_ok && ctx->lanes == 0 && ctx->num_envs >= 32768) variant = 7;
+    }
     if (variant == 0) {
         // single-microsecond launches: the stream kernel where one round of blocks covers the batch with chunks of
         // at most 64 cells (measured: 27.5 vs 30.3 us at 65 536 x 128, 20.5 vs 24.9 us at 4 096 x 400), else the
@@ -3058,9 +3122,6 @@ static int32_t plan_launch(wedm_ctx* ctx, bool single, bool tr, bool frozen_ok, 
         else if (fused_ok) variant = 3;
         else variant = lanes_ok ? 2 : 1;
     }
-    // kernel 7 (register kernel): one environment per lane, wires of at most 128 segments, uniform geometry, float32 stencil;
-    // it has no trace point: a launch with a trace sample takes the LDS kernels
-    const bool regs_ok = uniform && ctx->walk_regs_ok && ctx->n_seg_max <= 128 && !f64 && !ctx->replay;
     if (variant == 7 && !regs_ok)
         return fail(ctx, WEDM_ERR_UNSUPPORTED, "wedm_step: register kernel needs uniform geometry, at most 128 segments and the float32 stencil");
     if (variant == 7 && tr) variant = packed_ok ? 4 : fused_ok ? 3 : lanes_ok ? 2 : 1;
@@ -3084,10 +3145,11 @@ static int32_t plan_launch(wedm_ctx* ctx, bool single, bool tr, bool frozen_ok, 
                  : (tr ? (const void*)wedm_step_global<true, false, false> : (const void*)wedm_step_global<false, false, false>);
         std::snprintf(out.name, sizeof(out.name), "wedm_step_global%s<<<%d,256>>>", ctx->replay ? "[injected variates]" : f64 ? "[f64 stencil]" : "", grid);
     } else if (variant == 7) {
-        grid = (ctx->num_envs + 255) / 256;
-        out.walk = ctx->walk_dev + 10;  // the table of two chunks of 64 cells
-        fn = (const void*)wedm_step_regs<128>;
-        std::snprintf(out.name, sizeof(out.name), "wedm_step_regs<128><<<%d,256>>>", grid);
+        const int rl = ctx->lanes == 1 ? 1 : 2;  // lanes per environment (default 2: two waves per SIMD)
+        grid = (ctx->num_envs + 256 / rl - 1) / (256 / rl);
+        out.walk = ctx->walk_dev + (rl == 1 ? 10 : 11);  // two chunks of 64 cells / four of 32
+        fn = rl == 1 ? (const void*)wedm_step_regs<128, 1> : (const void*)wedm_step_regs<128, 2>;
+        std::snprintf(out.name, sizeof(out.name), "wedm_step_regs<%d><<<%d,256>>>", rl, grid);
     } else if (variant == 5) {
         grid = (ctx->num_envs + 63) / 64;
         fn = tr ? (const void*)wedm_step_split<true> : (const void*)wedm_step_split<false>;
@@ -3241,7 +3303,7 @@ int32_t wedm_create(const wedm_params* params, int32_t num_envs, int32_t n_seg_m
         return WEDM_ERR_HIP;
     }
     if (!params->per_env_geometry) {
-        std::vector<WalkTable> host_tabs(11);  // [10]: two chunks of exactly 64 cells (register kernel)
+        std::vector<WalkTable> host_tabs(12);  // [10], [11]: two chunks of exactly 64 cells, four of 32 (register kernel)
         const int Ls[5] = {1, 2, 4, 8, 16};
         for (int i = 0; i < 5; ++i) {
             ctx->walk_ok[i] = build_walk(*params, Ls[i], host_tabs[i]);
@@ -3249,7 +3311,8 @@ int32_t wedm_create(const wedm_params* params, int32_t num_envs, int32_t n_seg_m
             if (ctx->walk_ok[i] && (host_tabs[i].kind_n1_mask & 0x80000000u)) ctx->walk_n1z |= 1u << i;
             ctx->walk4_ok[i] = build_walk(*params, Ls[i], host_tabs[5 + i], 4);
             ctx->walk4_C[i] = host_tabs[5 + i].C;
-            if (i == 0) ctx->walk_regs_ok = params->n_seg <= 128 && build_walk(*params, 2, host_tabs[10], 64) && host_tabs[10].C == 64;
+            if (i == 0) ctx->walk_regs_ok = params->n_seg <= 128 && build_walk(*params, 2, host_tabs[10], 64) && host_tabs[10].C == 64 &&
+                                            build_walk(*params, 4, host_tabs[11], 32) && host_tabs[11].C == 32;
         }
         const size_t tab_bytes = host_tabs.size() * sizeof(WalkTable);
         if ((e = hipMalloc((void**)&ctx->walk_dev, tab_bytes)) != hipSuccess ||

@@ -426,7 +426,7 @@ def test_full_size_fusion_and_sharding_invariance():
     act = a_env.make_action(0.1, 80.0, 5, 3.0, 80.0)
     a_env.step_many(act, 1000)
     a_env.step_many(act, 300)
-    assert "wedm_step_packed" in a_env._backend.last_kernel()
+    assert "wedm_step_regs<2>" in a_env._backend.last_kernel()
     for _ in range(1300):
         b_env.step(act)
     assert "wedm_step_stream<2>" in b_env._backend.last_kernel()
@@ -755,9 +755,15 @@ def test_full_headline_batch_matches_oracle_bit_for_bit():
         act = env.make_action(0.1, 80.0, 5, 3.0, 80.0)
         env.step_many(act, 1000)
         env.step_many(act, 1000)
-    assert "wedm_step_packed<2>" in gpu._backend.last_kernel()
+    assert "wedm_step_regs<2>" in gpu._backend.last_kernel()
     check(gpu, cpu, n)
     assert int(gpu.state.spark_count.sum()) > 50000
+    # the LDS kernel that ran this workload before the register kernel existed, same bytes
+    gpu.set_kernel(4, 2)
+    for env in (gpu, cpu):
+        env.step_many(env.make_action(0.1, 80.0, 5, 3.0, 80.0), 1000)
+    assert "wedm_step_packed<2>" in gpu._backend.last_kernel()
+    check(gpu, cpu, n)
 
 
 @pytest.mark.parametrize("k", range(8))
@@ -1456,7 +1462,7 @@ def test_register_kernel_one_environment_per_lane_matches_oracle(mode):
         env.state.wire_unwinding_velocity[::7] = 0.0                                  # mixed advection inside a wave
         for k in (1, 900, 600):
             env.step_many(a, k)
-    assert "wedm_step_regs<128>" in gpu._backend.last_kernel()
+    assert "wedm_step_regs<" in gpu._backend.last_kernel()
     check(gpu, cpu, n)
     st = gpu.state
     assert int(st.spark_count.sum()) > 10 * n
