@@ -15,8 +15,9 @@ weak scaling.  ``--workload config2`` selects num_envs 4096 / 400 segments inste
 Prints ONE JSON line (rank 0).
 
 ``roofline`` names the resource that binds the dominant kernel.  The fused launches keep the wire
-in LDS for 1000 us, so HBM sees each byte once per launch (~0.3 % of peak) and the kernel is bound
-by vector-ALU ISSUE: ``achieved`` = wave-level VALU instructions per launch (SQ_INSTS_VALU from a
+on the chip for 1000 us (in the lanes' registers: wedm_step_regs, the kernel of the headline batch;
+in LDS: the kernels of longer wires and smaller batches), so HBM sees each byte once per launch
+(~0.3 % of peak) and the kernel is bound by vector-ALU ISSUE: ``achieved`` = wave-level VALU instructions per launch (SQ_INSTS_VALU from a
 separate rocprofv3 --pmc pass of this same command, recorded in profiles/valu.json) / the kernel
 duration measured live with HIP events on the launch stream; ``peak`` = 256 CUs x 4 SIMDs x
 2.4 GHz / 2 cycles per wave64 instruction = 1.2288e12 wave-instr/s (MI355X_MICROARCH.md: a wave64
@@ -235,7 +236,8 @@ def roofline_block(kernel_name, kernel_ms, n_envs, n_sub, n_seg, traffic_overrid
         out["achieved"] = None
         out["frac"] = None
         out["source"] = valu_why
-    out["note"] = ("the fused launch keeps the wire in LDS for all its microseconds: HBM sees each byte once per launch, "
+    where = "in the lanes' registers" if "wedm_step_regs" in kernel_name else "in LDS"
+    out["note"] = (f"the fused launch keeps the wire {where} for all its microseconds: HBM sees each byte once per launch, "
                    "the kernel is bound by VALU issue; frac = wave-level VALU instructions per second / (1024 SIMDs x 2.4 GHz / 2)")
     return out
 
@@ -334,9 +336,10 @@ def side_measurements(n_local, wire, S, device):
                 "resets_per_env_per_launch": (int(env.state.episode.sum().item()) - e0) / n_local / 20.0,
                 "timing": "wall clock around 20 launches of 1000 us"})
     env.close()
-    # the same batch WITHOUT autoreset: terminated environments stay frozen until the host resets them.  The first launch that
-    # finds one reports it to the host (a host-visible word, no synchronisation) and the handle moves to the kernel
-    # instantiation whose tile code tolerates frozen lanes; before, such a wave fell back to the per-cell predicated path.
+    # the same batch WITHOUT autoreset: terminated environments stay frozen until the host resets them.  The register
+    # kernel walks under the mask of the live lanes (frozen lanes keep their registers); a handle on the LDS kernels
+    # moves by itself to the instantiation whose tile code tolerates frozen lanes (the first launch that finds one reports
+    # it through a host-visible word); before, such a wave fell back to the per-cell predicated path.
     env = WireEDMEnv(num_envs=n_local, device=device, wire_params=wire, config=EnvironmentConfig(target_cutting_distance=50.002))
     env.reset(seed=7)
     act = env.make_action(0.1, 80.0, 5, 3.0, 80.0)

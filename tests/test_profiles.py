@@ -61,17 +61,18 @@ def test_headline_roofline_recomputes_from_profiles():
     # value, ms_per_step and the kernel duration tell one story; rocprofv3 agrees with the HIP events
     assert b["value"] == pytest.approx(65536 * 1000 / (b["ms_per_step"] * 1e-3), rel=1e-9)
     assert rf["kernel_ms"] <= b["ms_per_step"] * 1.001
-    avg_ms, calls = rocprof_avg_ms("rocprofv3_kernel_stats_config3.csv", "wedm_step_packed<2, false, false, false>")
+    assert "wedm_step_regs<2>" in kernel                                # the wire in the lanes' registers, two lanes per environment
+    avg_ms, calls = rocprof_avg_ms("rocprofv3_kernel_stats_config3.csv", "wedm_step_regs<128, 2>")
     assert calls >= 20 and avg_ms == pytest.approx(rf["kernel_ms"], rel=0.03)
     # traffic well above the algorithmic minimum would mean wasted re-reads: T + state in and out + obs = ~102 MB
     assert traffic["hbm_bytes_per_launch"] < 1.2 * 102e6
     assert b["cpu_baseline"]["kind"] == "port" and b["cpu_baseline"]["cores"] >= 1
     assert len(b["side"]) == 5 and b["side"][3]["resets_per_env_per_launch"] > 0.05
-    # a handle WITHOUT autoreset whose batch holds terminated (frozen) environments: its launches take as long as the quiet
-    # headline's to within 5 % (the handle moved to the frozen-lane tile code by itself)
+    # a handle WITHOUT autoreset whose batch holds terminated (frozen) environments: its launches take no longer than the
+    # quiet headline's (the register kernel walks under the mask of the live lanes; a wave of frozen lanes only skips work)
     frozen = b["side"][4]
-    assert frozen["frozen_fraction"] > 0.1 and "[frozen lanes ok]" in frozen["kernel"]
-    assert frozen["kernel_ms"] == pytest.approx(rf["kernel_ms"], rel=0.05)
+    assert frozen["frozen_fraction"] > 0.1 and "wedm_step_regs<2>" in frozen["kernel"]
+    assert frozen["kernel_ms"] <= rf["kernel_ms"] * 1.05
     # the VALU pipe's occupancy, from one counter pass (SQ_ACTIVE_INST_VALU / SQ_WAVE_CYCLES per resident wave)
     sqv = {l.split("\t")[2]: float(l.split("\t")[3]) for l in (R / "rocprofv3_pmc_sq_config3.txt").read_text().splitlines()}
     assert rf["valu_pipe_busy"]["frac"] == pytest.approx(sqv["SQ_ACTIVE_INST_VALU"] / (sqv["SQ_WAVE_CYCLES"] / 2.0), rel=1e-6)
