@@ -8,7 +8,9 @@
 //   wedm_step_split  : single microseconds where the stream kernel does not fit: the wire cut over the four waves of
 //                      a block, in place in global memory.
 //   wedm_step_stream<L>: single microseconds (the reference's step() cadence), uniform geometry: the whole chunk of a
-//                      lane requested up front into registers, one tile walk in LDS, no barrier.
+//                      lane requested up front into registers, one tile walk, no barrier.  Launches of exactly one
+//                      microsecond have their own instantiation: the walk runs out of those registers (packed pairs of
+//                      adjacent cells), every tile stored where it is computed; otherwise the walk is the LDS one.
 //   wedm_step_lanes<L>: any geometry (one (h, d) pair per environment: BASELINE config 5).  L lanes per environment,
 //                      wire chunks in LDS; interior formula stage-major with per-cell coefficients from the lane's own
 //                      indices, boundary / plasma cells patched (the per-cell predicated walk remains as fallback).
@@ -19,7 +21,11 @@
 //                      inputs -> bit-identical results).  The walk follows a host-built, wave-uniform TILE TABLE
 //                      (build_walk): regular tiles of 8 cells run stage-major without a per-cell predicate; boundary,
 //                      plasma and tail cells are patched from values computed before the walk.
-//   wedm_step_packed<L>: the same with two chunks per lane advanced together in float2 registers (the headline kernel).
+//   wedm_step_packed<L>: the same with two chunks per lane advanced together in float2 registers.
+//   wedm_step_regs<CELLS, L>: wires of at most 128 segments, uniform geometry: the wire lives in the registers of the L
+//                      (1 or 2) lanes of its environment for the whole launch, as packed pairs of two virtual chunks; no
+//                      LDS, halos between the two lanes by DPP, one wave-uniform mask per microsecond picks the tiles that
+//                      need more than 88 packed operations.  The headline kernel (65 536 x 128: two lanes per environment).
 //   wedm_reset_kernel: WireEDMEnv.reset for a masked subset.
 // The packed / fused kernels exist in several instantiations (signal trace point, FROZEN_OK for autoreset handles,
 // N1 / EXTRA for tile tables with one-change tiles or short tails): code that costs the other launches 1-2 % by its
