@@ -1943,6 +1943,9 @@ __device__ __forceinline__ float max3_raw(float a, float b, float c) {
     return r;
 }
 
+#ifndef WEDM_REGS_DENSE
+#define WEDM_REGS_DENSE WEDM_PACKED_DENSE  // the quiet line also carries sparks that keep burning or end (see WEDM_PACKED_DENSE)
+#endif
 #ifndef WEDM_REGS_SW2
 #define WEDM_REGS_SW2 2
 #endif
@@ -2050,7 +2053,7 @@ __global__ void __launch_bounds__(256, L) wedm_step_regs(const KArgs k) {
         if (__all(s.done)) break;
         Coef cf{0.0f, 0.0f, 0, -1};
         QuietTry qt;
-        const bool was_quiet = quiet_prelude_t<WEDM_PACKED_DENSE>(hv, cold, g, e, gid, s, qt, cf);
+        const bool was_quiet = quiet_prelude_t<WEDM_REGS_DENSE>(hv, cold, g, e, gid, s, qt, cf);
         if (!was_quiet) {
             if (!s.done) cf = scalar_prelude(hv, cold, g, e, gid, s, ps, writer, qt);
             build_conv();
