@@ -1,3 +1,6 @@
+#!/bin/bash
+# tools/regs_sweep.sh: 128-segment batches of 8 192 ... 131 072 environments, fused launches of 1000 us: the automatic kernel
+# choice against the register kernel forced (--kernel 7), then the full bench line with its side measurements on kernel 7
 OUT=gpurun_out/regs_sweep; mkdir -p $OUT
 for N in 8192 16384 32768 49152 65536 131072; do
  for K in 0 7; do
