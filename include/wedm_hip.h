@@ -403,7 +403,8 @@ int64_t wedm_trace_samples(wedm_ctx* ctx);
  * per-cell coefficients, no stage-major / packed form).                                          */
 int32_t wedm_set_kernel(wedm_ctx* ctx, int32_t variant);
 
-/* lanes that share one environment in kernels 2, 3, 4 and 6: 0 = auto, or 1, 2, 4, 8 (16: not kernel 4) */
+/* lanes that share one environment in kernels 2, 3, 4 and 6: 0 = auto, or 1, 2, 4, 8 (16: not kernel 4); kernel 7: 1, anything
+ * else = 2.  A lane count set here also keeps the automatic choice (kernel 0) off the register kernel.              */
 int32_t wedm_set_lanes(wedm_ctx* ctx, int32_t lanes);
 
 /* name / launch geometry of the kernel the last wedm_step used (for profiles) */
