@@ -2246,6 +2246,298 @@ __global__ void __launch_bounds__(256, L) wedm_step_regs(const KArgs k) {
 }
 
 
+// ============================================ wide register kernel: long wires of a SMALL batch in registers
+// Wires of up to 2 H L (512) segments, uniform geometry, float32 stencil, launches without a trace sample.
+// The case it is for is 4 096 x 400: a batch that gives the chip one wave per SIMD whatever the kernel, so a launch's
+// time is the dependent chain of ONE wave per microsecond, and what shortens the chain is fewer cells per lane and no
+// LDS round trip inside it.  L = 16 lanes -- one DPP row -- own an environment; a lane holds 2 H = 32 cells as H = 16
+// packed pairs P[m] = (T[base + m], T[base + H + m]) (two virtual chunks, as in wedm_step_regs): two tiles per microsecond.
+// What differs from wedm_step_regs:
+//   * no walk table.  The wire need not fill the lanes: lane c's cells 32 c .. 32 c + 31 that lie past the wire's end are
+//     PADDING -- loaded as zeros, advanced like interior cells (the packed operations compute both halves of a pair
+//     anyway), never stored, kept out of the maximum by one select per half and tile, and never read by a real cell
+//     (the wire's last cell takes the predicated formula, which has no right neighbour).
+//   * zone and contact flags per CELL, from the geometry's indices, as registers: a convection coefficient pair per
+//     pair of cells (rebuilt when the general prelude refreshes the coefficients) and a 0 / 1 Joule mask pair; a tile is
+//     regular whatever flags change inside it.  What is left for the predicated per-cell code is a tile that the wire's
+//     end cuts (n_seg not a multiple of 8) and a wave with a negative plasma heat.
+//   * halos between the lanes of an environment by DPP row shifts, the maximum over them by DPP quad / row mirrors.
+__device__ __forceinline__ float dpp_row_shr1(float old, float x) {  // lane i <- lane i - 1 of its row of 16; lane 0 keeps `old`
+    return __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(old), __float_as_int(x), 0x111, 0xF, 0xF, false));
+}
+__device__ __forceinline__ float dpp_row_shl1(float old, float x) {  // lane i <- lane i + 1; lane 15 keeps `old`
+    return __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(old), __float_as_int(x), 0x101, 0xF, 0xF, false));
+}
+template <int CTRL>
+__device__ __forceinline__ float dpp_perm(float x) {
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), CTRL, 0xF, 0xF, false));
+}
+
+#ifndef WEDM_WIDE_MIN_BLOCKS
+#define WEDM_WIDE_MIN_BLOCKS 1
+#endif
+#ifndef WEDM_WIDE_AUTO_MAX_ENVS
+#define WEDM_WIDE_AUTO_MAX_ENVS 4096  // one block of 16 environments per CU
+#endif
+template <int H, int L>
+__global__ void __launch_bounds__(256, WEDM_WIDE_MIN_BLOCKS) wedm_step_regs_wide(const KArgs k) {
+    static_assert(H % 8 == 0 && H <= 32, "whole tiles");
+    static_assert(L == 4 || L == 8 || L == 16, "the lanes of an environment lie in one DPP row");
+    constexpr int EPB = 256 / L;
+    constexpr int SW = 4;  // pairs per stage: a wave alone on its SIMD needs the distance between dependent operations
+    const ColdRef cold = kernarg_cold();
+    Hot hv = k.hot;
+    pin_hot_in_vgprs(hv);
+    const int tid = threadIdx.x;
+    const int c = tid % L;  // this lane's part of the wire
+    const int64_t e = (int64_t)blockIdx.x * EPB + tid / L;
+    const bool live = e < k.num_envs;
+    const bool writer = c == 0;
+    const int n = k.hot.n_seg;
+    const int64_t stride = cold->s.stride;
+    const int base = c * 2 * H;  // this lane's first cell
+
+    Env s;
+    Geom g;
+    Persist ps{0.0f, 0.0f, 0.0f, 0};
+    load_geom(k.hot, cold, live ? e : 0, g);
+    if (live) load_env(cold, e, s);
+    else { s.done = WEDM_DEAD_LANE; s.unwind = 0.0; s.h_base = 0.0f; s.h_zone = 0.0f; }
+    // the wire: word q = cells 4 q .. 4 q + 3 of this environment, 16 bytes per lane; words past the end: zeros (padding)
+    const int nq = (n + 3) >> 2;
+    float* const Te = cold->s.T + (live ? e : 0) * 4;
+    const int q0 = base / 4;  // this lane's first word
+    f2 P[H];
+#pragma unroll
+    for (int q = 0; q < H / 4; ++q) {
+        const f4v a = (q0 + q < nq) ? *(const f4v*)(Te + (int64_t)(q0 + q) * stride * 4) : f4v{0.0f, 0.0f, 0.0f, 0.0f};
+        const f4v b = (q0 + H / 4 + q < nq) ? *(const f4v*)(Te + (int64_t)(q0 + H / 4 + q) * stride * 4) : f4v{0.0f, 0.0f, 0.0f, 0.0f};
+#pragma unroll
+        for (int u = 0; u < 4; ++u) P[4 * q + u] = f2{a[u], b[u]};
+    }
+    const float spool = k.hot.spool, tref = k.hot.tref, alpha = k.hot.alpha, tdiel = k.hot.tdiel;
+    const bool reinit = live && s.done && WEDM_AUTORESET(cold);  // next-step autoreset (all lanes of the environment agree)
+    if (reinit) reinit_env(cold, e, s, writer);
+    if (__any(reinit)) {
+#pragma unroll
+        for (int m = 0; m < H; ++m) P[m] = reinit ? f2{spool, spool} : P[m];
+    }
+    if (c == 0) P[0].x = spool;  // wire cell 0 is held at the spool temperature (wire.py:83)
+    unfreeze_wire(k.hot, s);  // keep_stepping_terminated: the DONE row is `terminated` of the last step and freezes nothing
+    const bool frozen0 = s.done;
+    if (!s.done) {
+        s.ipk = peak_current(cold, s.mode, e);
+        init_persist(k.hot, cold, e, s, ps);
+    }
+    const uint32_t gid = k.hot.env_id_offset + (uint32_t)e;
+
+    // cells of this lane's two chunks that exist (0 .. H each), per-cell flags as bit masks (bit m: cell m of the chunk)
+    const int nA = min(max(n - base, 0), H), nB = min(max(n - base - H, 0), H);
+    uint32_t zoneA = 0u, zoneB = 0u, jouleA = 0u, jouleB = 0u;
+#pragma unroll
+    for (int m = 0; m < H; ++m) {
+        const int ia = base + m, ib = base + H + m;
+        zoneA |= (ia >= g.az_start && ia < g.az_end) ? (1u << m) : 0u;
+        zoneB |= (ib >= g.az_start && ib < g.az_end) ? (1u << m) : 0u;
+        jouleA |= (ia >= g.cb && ia <= g.ct) ? (1u << m) : 0u;
+        jouleB |= (ib >= g.cb && ib <= g.ct) ? (1u << m) : 0u;
+    }
+    // tiles the wire's end cuts in some lane (wave-uniform: uniform geometry): they take the predicated per-cell code
+    uint32_t cut = 0u;
+#pragma unroll
+    for (int t = 0; t < H / 8; ++t)
+        cut |= __any((nA > 8 * t && nA < 8 * t + 8) || (nB > 8 * t && nB < 8 * t + 8)) ? (1u << t) : 0u;
+    cut = __builtin_amdgcn_readfirstlane(cut);
+    // the wire's last cell: in a tile the end does not cut it is the last cell of its tile (n_seg a multiple of 8)
+    const int ll = n - 1 - base;  // lane-local index of the last cell, if this lane holds it
+    const bool owns_last = ll >= 0 && ll < 2 * H;
+    const int lloc = (n - 1) & (2 * H - 1);  // the same index, wave-uniform
+    const bool last_in_b = lloc >= H;
+    const uint32_t last_tile = ((n & 7) == 0) ? (1u << ((lloc & (H - 1)) >> 3)) : 0u;
+    // 0 / 1 Joule mask pairs and the convection coefficient pairs of this lane's cells
+    f2 jm[H], convc[H];
+#pragma unroll
+    for (int m = 0; m < H; ++m) jm[m] = f2{((jouleA >> m) & 1u) ? 1.0f : 0.0f, ((jouleB >> m) & 1u) ? 1.0f : 0.0f};
+    auto build_conv = [&]() {
+#pragma unroll
+        for (int m = 0; m < H; ++m)
+            convc[m] = f2{((zoneA >> m) & 1u) ? ps.conv_zone : ps.conv_base, ((zoneB >> m) & 1u) ? ps.conv_zone : ps.conv_base};
+    };
+    build_conv();
+
+    for (int it = 0; it < k.n_substeps; ++it) {
+        if (__all(s.done)) break;
+        Coef cf{0.0f, 0.0f, 0, -1};
+        QuietTry qt;
+        const bool was_quiet = quiet_prelude_t<WEDM_REGS_DENSE>(hv, cold, g, e, gid, s, qt, cf);
+        if (!was_quiet) {
+            if (!s.done) cf = scalar_prelude(hv, cold, g, e, gid, s, ps, writer, qt);
+            build_conv();
+        }
+        freeze_wire(s);
+        const bool act = !s.done;
+        float tmax = spool;
+        // (uniform geometry, opaque per microsecond: the predicates of the rare per-cell code are computed where they are
+        // used instead of once before the loop and kept -- see wedm_step_regs)
+        Geom gw = g;
+        gw.n_seg = __builtin_amdgcn_readfirstlane(g.n_seg); gw.az_start = __builtin_amdgcn_readfirstlane(g.az_start);
+        gw.az_end = __builtin_amdgcn_readfirstlane(g.az_end); gw.cb = __builtin_amdgcn_readfirstlane(g.cb);
+        gw.ct = __builtin_amdgcn_readfirstlane(g.ct);
+        asm volatile("" : "+s"(gw.n_seg), "+s"(gw.az_start), "+s"(gw.az_end), "+s"(gw.cb), "+s"(gw.ct));
+        int nw = __builtin_amdgcn_readfirstlane(n);
+        asm volatile("" : "+s"(nw));
+        // halos, OLD values: T[base + H - 1] (left of chunk B) and T[base + H] (right of chunk A) are the lane's own; the
+        // left of chunk A is the previous lane's last cell, the right of chunk B the next lane's first (every lane takes
+        // part in the exchange, frozen environments and padding lanes included)
+        const float a_last = P[H - 1].x, b_first = P[0].y;
+        float halo_l = dpp_row_shr1(spool, P[H - 1].y), halo_r = dpp_row_shl1(0.0f, P[0].x);
+        if (L < 16) { halo_l = c == 0 ? spool : halo_l; halo_r = c == L - 1 ? 0.0f : halo_r; }
+        if (act) {  // (the lanes of terminated environments sit the walk out: their registers stay)
+            // a wave with a negative plasma heat walks every cell on the predicated formula (identical results, slower)
+            const bool all_slow = __any(cf.q < 0.0f);
+            const float jf_lane = cf.joule_on ? cf.jf : 0.0f;
+            const bool joule_wave = __any(jf_lane != 0.0f);
+            const uint32_t n_now = all_slow ? 0u : ~cut;
+            // the tiles that hold some lane's plasma cell (a lane's own cells only)
+            const int pcell = (cf.pidx >= 1 && cf.pidx >= base && cf.pidx < base + 2 * H) ? cf.pidx - base : -1;  // lane-local
+            uint32_t ptiles = 0u;
+            if (__any(pcell >= 0)) {
+                const int pt = pcell >= 0 ? ((pcell & (H - 1)) >> 3) : -1;
+#pragma unroll
+                for (int t = 0; t < H / 8; ++t) ptiles |= __any(pt == t) ? (1u << t) : 0u;
+            }
+            const uint32_t odd = ptiles | last_tile;  // regular tiles with cells to patch
+            const f2 jfp = f2{jf_lane, jf_lane};
+            f2 leftp = f2{halo_l, a_last};  // OLD pair before the tile
+#pragma unroll
+            for (int t = 0; t < H / 8; ++t) {
+                const int j = 8 * t;
+                f2 tm[8], tc[8], tp[8], pn[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    tc[u] = P[j + u];
+                    tm[u] = u == 0 ? leftp : P[j + u - 1];
+                    tp[u] = (j + u + 1 < H) ? P[j + u + 1 < H ? j + u + 1 : 0] : f2{b_first, halo_r};
+                }
+                leftp = tc[7];
+                if ((n_now >> t) & 1u) {
+                    f2 tmA[4], tcA[4], tpA[4], pnA[4], tmB[4], tcB[4], tpB[4], pnB[4], cvA[4], cvB[4];
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) {
+                        tmA[u] = tm[u]; tcA[u] = tc[u]; tpA[u] = tp[u]; tmB[u] = tm[4 + u]; tcB[u] = tc[4 + u]; tpB[u] = tp[4 + u];
+                        cvA[u] = convc[j + u]; cvB[u] = convc[j + 4 + u];
+                    }
+                    if (joule_wave) {
+                        f2 jvA[4], jvB[4];
+#pragma unroll
+                        for (int u = 0; u < 4; ++u) { jvA[u] = jm[j + u] * jfp; jvB[u] = jm[j + 4 + u] * jfp; }
+                        quad_staged<true, true, SW>(tmA, tcA, tpA, pnA, g.k, g.tuf, cvA, tdiel, ps.adv, jvA, alpha, tref);
+                        quad_staged<true, true, SW>(tmB, tcB, tpB, pnB, g.k, g.tuf, cvB, tdiel, ps.adv, jvB, alpha, tref);
+                    } else {
+                        quad_staged<false, true, SW>(tmA, tcA, tpA, pnA, g.k, g.tuf, cvA, tdiel, ps.adv, cvA, alpha, tref);
+                        quad_staged<false, true, SW>(tmB, tcB, tpB, pnB, g.k, g.tuf, cvB, tdiel, ps.adv, cvB, alpha, tref);
+                    }
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) { pn[u] = pnA[u]; pn[4 + u] = pnB[u]; }
+                    if (t == 0) pn[0].x = (c == 0) ? spool : pn[0].x;  // wire cell 0
+                    float l7x = pn[7].x, l7y = pn[7].y, extra = spool;
+                    if ((odd >> t) & 1u) {
+                        // the wire's last cell (last position of its tile): out of the regular maximum, predicated formula
+                        if ((last_tile >> t) & 1u) {
+                            const float x = stencil_cell(base + (last_in_b ? H : 0) + j + 7, nw, last_in_b ? tm[7].y : tm[7].x,
+                                                         last_in_b ? tc[7].y : tc[7].x, 0.0f, gw, cf, ps, tref, alpha, tdiel);
+                            const bool hx = owns_last && !last_in_b, hy = owns_last && last_in_b;
+                            l7x = hx ? spool : l7x; l7y = hy ? spool : l7y;
+                            pn[7].x = hx ? x : pn[7].x; pn[7].y = hy ? x : pn[7].y;
+                            extra = owns_last ? x : extra;
+                        }
+                        // plasma cells of the lanes that have one in this tile: the predicated formula from the same OLD values
+                        // (the regular value stays in the maximum, as where the LDS kernels patch the cell after the walk)
+                        if ((ptiles >> t) & 1u) {
+#pragma unroll
+                            for (int u = 0; u < 8; ++u) {
+                                if (__any(pcell == j + u)) {
+                                    const float x = stencil_cell(base + j + u, nw, (base + j + u == 1) ? spool : tm[u].x, tc[u].x, tp[u].x, gw, cf, ps, tref, alpha, tdiel);
+                                    pn[u].x = (pcell == j + u) ? x : pn[u].x;
+                                    extra = (pcell == j + u) ? fmax_gt(extra, x) : extra;
+                                }
+                                if (__any(pcell == H + j + u)) {
+                                    const float x = stencil_cell(base + H + j + u, nw, tm[u].y, tc[u].y, tp[u].y, gw, cf, ps, tref, alpha, tdiel);
+                                    pn[u].y = (pcell == H + j + u) ? x : pn[u].y;
+                                    extra = (pcell == H + j + u) ? fmax_gt(extra, x) : extra;
+                                }
+                            }
+                        }
+                    }
+                    // the maximum of the chunk halves that exist (a tile is whole or padding here)
+                    float mx = max3_raw(l7x, pn[0].x, pn[1].x), my = max3_raw(l7y, pn[0].y, pn[1].y);
+                    mx = max3_raw(mx, pn[2].x, pn[3].x); my = max3_raw(my, pn[2].y, pn[3].y);
+                    mx = max3_raw(mx, pn[4].x, pn[5].x); my = max3_raw(my, pn[4].y, pn[5].y);
+                    mx = fmax_gt(mx, pn[6].x); my = fmax_gt(my, pn[6].y);
+                    mx = nA > j ? mx : spool; my = nB > j ? my : spool;
+                    if ((odd >> t) & 1u) mx = fmax_gt(mx, extra);
+                    tmax = max3_raw(tmax, mx, my);
+                } else {
+                    // the wire's end inside the tile, or a negative plasma heat: every cell that exists on the predicated formula
+#pragma unroll
+                    for (int u = 0; u < 8; ++u) {
+                        pn[u] = tc[u];
+                        const int ia = base + j + u, ib = base + H + j + u;
+                        {
+                            const float x = (ia >= 1) ? stencil_cell(ia, nw, (ia == 1) ? spool : tm[u].x, tc[u].x, tp[u].x, gw, cf, ps, tref, alpha, tdiel) : spool;
+                            pn[u].x = ia < nw ? x : pn[u].x;
+                            tmax = ia < nw ? fmax_gt(tmax, x) : tmax;
+                        }
+                        {
+                            const float x = stencil_cell(ib, nw, tm[u].y, tc[u].y, tp[u].y, gw, cf, ps, tref, alpha, tdiel);
+                            pn[u].y = ib < nw ? x : pn[u].y;
+                            tmax = ib < nw ? fmax_gt(tmax, x) : tmax;
+                        }
+                    }
+                }
+#pragma unroll
+                for (int u = 0; u < 8; ++u) P[j + u] = pn[u];
+            }
+        }
+        // the maximum over the lanes of the environment (all lanes take part; frozen and padding lanes hold the spool value)
+        tmax = fmax_gt(tmax, dpp_perm<0xB1>(tmax));   // quad_perm [1,0,3,2]
+        tmax = fmax_gt(tmax, dpp_perm<0x4E>(tmax));   // quad_perm [2,3,0,1]
+        if (L >= 8) tmax = fmax_gt(tmax, dpp_perm<0x141>(tmax));  // row_half_mirror
+        if (L >= 16) tmax = fmax_gt(tmax, dpp_perm<0x140>(tmax)); // row_mirror
+        unfreeze_wire(hv, s);
+        if (!s.done) {
+            scalar_epilogue(hv, s, tmax);
+            if (s.ctrl) control_step_outputs(cold, e, s, writer);
+        }
+    }
+
+    if (live) {
+#pragma unroll
+        for (int q = 0; q < 2 * H / 4; ++q) {
+            const int m = (q % (H / 4)) * 4;
+            const bool hi = q >= H / 4;
+            const f4v w = hi ? f4v{P[m].y, P[m + 1].y, P[m + 2].y, P[m + 3].y} : f4v{P[m].x, P[m + 1].x, P[m + 2].x, P[m + 3].x};
+            const int cell = base + 4 * q;
+            if (cell + 3 < n) {
+                *(f4v*)(Te + (int64_t)(q0 + q) * stride * 4) = w;
+            } else {  // the wire's last, partial word: the cells past the end are padding and keep their value
+#pragma unroll
+                for (int u = 0; u < 4; ++u)
+                    if (cell + u < n) Te[(int64_t)(q0 + q) * stride * 4 + u] = w[u];
+            }
+        }
+    }
+    if (live && writer) {
+        if (WEDM_REWARD_ON(cold)) {
+            if (!frozen0) write_reward(cold, e, s);
+            else cold->s.reward[e] = 0.0f;  // a frozen environment earns nothing (not the previous launch's reward)
+        }
+        store_time_hi(cold, e, s, (uint32_t)k.n_substeps * (uint32_t)k.hot.dt_us);
+        store_env(cold, e, s);
+    }
+}
+
+
 // ============================================ packed fused kernel, L lanes / env, 2 cells / op
 // Same walk as wedm_step_fused, but every lane owns TWO virtual chunks A and B of Cv cells and
 // advances them together in one float2 register pair, so each v_pk_add_f32 / v_pk_mul_f32 does
@@ -3113,6 +3405,17 @@ static int32_t plan_launch(wedm_ctx* ctx, bool single, bool tr, bool frozen_ok, 
             return fail(ctx, WEDM_ERR_UNSUPPORTED, "wedm_step: stencil_mode 1 (float64 stencil expressions) runs on kernels 1, 2 and 3 only");
         if (variant == 0) variant = (!single && fused_ok) ? 3 : (lanes_ok ? 2 : 1);
     }
+    // kernel 8 (wide register kernel): 16 lanes per environment, 32 cells each in registers; uniform geometry, float32
+    // stencil, at most 512 segments, no trace point.  Chosen by itself for long wires (more than 256 segments, a multiple
+    // of 8: no tile cut by the wire's end) in a batch that one round of blocks covers at one wave per SIMD
+    // (measured, 4 096 x 400: DESIGN.md 4.1b)
+    const bool wide_ok = uniform && P.n_seg >= 9 && P.n_seg <= 512 && !f64 && !ctx->replay && (ctx->lanes == 0 || ctx->lanes == 16);
+    if (variant == 0 && !single && !tr && wide_ok && ctx->lanes == 0 && P.n_seg > 256 && (P.n_seg & 7) == 0 &&
+        ctx->num_envs <= WEDM_WIDE_AUTO_MAX_ENVS)
+        variant = 8;
+    if (variant == 8 && !wide_ok)
+        return fail(ctx, WEDM_ERR_UNSUPPORTED, "wedm_step: wide register kernel needs uniform geometry, 9 to 512 segments, the float32 stencil and lanes 0 or 16");
+    if (variant == 8 && tr) variant = packed_ok ? 4 : fused_ok ? 3 : lanes_ok ? 2 : 1;  // it has no trace point
     // kernel 7 (register kernel): one or two lanes per environment with the wire in their registers; wires of at most 128
     // segments, uniform geometry, float32 stencil; it has no trace point: a launch with a trace sample takes the LDS kernels
     const bool regs_ok = uniform && ctx->walk_regs_ok && ctx->n_seg_max <= 128 && !f64 && !ctx->replay;
@@ -3159,6 +3462,10 @@ static int32_t plan_launch(wedm_ctx* ctx, bool single, bool tr, bool frozen_ok, 
         out.walk = ctx->walk_dev + (rl == 1 ? 10 : 11);  // two chunks of 64 cells / four of 32
         fn = rl == 1 ? (const void*)wedm_step_regs<128, 1> : (const void*)wedm_step_regs<128, 2>;
         std::snprintf(out.name, sizeof(out.name), "wedm_step_regs<%d><<<%d,256>>>", rl, grid);
+    } else if (variant == 8) {
+        grid = (ctx->num_envs + 15) / 16;
+        fn = (const void*)wedm_step_regs_wide<16, 16>;
+        std::snprintf(out.name, sizeof(out.name), "wedm_step_regs_wide<16><<<%d,256>>>", grid);
     } else if (variant == 5) {
         grid = (ctx->num_envs + 63) / 64;
         fn = tr ? (const void*)wedm_step_split<true> : (const void*)wedm_step_split<false>;
@@ -3420,7 +3727,7 @@ int32_t wedm_bind_rng_replay(wedm_ctx* ctx, const double* table, int64_t n_steps
 
 int32_t wedm_set_kernel(wedm_ctx* ctx, int32_t variant) {
     if (!ctx) return WEDM_ERR_BAD_ARG;
-    if (variant < 0 || variant > 7) return fail(ctx, WEDM_ERR_BAD_ARG, "wedm_set_kernel: variant must be 0..7");
+    if (variant < 0 || variant > 8) return fail(ctx, WEDM_ERR_BAD_ARG, "wedm_set_kernel: variant must be 0..8");
     ctx->variant = variant;
     ctx->invalidate_plans();
     return WEDM_OK;

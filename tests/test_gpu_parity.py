@@ -52,7 +52,7 @@ def test_native_library_is_the_one_running():
     env.step(env.make_action())
     assert "wedm_step_stream" in env._backend.last_kernel() or "wedm_step_split" in env._backend.last_kernel()
     env.step_many(env.make_action(), 10)
-    assert "wedm_step_packed" in env._backend.last_kernel() or "wedm_step_fused" in env._backend.last_kernel()
+    assert any(k in env._backend.last_kernel() for k in ("wedm_step_packed", "wedm_step_fused", "wedm_step_regs_wide"))
     env.set_kernel(2)
     env.step_many(env.make_action(), 10)
     assert "wedm_step_lanes" in env._backend.last_kernel()
@@ -478,7 +478,7 @@ def test_run_controlled_on_gpu_matches_oracle():
         assert run_controlled(env, GapController(desired_gap=8.0, current_mode=9), 6500) == 6500
     check(gpu, cpu, n)
     assert int(gpu.state.spark_count.sum()) > 100
-    assert "wedm_step_packed" in gpu._backend.last_kernel() or "wedm_step_fused" in gpu._backend.last_kernel()
+    assert any(k in gpu._backend.last_kernel() for k in ("wedm_step_packed", "wedm_step_fused", "wedm_step_regs_wide"))
 
 
 def test_vector_env_autoreset_on_gpu():
@@ -510,7 +510,7 @@ def test_tiny_wires_all_kernels(segment_len, n_seg):
     from sparc_amd._lib import WedmError
 
     ran = 0
-    for variant, lanes in KERNELS + [(7, 0)]:
+    for variant, lanes in KERNELS + [(7, 0), (8, 0)]:
         gpu.set_kernel(variant, lanes)
         a_g, a_c = gpu.make_action(0.1, 80.0, 9, 3.0, 30.0), cpu.make_action(0.1, 80.0, 9, 3.0, 30.0)
         try:
@@ -837,7 +837,7 @@ def test_randomized_configurations_all_kernels_bit_exact(case):
         env.state.workpiece_position = torch.as_tensor(10.0 + gaps)
         env.state.target_position = torch.as_tensor(np.where(np.arange(n) % 7 == 3, 10.0 + gaps + 0.01, 5000.0)) if extreme else 5000.0
         env.state.debris_volume = torch.as_tensor(debris) if (case % 2 or extreme) else 0.0
-    variants = [(0, 0), (1, 0), (5, 0), (2, 4), (2, 8)] if per_env else KERNELS + [(0, 0), (7, 0)]
+    variants = [(0, 0), (1, 0), (5, 0), (2, 4), (2, 8)] if per_env else KERNELS + [(0, 0), (7, 0), (8, 0)]
     servo = rng.uniform(50, 300, n) if kw["mechanics_control_mode"] == "velocity" else rng.uniform(-0.05, 0.3, n)
     if extreme:
         servo = servo * rng.choice([1.0, 1.0, 20.0, -3.0], n)
@@ -1404,7 +1404,7 @@ def test_native_seed_reference_run_followed_on_the_gpu(golden_dir):
     assert not bool(st.error.any())
     env.bind_rng_replay(None)
     env.step_many(env.make_action(), 10)
-    assert "wedm_step_packed" in env._backend.last_kernel() or "wedm_step_fused" in env._backend.last_kernel()
+    assert any(k in env._backend.last_kernel() for k in ("wedm_step_packed", "wedm_step_fused", "wedm_step_regs_wide"))
 
 
 def test_densely_sparking_batch_on_the_packed_kernel_matches_oracle():
@@ -1480,3 +1480,113 @@ def test_register_kernel_one_environment_per_lane_matches_oracle(mode, lanes):
     assert "wedm_step_regs" not in gpu._backend.last_kernel()
     assert_rings_equal(*traces)
     check(gpu, cpu, n)
+
+
+@pytest.mark.parametrize("mode", ["default", "autoreset", "reference"])
+def test_wide_register_kernel_on_the_default_grid_matches_oracle(mode):
+    """Kernel 8 (16 lanes per environment, 32 cells each in registers, no LDS, no walk table) on the default grid --
+    400 segments: lane 12 holds the wire's last 16 cells and 16 cells of padding, lanes 13..15 padding only; the zone
+    starts inside a tile (cell 149), the contacts at cells 100 and 300 -- against the oracle batch, every byte: sparks
+    in every tile of the zone (plasma cell recomputed inside its tile), current between the contacts, wire breaks by
+    temperature (frozen lanes inside live waves) and by collision, reached targets; launches of 1, 2, 1000 and 1300 us;
+    in-launch autoreset with the progress reward; the reference's reset semantics with stepping past `terminated`; a
+    batch that does not fill its last block."""
+    n = 333
+    kw = dict(config=EnvironmentConfig(target_cutting_distance=5000.0))
+    if mode == "autoreset":
+        kw.update(autoreset=True, reward="progress", crater_log_capacity=8)
+    if mode == "reference":
+        kw.update(reset_semantics="reference", freeze_terminated=False, ignition_params=IgnitionModuleParameters(default_current_mode="I13"))
+    gpu, cpu = make_pair(n, **kw)
+    assert gpu.n_segments == 400
+    idx = torch.arange(n)
+    for env in (gpu, cpu):
+        env.reset(seed=77)
+        close_gap(env, 21.0, 10.0)
+        env.state.workpiece_position = torch.where(idx % 9 == 2, 11.2, 21.0)          # hard shorts
+        env.state.target_position = torch.where(idx % 4 == 1, 21.0005, 5000.0)        # reached after the first craters
+        env.state.wire_position = torch.where(idx % 11 == 5, 125.0, 10.0)             # collision: wire > workpiece + 100
+        hot = env.state.wire_temperature
+        hot[7::13, 190:194] = 1600.0                                                  # breaks at the first step
+        hot[70, 399] = 900.0                                                          # a hot last cell (Neumann end)
+        hot[71, 1] = 900.0                                                            # a hot first interior cell
+        hot[72, 383:386] = 700.0                                                      # across the lanes 11 | 12
+        a = env.make_action(0.1, 80.0, 17, 3.0, 20.0)
+        for k in (1, 2, 1000, 1, 1300):
+            env.step_many(a, k)
+        env.reset(seed=78, options={"mask": idx % 3 == 0})
+        env.state.wire_position = torch.where(idx % 3 == 0, 35.0, env.state.wire_position.cpu())
+        env.state.wire_unwinding_velocity[::7] = 0.0                                  # mixed advection inside a wave
+        for k in (2, 900, 600):
+            env.step_many(a, k)
+    assert "wedm_step_regs_wide<16>" in gpu._backend.last_kernel()                    # (chosen by itself for fused launches)
+    check(gpu, cpu, n)
+    st = gpu.state
+    assert int(st.spark_count.sum()) > 10 * n
+    if mode == "default":
+        assert bool(st.is_wire_broken.any()) and bool(st.is_target_distance_reached.any())
+    if mode == "autoreset":
+        assert int(st.episode.max()) >= 1
+        return   # (the oracle seam samples a trace after single microseconds, and every launch boundary is an episode boundary here)
+    # a launch with a trace sample has no register-kernel form: the LDS kernels take it, results unchanged
+    traces = [e.bind_trace(["voltage", "wire_max_temperature"], every=1, capacity=64, envs=(0, 64)) for e in (gpu, cpu)]
+    for env in (gpu, cpu):
+        env.step_many(env.make_action(0.1, 80.0, 17, 3.0, 20.0), 40)
+    assert "wedm_step_regs_wide" not in gpu._backend.last_kernel()
+    assert_rings_equal(*traces)
+    check(gpu, cpu, n)
+
+
+WIDE_N = [9, 15, 16, 17, 31, 32, 33, 63, 64, 65, 100, 128, 200, 255, 256, 257, 264, 300, 383, 384, 385, 390, 392, 396, 399,
+          401, 408, 415, 416, 417, 440, 448, 479, 480, 481, 496, 504, 511, 512]
+
+
+@pytest.mark.parametrize("part", [0, 1, 2])
+def test_wide_register_kernel_over_wire_lengths(part):
+    """Kernel 8 forced over wire lengths from 9 to 512 segments: the wire's end at every kind of place -- closing a
+    tile (n_seg a multiple of 8: the last cell patched inside a regular tile, in chunk A or chunk B of its lane),
+    cutting one (the predicated per-cell code for that tile index in every lane), at a lane's first cell, at the last
+    cell of the last lane (512) -- zone and contact indices wherever the geometry puts them; sparks, current, a wire
+    break (frozen lanes in a live wave), hot end cells; fused launches and single microseconds."""
+    n_envs = 96
+    for n_seg in WIDE_N[part::3]:
+        kw = dict(wire_params=WireModuleParameters(segment_len=80.0 / (n_seg + 0.5)),
+                  config=EnvironmentConfig(target_cutting_distance=5000.0))
+        gpu, cpu = make_pair(n_envs, **kw)
+        assert gpu.n_segments == n_seg
+        gpu.set_kernel(8, 0)
+        for env in (gpu, cpu):
+            env.reset(seed=1000 + n_seg)
+            close_gap(env, 21.0, 10.0)
+            hot = env.state.wire_temperature
+            hot[5, n_seg // 2] = 1600.0       # environment 5 breaks its wire at the first step: frozen lanes in its wave
+            hot[70, n_seg - 1] = 900.0        # a hot last cell (Neumann end) ...
+            hot[71, 1] = 900.0                # ... and a hot first interior cell
+            act = env.make_action(0.1, 80.0, 17, 3.0, 20.0)
+            env.step_many(act, 290)
+            for _ in range(6):
+                env.step(act)
+        torch.cuda.synchronize()
+        assert "wedm_step_regs_wide<16>" in gpu._backend.last_kernel()
+        assert int(cpu.state.spark_count.sum()) > n_envs and bool(cpu.state.is_wire_broken[5])
+        diffs = block_diffs(gpu.state.clone_blocks(), cpu.state.clone_blocks(), n_envs)
+        assert not diffs, f"n_seg {n_seg}, kernel {gpu._backend.last_kernel()}:\n" + "\n".join(diffs[:10])
+        gpu.close()
+
+
+def test_wide_register_kernel_config2_batch_densely_sparking_matches_oracle():
+    """The bench's config-2 batch (4 096 x 400, the automatic choice) with mixed current modes and ON times at a small gap:
+    general preludes, Joule terms on most steps and plasma cells in every lane of the zone, every byte."""
+    n = 4096
+    gpu, cpu = make_pair(n)
+    both((gpu, cpu), lambda e: (e.reset(seed=606), close_gap(e, 18.0, 10.0)))
+    rng = np.random.default_rng(1)
+    modes = rng.choice([5, 9, 13, 17], n).astype(np.int32)
+    on = rng.choice([1.0, 2.0, 3.5, 5.0], n)
+    for env in (gpu, cpu):
+        a = env.make_action(0.05, 80.0, modes, on, 15.0)
+        for k in (1000, 777):
+            env.step_many(a, k)
+    assert "wedm_step_regs_wide<16>" in gpu._backend.last_kernel(), gpu._backend.last_kernel()
+    check(gpu, cpu, n)
+    assert int(gpu.state.spark_count.sum()) / n / 1.777 > 5.0          # densely sparking indeed
