@@ -2276,6 +2276,12 @@ __device__ __forceinline__ float dpp_perm(float x) {
 #ifndef WEDM_WIDE_MIN_BLOCKS
 #define WEDM_WIDE_MIN_BLOCKS 1
 #endif
+#ifndef WEDM_WIDE_SW
+#define WEDM_WIDE_SW 2  // pairs per stage (4 096 x 400: 1.883e9 with 2, 1.862e9 with 4)
+#endif
+#ifndef WEDM_WIDE_DENSE
+#define WEDM_WIDE_DENSE WEDM_REGS_DENSE
+#endif
 #ifndef WEDM_WIDE_AUTO_MAX_ENVS
 #define WEDM_WIDE_AUTO_MAX_ENVS 4096  // one block of 16 environments per CU
 #endif
@@ -2284,7 +2290,7 @@ __global__ void __launch_bounds__(256, WEDM_WIDE_MIN_BLOCKS) wedm_step_regs_wide
     static_assert(H % 8 == 0 && H <= 32, "whole tiles");
     static_assert(L == 4 || L == 8 || L == 16, "the lanes of an environment lie in one DPP row");
     constexpr int EPB = 256 / L;
-    constexpr int SW = 4;  // pairs per stage: a wave alone on its SIMD needs the distance between dependent operations
+    constexpr int SW = WEDM_WIDE_SW;
     const ColdRef cold = kernarg_cold();
     Hot hv = k.hot;
     pin_hot_in_vgprs(hv);
@@ -2364,44 +2370,57 @@ __global__ void __launch_bounds__(256, WEDM_WIDE_MIN_BLOCKS) wedm_step_regs_wide
             convc[m] = f2{((zoneA >> m) & 1u) ? ps.conv_zone : ps.conv_base, ((zoneB >> m) & 1u) ? ps.conv_zone : ps.conv_base};
     };
     build_conv();
+    WEDM_STAMP_DECL;
 
     for (int it = 0; it < k.n_substeps; ++it) {
         if (__all(s.done)) break;
+        WEDM_STAMP(st0);
         Coef cf{0.0f, 0.0f, 0, -1};
         QuietTry qt;
-        const bool was_quiet = quiet_prelude_t<WEDM_REGS_DENSE>(hv, cold, g, e, gid, s, qt, cf);
+        const bool was_quiet = quiet_prelude_t<WEDM_WIDE_DENSE>(hv, cold, g, e, gid, s, qt, cf);
         if (!was_quiet) {
             if (!s.done) cf = scalar_prelude(hv, cold, g, e, gid, s, ps, writer, qt);
             build_conv();
         }
         freeze_wire(s);
+        WEDM_STAMP(st1);
         const bool act = !s.done;
         float tmax = spool;
-        // (uniform geometry, opaque per microsecond: the predicates of the rare per-cell code are computed where they are
-        // used instead of once before the loop and kept -- see wedm_step_regs)
-        Geom gw = g;
-        gw.n_seg = __builtin_amdgcn_readfirstlane(g.n_seg); gw.az_start = __builtin_amdgcn_readfirstlane(g.az_start);
-        gw.az_end = __builtin_amdgcn_readfirstlane(g.az_end); gw.cb = __builtin_amdgcn_readfirstlane(g.cb);
-        gw.ct = __builtin_amdgcn_readfirstlane(g.ct);
-        asm volatile("" : "+s"(gw.n_seg), "+s"(gw.az_start), "+s"(gw.az_end), "+s"(gw.cb), "+s"(gw.ct));
-        int nw = __builtin_amdgcn_readfirstlane(n);
-        asm volatile("" : "+s"(nw));
         // halos, OLD values: T[base + H - 1] (left of chunk B) and T[base + H] (right of chunk A) are the lane's own; the
         // left of chunk A is the previous lane's last cell, the right of chunk B the next lane's first (every lane takes
         // part in the exchange, frozen environments and padding lanes included)
         const float a_last = P[H - 1].x, b_first = P[0].y;
         float halo_l = dpp_row_shr1(spool, P[H - 1].y), halo_r = dpp_row_shl1(0.0f, P[0].x);
         if (L < 16) { halo_l = c == 0 ? spool : halo_l; halo_r = c == L - 1 ? 0.0f : halo_r; }
-        if (act) {  // (the lanes of terminated environments sit the walk out: their registers stay)
+        // PLAIN: no lane of the wave carries current or a plasma heat in this microsecond (the ordinary one): no Joule
+        // term, no plasma cell, nothing to look for -- the walk is its two tiles and the wire's last cell
+        const bool busy = __any(cf.joule_on != 0 || cf.pidx >= 0 || cf.q != 0.0f);
+        auto walk = [&](auto plain_tag) {
+            constexpr bool PLAIN = decltype(plain_tag)::value;
+            const Coef cz{0.0f, 0.0f, 0, -1};
+            const Coef& cw = PLAIN ? cz : cf;
+            // (uniform geometry, opaque where it is used: the predicates of the rare per-cell code are computed there
+            // instead of once before the loop and kept -- see wedm_step_regs)
+            Geom gw = g;
+            int nw = n;
+            auto prep_gw = [&]() {
+                gw.n_seg = __builtin_amdgcn_readfirstlane(g.n_seg); gw.az_start = __builtin_amdgcn_readfirstlane(g.az_start);
+                gw.az_end = __builtin_amdgcn_readfirstlane(g.az_end); gw.cb = __builtin_amdgcn_readfirstlane(g.cb);
+                gw.ct = __builtin_amdgcn_readfirstlane(g.ct);
+                asm volatile("" : "+s"(gw.n_seg), "+s"(gw.az_start), "+s"(gw.az_end), "+s"(gw.cb), "+s"(gw.ct));
+                nw = __builtin_amdgcn_readfirstlane(n);
+                asm volatile("" : "+s"(nw));
+            };
+            if (!PLAIN) prep_gw();
             // a wave with a negative plasma heat walks every cell on the predicated formula (identical results, slower)
-            const bool all_slow = __any(cf.q < 0.0f);
-            const float jf_lane = cf.joule_on ? cf.jf : 0.0f;
-            const bool joule_wave = __any(jf_lane != 0.0f);
+            const bool all_slow = !PLAIN && __any(cf.q < 0.0f);
+            const float jf_lane = (!PLAIN && cf.joule_on) ? cf.jf : 0.0f;
+            const bool joule_wave = !PLAIN && __any(jf_lane != 0.0f);
             const uint32_t n_now = all_slow ? 0u : ~cut;
             // the tiles that hold some lane's plasma cell (a lane's own cells only)
-            const int pcell = (cf.pidx >= 1 && cf.pidx >= base && cf.pidx < base + 2 * H) ? cf.pidx - base : -1;  // lane-local
+            const int pcell = (!PLAIN && cf.pidx >= 1 && cf.pidx >= base && cf.pidx < base + 2 * H) ? cf.pidx - base : -1;  // lane-local
             uint32_t ptiles = 0u;
-            if (__any(pcell >= 0)) {
+            if (!PLAIN && __any(pcell >= 0)) {
                 const int pt = pcell >= 0 ? ((pcell & (H - 1)) >> 3) : -1;
 #pragma unroll
                 for (int t = 0; t < H / 8; ++t) ptiles |= __any(pt == t) ? (1u << t) : 0u;
@@ -2427,7 +2446,7 @@ __global__ void __launch_bounds__(256, WEDM_WIDE_MIN_BLOCKS) wedm_step_regs_wide
                         tmA[u] = tm[u]; tcA[u] = tc[u]; tpA[u] = tp[u]; tmB[u] = tm[4 + u]; tcB[u] = tc[4 + u]; tpB[u] = tp[4 + u];
                         cvA[u] = convc[j + u]; cvB[u] = convc[j + 4 + u];
                     }
-                    if (joule_wave) {
+                    if (!PLAIN && joule_wave) {
                         f2 jvA[4], jvB[4];
 #pragma unroll
                         for (int u = 0; u < 4; ++u) { jvA[u] = jm[j + u] * jfp; jvB[u] = jm[j + 4 + u] * jfp; }
@@ -2442,10 +2461,11 @@ __global__ void __launch_bounds__(256, WEDM_WIDE_MIN_BLOCKS) wedm_step_regs_wide
                     if (t == 0) pn[0].x = (c == 0) ? spool : pn[0].x;  // wire cell 0
                     float l7x = pn[7].x, l7y = pn[7].y, extra = spool;
                     if ((odd >> t) & 1u) {
+                        if (PLAIN) prep_gw();
                         // the wire's last cell (last position of its tile): out of the regular maximum, predicated formula
                         if ((last_tile >> t) & 1u) {
                             const float x = stencil_cell(base + (last_in_b ? H : 0) + j + 7, nw, last_in_b ? tm[7].y : tm[7].x,
-                                                         last_in_b ? tc[7].y : tc[7].x, 0.0f, gw, cf, ps, tref, alpha, tdiel);
+                                                         last_in_b ? tc[7].y : tc[7].x, 0.0f, gw, cw, ps, tref, alpha, tdiel);
                             const bool hx = owns_last && !last_in_b, hy = owns_last && last_in_b;
                             l7x = hx ? spool : l7x; l7y = hy ? spool : l7y;
                             pn[7].x = hx ? x : pn[7].x; pn[7].y = hy ? x : pn[7].y;
@@ -2453,7 +2473,7 @@ __global__ void __launch_bounds__(256, WEDM_WIDE_MIN_BLOCKS) wedm_step_regs_wide
                         }
                         // plasma cells of the lanes that have one in this tile: the predicated formula from the same OLD values
                         // (the regular value stays in the maximum, as where the LDS kernels patch the cell after the walk)
-                        if ((ptiles >> t) & 1u) {
+                        if (!PLAIN && ((ptiles >> t) & 1u)) {
 #pragma unroll
                             for (int u = 0; u < 8; ++u) {
                                 if (__any(pcell == j + u)) {
@@ -2479,17 +2499,18 @@ __global__ void __launch_bounds__(256, WEDM_WIDE_MIN_BLOCKS) wedm_step_regs_wide
                     tmax = max3_raw(tmax, mx, my);
                 } else {
                     // the wire's end inside the tile, or a negative plasma heat: every cell that exists on the predicated formula
+                    if (PLAIN) prep_gw();
 #pragma unroll
                     for (int u = 0; u < 8; ++u) {
                         pn[u] = tc[u];
                         const int ia = base + j + u, ib = base + H + j + u;
                         {
-                            const float x = (ia >= 1) ? stencil_cell(ia, nw, (ia == 1) ? spool : tm[u].x, tc[u].x, tp[u].x, gw, cf, ps, tref, alpha, tdiel) : spool;
+                            const float x = (ia >= 1) ? stencil_cell(ia, nw, (ia == 1) ? spool : tm[u].x, tc[u].x, tp[u].x, gw, cw, ps, tref, alpha, tdiel) : spool;
                             pn[u].x = ia < nw ? x : pn[u].x;
                             tmax = ia < nw ? fmax_gt(tmax, x) : tmax;
                         }
                         {
-                            const float x = stencil_cell(ib, nw, tm[u].y, tc[u].y, tp[u].y, gw, cf, ps, tref, alpha, tdiel);
+                            const float x = stencil_cell(ib, nw, tm[u].y, tc[u].y, tp[u].y, gw, cw, ps, tref, alpha, tdiel);
                             pn[u].y = ib < nw ? x : pn[u].y;
                             tmax = ib < nw ? fmax_gt(tmax, x) : tmax;
                         }
@@ -2498,18 +2519,27 @@ __global__ void __launch_bounds__(256, WEDM_WIDE_MIN_BLOCKS) wedm_step_regs_wide
 #pragma unroll
                 for (int u = 0; u < 8; ++u) P[j + u] = pn[u];
             }
+        };
+        if (act) {  // (the lanes of terminated environments sit the walk out: their registers stay)
+            if (busy) walk(std::false_type{});
+            else walk(std::true_type{});
         }
+        WEDM_STAMP(st2);
         // the maximum over the lanes of the environment (all lanes take part; frozen and padding lanes hold the spool value)
         tmax = fmax_gt(tmax, dpp_perm<0xB1>(tmax));   // quad_perm [1,0,3,2]
         tmax = fmax_gt(tmax, dpp_perm<0x4E>(tmax));   // quad_perm [2,3,0,1]
         if (L >= 8) tmax = fmax_gt(tmax, dpp_perm<0x141>(tmax));  // row_half_mirror
         if (L >= 16) tmax = fmax_gt(tmax, dpp_perm<0x140>(tmax)); // row_mirror
         unfreeze_wire(hv, s);
+        WEDM_STAMP(st3);
         if (!s.done) {
             scalar_epilogue(hv, s, tmax);
             if (s.ctrl) control_step_outputs(cold, e, s, writer);
         }
+        WEDM_STAMP(st4);
+        WEDM_STAMP_ACC();
     }
+    WEDM_STAMP_OUT();
 
     if (live) {
 #pragma unroll
