@@ -398,13 +398,18 @@ int64_t wedm_trace_samples(wedm_ctx* ctx);
  * chunk of a lane requested up front, tile walk in LDS, no barrier; the automatic choice for
  * n_substeps == 1 where one round of blocks covers the batch), 7 = register kernel (one environment per
  * lane with its whole wire in registers: no LDS, the scalar physics once per environment; uniform geometry,
- * at most 128 segments, float32 stencil; launches with a trace sample take the LDS kernels).  All variants
- * produce bit-identical results.  With wedm_params.stencil_mode 1 only 0, 1, 2 and 3 are accepted (3: the tile walk with
+ * at most 128 segments, float32 stencil; launches with a trace sample take the LDS kernels),
+ * 8 = wide register kernel (4, 8 or 16 lanes per environment -- the fewest that hold the wire at 32 cells per lane --
+ * with the wire in their registers and per-cell zone / contact coefficients: no LDS, no tile table; uniform geometry,
+ * 9 to 512 segments, float32 stencil; the automatic choice for fused launches of a batch that one round of blocks
+ * covers -- environments x lanes <= 65 536 -- when the segment count is a multiple of 8; launches with a trace sample
+ * take the LDS kernels).  All variants produce bit-identical results.  With wedm_params.stencil_mode 1 only 0, 1, 2 and 3 are accepted (3: the tile walk with
  * per-cell coefficients, no stage-major / packed form).                                          */
 int32_t wedm_set_kernel(wedm_ctx* ctx, int32_t variant);
 
 /* lanes that share one environment in kernels 2, 3, 4 and 6: 0 = auto, or 1, 2, 4, 8 (16: not kernel 4); kernel 7: 1, anything
- * else = 2.  A lane count set here also keeps the automatic choice (kernel 0) off the register kernel.              */
+ * else = 2; kernel 8: 0 = the fewest, or 4, 8, 16 if 32 cells per lane cover the wire.  A lane count set here also keeps
+ * the automatic choice (kernel 0) off the register kernels.                                                          */
 int32_t wedm_set_lanes(wedm_ctx* ctx, int32_t lanes);
 
 /* name / launch geometry of the kernel the last wedm_step used (for profiles) */

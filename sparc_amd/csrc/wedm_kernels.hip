@@ -2259,8 +2259,8 @@ __global__ void __launch_bounds__(256, L) wedm_step_regs(const KArgs k) {
 //     (the wire's last cell takes the predicated formula, which has no right neighbour).
 //   * zone and contact flags per CELL, from the geometry's indices, as registers: a convection coefficient pair per
 //     pair of cells (rebuilt when the general prelude refreshes the coefficients) and a 0 / 1 Joule mask pair; a tile is
-//     regular whatever flags change inside it.  What is left for the predicated per-cell code is a tile that the wire's
-//     end cuts (n_seg not a multiple of 8) and a wave with a negative plasma heat.
+//     regular whatever flags change inside it, also the one the wire's end cuts (n_seg not a multiple of 8: its maximum
+//     is taken cell by cell).  What is left for the predicated per-cell code is a wave with a negative plasma heat.
 //   * halos between the lanes of an environment by DPP row shifts, the maximum over them by DPP quad / row mirrors.
 __device__ __forceinline__ float dpp_row_shr1(float old, float x) {  // lane i <- lane i - 1 of its row of 16; lane 0 keeps `old`
     return __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(old), __float_as_int(x), 0x111, 0xF, 0xF, false));
@@ -2282,8 +2282,8 @@ __device__ __forceinline__ float dpp_perm(float x) {
 #ifndef WEDM_WIDE_DENSE
 #define WEDM_WIDE_DENSE WEDM_REGS_DENSE
 #endif
-#ifndef WEDM_WIDE_AUTO_MAX_ENVS
-#define WEDM_WIDE_AUTO_MAX_ENVS 4096  // one block of 16 environments per CU
+#ifndef WEDM_WIDE_AUTO_MAX_LANES
+#define WEDM_WIDE_AUTO_MAX_LANES 65536  // one block per CU: 4 096 environments x 16 lanes, 16 384 x 4
 #endif
 template <int H, int L>
 __global__ void __launch_bounds__(256, WEDM_WIDE_MIN_BLOCKS) wedm_step_regs_wide(const KArgs k) {
@@ -2348,7 +2348,8 @@ __global__ void __launch_bounds__(256, WEDM_WIDE_MIN_BLOCKS) wedm_step_regs_wide
         jouleA |= (ia >= g.cb && ia <= g.ct) ? (1u << m) : 0u;
         jouleB |= (ib >= g.cb && ib <= g.ct) ? (1u << m) : 0u;
     }
-    // tiles the wire's end cuts in some lane (wave-uniform: uniform geometry): they take the predicated per-cell code
+    // the tile the wire's end cuts, if n_seg is not a multiple of 8 (wave-uniform: uniform geometry): regular code too, with
+    // its maximum taken cell by cell over the cells that exist and the last cell patched where it lies
     uint32_t cut = 0u;
 #pragma unroll
     for (int t = 0; t < H / 8; ++t)
@@ -2360,6 +2361,8 @@ __global__ void __launch_bounds__(256, WEDM_WIDE_MIN_BLOCKS) wedm_step_regs_wide
     const int lloc = (n - 1) & (2 * H - 1);  // the same index, wave-uniform
     const bool last_in_b = lloc >= H;
     const uint32_t last_tile = ((n & 7) == 0) ? (1u << ((lloc & (H - 1)) >> 3)) : 0u;
+    // cells of the two chunks that enter the regular maximum: those that exist, without the wire's last cell
+    const int ivA = min(max(n - 1 - base, 0), H), ivB = min(max(n - 1 - base - H, 0), H);
     // 0 / 1 Joule mask pairs and the convection coefficient pairs of this lane's cells
     f2 jm[H], convc[H];
 #pragma unroll
@@ -2416,7 +2419,7 @@ __global__ void __launch_bounds__(256, WEDM_WIDE_MIN_BLOCKS) wedm_step_regs_wide
             const bool all_slow = !PLAIN && __any(cf.q < 0.0f);
             const float jf_lane = (!PLAIN && cf.joule_on) ? cf.jf : 0.0f;
             const bool joule_wave = !PLAIN && __any(jf_lane != 0.0f);
-            const uint32_t n_now = all_slow ? 0u : ~cut;
+            const uint32_t n_now = all_slow ? 0u : ~0u;
             // the tiles that hold some lane's plasma cell (a lane's own cells only)
             const int pcell = (!PLAIN && cf.pidx >= 1 && cf.pidx >= base && cf.pidx < base + 2 * H) ? cf.pidx - base : -1;  // lane-local
             uint32_t ptiles = 0u;
@@ -2425,7 +2428,7 @@ __global__ void __launch_bounds__(256, WEDM_WIDE_MIN_BLOCKS) wedm_step_regs_wide
 #pragma unroll
                 for (int t = 0; t < H / 8; ++t) ptiles |= __any(pt == t) ? (1u << t) : 0u;
             }
-            const uint32_t odd = ptiles | last_tile;  // regular tiles with cells to patch
+            const uint32_t odd = ptiles | last_tile | cut;  // regular tiles with cells to patch
             const f2 jfp = f2{jf_lane, jf_lane};
             f2 leftp = f2{halo_l, a_last};  // OLD pair before the tile
 #pragma unroll
@@ -2471,6 +2474,24 @@ __global__ void __launch_bounds__(256, WEDM_WIDE_MIN_BLOCKS) wedm_step_regs_wide
                             pn[7].x = hx ? x : pn[7].x; pn[7].y = hy ? x : pn[7].y;
                             extra = owns_last ? x : extra;
                         }
+                        // the wire's last cell inside a tile that the end cuts: the same, at its (uniform) place
+                        if ((cut >> t) & 1u) {
+                            int lw = lloc;  // (opaque here: or its 16 compares are made before the loop and kept in spilled scalars)
+                            asm volatile("" : "+s"(lw));
+#pragma unroll
+                            for (int u = 0; u < 8; ++u) {
+                                if (lw == j + u) {
+                                    const float x = stencil_cell(base + j + u, nw, tm[u].x, tc[u].x, 0.0f, gw, cw, ps, tref, alpha, tdiel);
+                                    pn[u].x = owns_last ? x : pn[u].x;
+                                    extra = owns_last ? x : extra;
+                                }
+                                if (lw == H + j + u) {
+                                    const float x = stencil_cell(base + H + j + u, nw, tm[u].y, tc[u].y, 0.0f, gw, cw, ps, tref, alpha, tdiel);
+                                    pn[u].y = owns_last ? x : pn[u].y;
+                                    extra = owns_last ? x : extra;
+                                }
+                            }
+                        }
                         // plasma cells of the lanes that have one in this tile: the predicated formula from the same OLD values
                         // (the regular value stays in the maximum, as where the LDS kernels patch the cell after the walk)
                         if (!PLAIN && ((ptiles >> t) & 1u)) {
@@ -2489,16 +2510,31 @@ __global__ void __launch_bounds__(256, WEDM_WIDE_MIN_BLOCKS) wedm_step_regs_wide
                             }
                         }
                     }
-                    // the maximum of the chunk halves that exist (a tile is whole or padding here)
-                    float mx = max3_raw(l7x, pn[0].x, pn[1].x), my = max3_raw(l7y, pn[0].y, pn[1].y);
-                    mx = max3_raw(mx, pn[2].x, pn[3].x); my = max3_raw(my, pn[2].y, pn[3].y);
-                    mx = max3_raw(mx, pn[4].x, pn[5].x); my = max3_raw(my, pn[4].y, pn[5].y);
-                    mx = fmax_gt(mx, pn[6].x); my = fmax_gt(my, pn[6].y);
-                    mx = nA > j ? mx : spool; my = nB > j ? my : spool;
+                    float mx, my;
+                    if ((cut >> t) & 1u) {
+                        // cell by cell over the cells that exist (the last cell's regular value stays out: `extra` has its own)
+                        mx = spool; my = spool;
+                        int va = ivA, vb = ivB;  // (opaque for the same reason)
+                        asm volatile("" : "+v"(va), "+v"(vb));
+#pragma unroll
+                        for (int u = 0; u < 8; ++u) {
+                            mx = (j + u < va) ? fmax_gt(mx, pn[u].x) : mx;
+                            my = (j + u < vb) ? fmax_gt(my, pn[u].y) : my;
+                        }
+                        // (the patched last cell and plasma cells were written into pn: take the regular values of the
+                        // plasma cells as the other tiles do -- they are below the patched ones -- and the patches by `extra`)
+                    } else {
+                        // the maximum of the chunk halves that exist (a tile is whole or padding here)
+                        mx = max3_raw(l7x, pn[0].x, pn[1].x); my = max3_raw(l7y, pn[0].y, pn[1].y);
+                        mx = max3_raw(mx, pn[2].x, pn[3].x); my = max3_raw(my, pn[2].y, pn[3].y);
+                        mx = max3_raw(mx, pn[4].x, pn[5].x); my = max3_raw(my, pn[4].y, pn[5].y);
+                        mx = fmax_gt(mx, pn[6].x); my = fmax_gt(my, pn[6].y);
+                        mx = nA > j ? mx : spool; my = nB > j ? my : spool;
+                    }
                     if ((odd >> t) & 1u) mx = fmax_gt(mx, extra);
                     tmax = max3_raw(tmax, mx, my);
                 } else {
-                    // the wire's end inside the tile, or a negative plasma heat: every cell that exists on the predicated formula
+                    // a negative plasma heat in the wave: every cell that exists on the predicated formula
                     if (PLAIN) prep_gw();
 #pragma unroll
                     for (int u = 0; u < 8; ++u) {
@@ -3435,25 +3471,30 @@ static int32_t plan_launch(wedm_ctx* ctx, bool single, bool tr, bool frozen_ok, 
             return fail(ctx, WEDM_ERR_UNSUPPORTED, "wedm_step: stencil_mode 1 (float64 stencil expressions) runs on kernels 1, 2 and 3 only");
         if (variant == 0) variant = (!single && fused_ok) ? 3 : (lanes_ok ? 2 : 1);
     }
-    // kernel 8 (wide register kernel): 16 lanes per environment, 32 cells each in registers; uniform geometry, float32
-    // stencil, at most 512 segments, no trace point.  Chosen by itself for long wires (more than 256 segments, a multiple
-    // of 8: no tile cut by the wire's end) in a batch that one round of blocks covers at one wave per SIMD
-    // (measured, 4 096 x 400: DESIGN.md 4.1b)
-    const bool wide_ok = uniform && P.n_seg >= 9 && P.n_seg <= 512 && !f64 && !ctx->replay && (ctx->lanes == 0 || ctx->lanes == 16);
-    if (variant == 0 && !single && !tr && wide_ok && ctx->lanes == 0 && P.n_seg > 256 && (P.n_seg & 7) == 0 &&
-        ctx->num_envs <= WEDM_WIDE_AUTO_MAX_ENVS)
+    // kernel 8 (wide register kernel): 4, 8 or 16 lanes per environment (the fewest that hold the wire), 32 cells each in
+    // registers; uniform geometry, float32 stencil, at most 512 segments, no trace point.  Chosen by itself for a batch
+    // that one round of blocks covers at one wave per
+    // SIMD: such a launch is one wave's dependent chain per microsecond whatever the kernel, and this one's is the
+    // shortest (measured, 4 096 x 400 and 16 384 x 128: DESIGN.md 4.1b)
+    const int wl_min = P.n_seg <= 128 ? 4 : P.n_seg <= 256 ? 8 : 16;
+    const int wl = (ctx->lanes == 4 || ctx->lanes == 8 || ctx->lanes == 16) ? ctx->lanes : wl_min;
+    const bool wide_ok = uniform && P.n_seg >= 9 && P.n_seg <= 512 && !f64 && !ctx->replay &&
+                         (ctx->lanes == 0 || (wl == ctx->lanes && wl >= wl_min));
+    if (variant == 0 && !single && !tr && wide_ok && ctx->lanes == 0 &&
+        (int64_t)ctx->num_envs * wl <= (int64_t)WEDM_WIDE_AUTO_MAX_LANES)
         variant = 8;
     if (variant == 8 && !wide_ok)
-        return fail(ctx, WEDM_ERR_UNSUPPORTED, "wedm_step: wide register kernel needs uniform geometry, 9 to 512 segments, the float32 stencil and lanes 0 or 16");
+        return fail(ctx, WEDM_ERR_UNSUPPORTED, "wedm_step: wide register kernel needs uniform geometry, 9 to 512 segments, the float32 stencil and lanes 0, 4, 8 or 16 with 32 cells per lane covering the wire");
     if (variant == 8 && tr) variant = packed_ok ? 4 : fused_ok ? 3 : lanes_ok ? 2 : 1;  // it has no trace point
     // kernel 7 (register kernel): one or two lanes per environment with the wire in their registers; wires of at most 128
     // segments, uniform geometry, float32 stencil; it has no trace point: a launch with a trace sample takes the LDS kernels
     const bool regs_ok = uniform && ctx->walk_regs_ok && ctx->n_seg_max <= 128 && !f64 && !ctx->replay;
     if (variant == 0) {
-        // fused launches of a batch that gives every CU a block of the register kernel (measured, 128 segments, two lanes
-        // per environment against the best LDS kernel: 8 192 environments 2.8e9 vs 3.5e9, 16 384: 5.6e9 vs 6.1e9,
-        // 32 768: 1.10e10 vs 9.8e9, 65 536: 1.67e10 vs 1.44e10, 131 072: 1.76e10 vs 1.50e10)
-        if (!single && !tr && regs_ok && ctx->lanes == 0 && ctx->num_envs >= 32768) variant = 7;
+        // fused launches of a batch that gives most CUs a block of the register kernel (measured, 128 segments, two lanes
+        // per environment against the best LDS kernel: 8 192 environments 2.8e9 vs 3.5e9, 16 384: 5.5e9 vs 6.1e9,
+        // 24 576: 8.3e9 vs 7.4e9, 32 768: 1.10e10 vs 9.9e9, 65 536: 1.67e10 vs 1.44e10, 131 072: 1.76e10 vs 1.50e10;
+        // up to 16 384 environments the wide register kernel above has taken the launch: 8.1e9 there)
+        if (!single && !tr && regs_ok && ctx->lanes == 0 && ctx->num_envs >= 20480) variant = 7;
     }
     if (variant == 0) {
         // single-microsecond launches: the stream kernel where one round of blocks covers the batch with chunks of
@@ -3493,9 +3534,9 @@ static int32_t plan_launch(wedm_ctx* ctx, bool single, bool tr, bool frozen_ok, 
         fn = rl == 1 ? (const void*)wedm_step_regs<128, 1> : (const void*)wedm_step_regs<128, 2>;
         std::snprintf(out.name, sizeof(out.name), "wedm_step_regs<%d><<<%d,256>>>", rl, grid);
     } else if (variant == 8) {
-        grid = (ctx->num_envs + 15) / 16;
-        fn = (const void*)wedm_step_regs_wide<16, 16>;
-        std::snprintf(out.name, sizeof(out.name), "wedm_step_regs_wide<16><<<%d,256>>>", grid);
+        grid = (ctx->num_envs + 256 / wl - 1) / (256 / wl);
+        fn = wl == 4 ? (const void*)wedm_step_regs_wide<16, 4> : wl == 8 ? (const void*)wedm_step_regs_wide<16, 8> : (const void*)wedm_step_regs_wide<16, 16>;
+        std::snprintf(out.name, sizeof(out.name), "wedm_step_regs_wide<%d><<<%d,256>>>", wl, grid);
     } else if (variant == 5) {
         grid = (ctx->num_envs + 63) / 64;
         fn = tr ? (const void*)wedm_step_split<true> : (const void*)wedm_step_split<false>;

@@ -375,8 +375,9 @@ class WireEDMEnv:
         fused with packed float32 math, 5 = global-memory stencil split over four waves, 6 =
         stream kernel (5 / 6: single microseconds; auto picks between them by shape), 7 = register
         kernel (one environment per lane, its whole wire in registers: wires of at most 128 segments,
-        uniform geometry); ``lanes`` lanes per environment for 2/3/4/6 (0 = auto).  All variants are
-        bit-identical."""
+        uniform geometry), 8 = wide register kernel (4 / 8 / 16 lanes per environment with 32 cells each in
+        registers: wires of 9 to 512 segments, uniform geometry; auto picks it for fused launches of small
+        batches); ``lanes`` lanes per environment for 2/3/4/6/8 (0 = auto).  All variants are bit-identical."""
         self._backend.set_kernel(variant)
         if hasattr(self._backend, "set_lanes"):
             self._backend.set_lanes(lanes)

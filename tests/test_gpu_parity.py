@@ -1554,8 +1554,9 @@ def test_wide_register_kernel_over_wire_lengths(part):
                   config=EnvironmentConfig(target_cutting_distance=5000.0))
         gpu, cpu = make_pair(n_envs, **kw)
         assert gpu.n_segments == n_seg
-        gpu.set_kernel(8, 0)
-        for env in (gpu, cpu):
+        fewest = 4 if n_seg <= 128 else 8 if n_seg <= 256 else 16      # lanes per environment: 32 cells each
+
+        def scenario(env):
             env.reset(seed=1000 + n_seg)
             close_gap(env, 21.0, 10.0)
             hot = env.state.wire_temperature
@@ -1566,12 +1567,46 @@ def test_wide_register_kernel_over_wire_lengths(part):
             env.step_many(act, 290)
             for _ in range(6):
                 env.step(act)
-        torch.cuda.synchronize()
-        assert "wedm_step_regs_wide<16>" in gpu._backend.last_kernel()
+
+        scenario(cpu)
         assert int(cpu.state.spark_count.sum()) > n_envs and bool(cpu.state.is_wire_broken[5])
-        diffs = block_diffs(gpu.state.clone_blocks(), cpu.state.clone_blocks(), n_envs)
-        assert not diffs, f"n_seg {n_seg}, kernel {gpu._backend.last_kernel()}:\n" + "\n".join(diffs[:10])
+        want = cpu.state.clone_blocks()
+        for lanes in sorted({0, fewest, 16}):                           # 0: the fewest lanes that hold the wire
+            gpu.set_kernel(8, lanes)
+            scenario(gpu)
+            torch.cuda.synchronize()
+            assert f"wedm_step_regs_wide<{lanes or fewest}>" in gpu._backend.last_kernel()
+            diffs = block_diffs(gpu.state.clone_blocks(), want, n_envs)
+            assert not diffs, f"n_seg {n_seg}, kernel {gpu._backend.last_kernel()}:\n" + "\n".join(diffs[:10])
+        if fewest > 4:
+            from sparc_amd._lib import WedmError
+            gpu.set_kernel(8, 4)                                        # too few lanes for this wire
+            with pytest.raises(WedmError, match="UNSUPPORTED"):
+                gpu.step_many(gpu.make_action(), 2)
         gpu.close()
+
+
+def test_wide_register_kernel_is_the_choice_for_small_batches_of_the_headline_grid():
+    """128 segments: 4 lanes per environment hold the wire; a batch that one round of blocks covers takes the wide register
+    kernel by itself (a larger one the two-lane register kernel or the LDS kernels); against the oracle, dense sparking."""
+    n = 3000
+    kw = dict(wire_params=WireModuleParameters(segment_len=0.625))
+    gpu, cpu = make_pair(n, **kw)
+    both((gpu, cpu), lambda e: (e.reset(seed=606), close_gap(e, 18.0, 10.0)))
+    rng = np.random.default_rng(1)
+    modes = rng.choice([5, 9, 13, 17], n).astype(np.int32)
+    on = rng.choice([1.0, 2.0, 3.5, 5.0], n)
+    for env in (gpu, cpu):
+        a = env.make_action(0.05, 80.0, modes, on, 15.0)
+        for k in (1000, 777):
+            env.step_many(a, k)
+    assert "wedm_step_regs_wide<4>" in gpu._backend.last_kernel(), gpu._backend.last_kernel()
+    check(gpu, cpu, n)
+    assert int(gpu.state.spark_count.sum()) / n / 1.777 > 5.0          # densely sparking indeed
+    big = WireEDMEnv(num_envs=20000, device="cuda:0", **kw)
+    big.reset(seed=1)
+    big.step_many(big.make_action(), 10)
+    assert "wedm_step_regs_wide" not in big._backend.last_kernel()
 
 
 def test_wide_register_kernel_config2_batch_densely_sparking_matches_oracle():
