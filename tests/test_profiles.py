@@ -108,3 +108,25 @@ def test_other_workload_lines_are_well_formed(name, bound):
     assert b["config"]["ranks"] == 1 and b["config"]["env_id_offsets"] == [0]
     if b["roofline"].get("frac") is not None:
         assert 0.0 < b["roofline"]["frac"] <= 1.0
+
+
+def test_config2_line_is_the_wide_register_kernel_above_the_verdicts_bar():
+    """BASELINE configs[1] (4 096 x 400): round 2's verdict asked for >= 1.41e9 env-steps/s, 0.6 of the SURVEY 8(d)
+    algorithmic-HBM line.  The line is the wide register kernel's, its instruction count is the PMC pass's of the same
+    build, and the kernel issues no LDS instruction."""
+    b = bench("bench_config2.json")
+    assert "BASELINE configs[1]" in b["config"]["workload"] and b["config"]["global_num_envs"] == 4096
+    kernel = b["config"]["kernel"]
+    assert "wedm_step_regs_wide<16>" in kernel
+    assert b["value"] >= 1.9e9
+    alg = b["value"] * (8 * 400 + 208)                                  # B(S) = 8 S + 208 bytes per env-step
+    assert alg / 8.0e12 >= 0.6
+    valu = recorded("valu.json", kernel)
+    assert valu is not None and valu["build_id"] == b["config"]["build_id"]
+    sq = {l.split("\t")[2]: float(l.split("\t")[3]) for l in (R / "rocprofv3_pmc_sq_config2.txt").read_text().splitlines()}
+    assert sq["SQ_INSTS_VALU"] == pytest.approx(valu["valu_insts_per_launch"], rel=1e-9)
+    assert sq["SQ_INSTS_LDS"] == 0 and sq["SQ_WAVES"] == 1024           # 16 lanes per environment: one wave per SIMD
+    per_env_step = valu["valu_insts_per_launch"] / valu["env_steps_per_launch"]
+    assert 140 < per_env_step < 170
+    # the pipe-occupancy figure of DESIGN.md 4.1b
+    assert 0.5 < sq["SQ_ACTIVE_INST_VALU"] / sq["SQ_WAVE_CYCLES"] < 0.65
