@@ -2285,7 +2285,9 @@ __device__ __forceinline__ float dpp_perm(float x) {
 #ifndef WEDM_WIDE_AUTO_MAX_LANES
 #define WEDM_WIDE_AUTO_MAX_LANES 65536  // one block per CU: 4 096 environments x 16 lanes, 16 384 x 4
 #endif
-template <int H, int L>
+// CUT: the instantiation for wires whose end cuts a tile (n_seg not a multiple of 8); the code for that tile costs the
+// regular path 2 - 3 % by its presence (registers), so the other wires run the instantiation without it.
+template <int H, int L, bool CUT>
 __global__ void __launch_bounds__(256, WEDM_WIDE_MIN_BLOCKS) wedm_step_regs_wide(const KArgs k) {
     static_assert(H % 8 == 0 && H <= 32, "whole tiles");
     static_assert(L == 4 || L == 8 || L == 16, "the lanes of an environment lie in one DPP row");
@@ -2351,10 +2353,12 @@ __global__ void __launch_bounds__(256, WEDM_WIDE_MIN_BLOCKS) wedm_step_regs_wide
     // the tile the wire's end cuts, if n_seg is not a multiple of 8 (wave-uniform: uniform geometry): regular code too, with
     // its maximum taken cell by cell over the cells that exist and the last cell patched where it lies
     uint32_t cut = 0u;
+    if (CUT) {
 #pragma unroll
-    for (int t = 0; t < H / 8; ++t)
-        cut |= __any((nA > 8 * t && nA < 8 * t + 8) || (nB > 8 * t && nB < 8 * t + 8)) ? (1u << t) : 0u;
-    cut = __builtin_amdgcn_readfirstlane(cut);
+        for (int t = 0; t < H / 8; ++t)
+            cut |= __any((nA > 8 * t && nA < 8 * t + 8) || (nB > 8 * t && nB < 8 * t + 8)) ? (1u << t) : 0u;
+        cut = __builtin_amdgcn_readfirstlane(cut);
+    }
     // the wire's last cell: in a tile the end does not cut it is the last cell of its tile (n_seg a multiple of 8)
     const int ll = n - 1 - base;  // lane-local index of the last cell, if this lane holds it
     const bool owns_last = ll >= 0 && ll < 2 * H;
@@ -3535,7 +3539,10 @@ static int32_t plan_launch(wedm_ctx* ctx, bool single, bool tr, bool frozen_ok, 
         std::snprintf(out.name, sizeof(out.name), "wedm_step_regs<%d><<<%d,256>>>", rl, grid);
     } else if (variant == 8) {
         grid = (ctx->num_envs + 256 / wl - 1) / (256 / wl);
-        fn = wl == 4 ? (const void*)wedm_step_regs_wide<16, 4> : wl == 8 ? (const void*)wedm_step_regs_wide<16, 8> : (const void*)wedm_step_regs_wide<16, 16>;
+        fn = (P.n_seg & 7) ? (wl == 4 ? (const void*)wedm_step_regs_wide<16, 4, true> : wl == 8 ? (const void*)wedm_step_regs_wide<16, 8, true>
+                                                                                             : (const void*)wedm_step_regs_wide<16, 16, true>)
+                           : (wl == 4 ? (const void*)wedm_step_regs_wide<16, 4, false> : wl == 8 ? (const void*)wedm_step_regs_wide<16, 8, false>
+                                                                                              : (const void*)wedm_step_regs_wide<16, 16, false>);
         std::snprintf(out.name, sizeof(out.name), "wedm_step_regs_wide<%d><<<%d,256>>>", wl, grid);
     } else if (variant == 5) {
         grid = (ctx->num_envs + 63) / 64;
