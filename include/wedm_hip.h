@@ -402,8 +402,8 @@ int64_t wedm_trace_samples(wedm_ctx* ctx);
  * 8 = wide register kernel (4, 8 or 16 lanes per environment -- the fewest that hold the wire at 32 cells per lane --
  * with the wire in their registers and per-cell zone / contact coefficients: no LDS, no tile table; uniform geometry,
  * 9 to 512 segments, float32 stencil; the automatic choice for fused launches of a batch that one round of blocks
- * covers -- environments x lanes <= 65 536 -- when the segment count is a multiple of 8; launches with a trace sample
- * take the LDS kernels).  All variants produce bit-identical results.  With wedm_params.stencil_mode 1 only 0, 1, 2 and 3 are accepted (3: the tile walk with
+ * covers: environments x lanes <= 65 536; own instantiations for wires whose length is not a multiple of 8 and for
+ * launches with a trace sample).  All variants produce bit-identical results.  With wedm_params.stencil_mode 1 only 0, 1, 2 and 3 are accepted (3: the tile walk with
  * per-cell coefficients, no stage-major / packed form).                                          */
 int32_t wedm_set_kernel(wedm_ctx* ctx, int32_t variant);
 

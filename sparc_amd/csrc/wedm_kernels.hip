@@ -2247,7 +2247,7 @@ __global__ void __launch_bounds__(256, L) wedm_step_regs(const KArgs k) {
 
 
 // ============================================ wide register kernel: long wires of a SMALL batch in registers
-// Wires of up to 2 H L (512) segments, uniform geometry, float32 stencil, launches without a trace sample.
+// Wires of up to 2 H L (512) segments, uniform geometry, float32 stencil.
 // The case it is for is 4 096 x 400: a batch that gives the chip one wave per SIMD whatever the kernel, so a launch's
 // time is the dependent chain of ONE wave per microsecond, and what shortens the chain is fewer cells per lane and no
 // LDS round trip inside it.  L = 16 lanes -- one DPP row -- own an environment; a lane holds 2 H = 32 cells as H = 16
@@ -2287,7 +2287,8 @@ __device__ __forceinline__ float dpp_perm(float x) {
 #endif
 // CUT: the instantiation for wires whose end cuts a tile (n_seg not a multiple of 8); the code for that tile costs the
 // regular path 2 - 3 % by its presence (registers), so the other wires run the instantiation without it.
-template <int H, int L, bool CUT>
+// TRACE: the instantiation with the signal-trace point (a launch into which a sample falls); built on the CUT form.
+template <int H, int L, bool CUT, bool TRACE = false>
 __global__ void __launch_bounds__(256, WEDM_WIDE_MIN_BLOCKS) wedm_step_regs_wide(const KArgs k) {
     static_assert(H % 8 == 0 && H <= 32, "whole tiles");
     static_assert(L == 4 || L == 8 || L == 16, "the lanes of an environment lie in one DPP row");
@@ -2378,9 +2379,12 @@ __global__ void __launch_bounds__(256, WEDM_WIDE_MIN_BLOCKS) wedm_step_regs_wide
     };
     build_conv();
     WEDM_STAMP_DECL;
+    const bool tracing = WEDM_TRACING(k);
+    int trace_next = k.trace_next, trace_slot = k.trace_slot;
+    (void)trace_next; (void)trace_slot;
 
     for (int it = 0; it < k.n_substeps; ++it) {
-        if (__all(s.done)) break;
+        if (__all(s.done) && !tracing) break;  // (terminated environments keep being sampled: their frozen state)
         WEDM_STAMP(st0);
         Coef cf{0.0f, 0.0f, 0, -1};
         QuietTry qt;
@@ -2578,6 +2582,11 @@ __global__ void __launch_bounds__(256, WEDM_WIDE_MIN_BLOCKS) wedm_step_regs_wide
         }
         WEDM_STAMP(st4);
         WEDM_STAMP_ACC();
+        WEDM_TRACE_POINT(k, it, e, s, writer,
+                         for (int m = 0; m < H; ++m) {
+                             if (base + m < n) tT[(int64_t)(base + m) * tcnt] = P[m].x;
+                             if (base + H + m < n) tT[(int64_t)(base + H + m) * tcnt] = P[m].y;
+                         });
     }
     WEDM_STAMP_OUT();
 
@@ -3476,7 +3485,7 @@ static int32_t plan_launch(wedm_ctx* ctx, bool single, bool tr, bool frozen_ok, 
         if (variant == 0) variant = (!single && fused_ok) ? 3 : (lanes_ok ? 2 : 1);
     }
     // kernel 8 (wide register kernel): 4, 8 or 16 lanes per environment (the fewest that hold the wire), 32 cells each in
-    // registers; uniform geometry, float32 stencil, at most 512 segments, no trace point.  Chosen by itself for a batch
+    // registers; uniform geometry, float32 stencil, at most 512 segments.  Chosen by itself for a batch
     // that one round of blocks covers at one wave per
     // SIMD: such a launch is one wave's dependent chain per microsecond whatever the kernel, and this one's is the
     // shortest (measured, 4 096 x 400 and 16 384 x 128: DESIGN.md 4.1b)
@@ -3484,12 +3493,11 @@ static int32_t plan_launch(wedm_ctx* ctx, bool single, bool tr, bool frozen_ok, 
     const int wl = (ctx->lanes == 4 || ctx->lanes == 8 || ctx->lanes == 16) ? ctx->lanes : wl_min;
     const bool wide_ok = uniform && P.n_seg >= 9 && P.n_seg <= 512 && !f64 && !ctx->replay &&
                          (ctx->lanes == 0 || (wl == ctx->lanes && wl >= wl_min));
-    if (variant == 0 && !single && !tr && wide_ok && ctx->lanes == 0 &&
+    if (variant == 0 && !single && wide_ok && ctx->lanes == 0 &&
         (int64_t)ctx->num_envs * wl <= (int64_t)WEDM_WIDE_AUTO_MAX_LANES)
         variant = 8;
     if (variant == 8 && !wide_ok)
         return fail(ctx, WEDM_ERR_UNSUPPORTED, "wedm_step: wide register kernel needs uniform geometry, 9 to 512 segments, the float32 stencil and lanes 0, 4, 8 or 16 with 32 cells per lane covering the wire");
-    if (variant == 8 && tr) variant = packed_ok ? 4 : fused_ok ? 3 : lanes_ok ? 2 : 1;  // it has no trace point
     // kernel 7 (register kernel): one or two lanes per environment with the wire in their registers; wires of at most 128
     // segments, uniform geometry, float32 stencil; it has no trace point: a launch with a trace sample takes the LDS kernels
     const bool regs_ok = uniform && ctx->walk_regs_ok && ctx->n_seg_max <= 128 && !f64 && !ctx->replay;
@@ -3539,7 +3547,9 @@ static int32_t plan_launch(wedm_ctx* ctx, bool single, bool tr, bool frozen_ok, 
         std::snprintf(out.name, sizeof(out.name), "wedm_step_regs<%d><<<%d,256>>>", rl, grid);
     } else if (variant == 8) {
         grid = (ctx->num_envs + 256 / wl - 1) / (256 / wl);
-        fn = (P.n_seg & 7) ? (wl == 4 ? (const void*)wedm_step_regs_wide<16, 4, true> : wl == 8 ? (const void*)wedm_step_regs_wide<16, 8, true>
+        fn = tr ? (wl == 4 ? (const void*)wedm_step_regs_wide<16, 4, true, true> : wl == 8 ? (const void*)wedm_step_regs_wide<16, 8, true, true>
+                                                                                       : (const void*)wedm_step_regs_wide<16, 16, true, true>)
+           : (P.n_seg & 7) ? (wl == 4 ? (const void*)wedm_step_regs_wide<16, 4, true> : wl == 8 ? (const void*)wedm_step_regs_wide<16, 8, true>
                                                                                              : (const void*)wedm_step_regs_wide<16, 16, true>)
                            : (wl == 4 ? (const void*)wedm_step_regs_wide<16, 4, false> : wl == 8 ? (const void*)wedm_step_regs_wide<16, 8, false>
                                                                                               : (const void*)wedm_step_regs_wide<16, 16, false>);

@@ -548,7 +548,7 @@ def assert_rings_equal(tg, tc, rows=None):
         assert torch.equal(G, Cc), f"trace T: {int((G != Cc).sum())} of {G.numel()} differ"
 
 
-@pytest.mark.parametrize("variant,lanes", KERNELS)
+@pytest.mark.parametrize("variant,lanes", KERNELS + [(8, 0)])
 def test_device_trace_ring_matches_oracle(variant, lanes):
     """The ring the kernels fill inside fused launches == the ring the oracle seam fills by
     sampling after single microseconds: every slot, every traced row, wire temperature included."""
@@ -1528,11 +1528,11 @@ def test_wide_register_kernel_on_the_default_grid_matches_oracle(mode):
     if mode == "autoreset":
         assert int(st.episode.max()) >= 1
         return   # (the oracle seam samples a trace after single microseconds, and every launch boundary is an episode boundary here)
-    # a launch with a trace sample has no register-kernel form: the LDS kernels take it, results unchanged
-    traces = [e.bind_trace(["voltage", "wire_max_temperature"], every=1, capacity=64, envs=(0, 64)) for e in (gpu, cpu)]
+    # a launch with a trace sample: the instantiation with the trace point, wire temperature included
+    traces = [e.bind_trace(["voltage", "wire_max_temperature"], every=1, capacity=64, envs=(0, 64), wire_temperature=True) for e in (gpu, cpu)]
     for env in (gpu, cpu):
         env.step_many(env.make_action(0.1, 80.0, 17, 3.0, 20.0), 40)
-    assert "wedm_step_regs_wide" not in gpu._backend.last_kernel()
+    assert "wedm_step_regs_wide<16>" in gpu._backend.last_kernel()
     assert_rings_equal(*traces)
     check(gpu, cpu, n)
 
