@@ -239,6 +239,11 @@ def roofline_block(kernel_name, kernel_ms, n_envs, n_sub, n_seg, traffic_overrid
     where = "in the lanes' registers" if "wedm_step_regs" in kernel_name else "in LDS"
     out["note"] = (f"the fused launch keeps the wire {where} for all its microseconds: HBM sees each byte once per launch, "
                    "the kernel is bound by VALU issue; frac = wave-level VALU instructions per second / (1024 SIMDs x 2.4 GHz / 2)")
+    if "wedm_step_regs_wide" in kernel_name:
+        # the batch gives the chip at most one wave per SIMD: nothing overlaps with a wave's own dependent chain
+        out["note"] += ("; this batch is one round of blocks at ONE wave per SIMD, so the launch lasts as long as a wave's "
+                        "dependent chain per microsecond (prelude -> walk -> epilogue: DESIGN.md 4.1b) -- the occupancy of the "
+                        "VALU pipe (valu_pipe_busy) and the algorithmic-HBM equivalent say how much of the chip that leaves idle")
     return out
 
 
