@@ -2260,7 +2260,9 @@ __global__ void __launch_bounds__(256, L) wedm_step_regs(const KArgs k) {
 //   * zone and contact flags per CELL, from the geometry's indices, as registers: a convection coefficient pair per
 //     pair of cells (rebuilt when the general prelude refreshes the coefficients) and a 0 / 1 Joule mask pair; a tile is
 //     regular whatever flags change inside it, also the one the wire's end cuts (n_seg not a multiple of 8: its maximum
-//     is taken cell by cell).  What is left for the predicated per-cell code is a wave with a negative plasma heat.
+//     is taken cell by cell).  The few cells that are not interior cells (the last cell, plasma cells) are recomputed
+//     by the predicated formula and replace the regular result before the maximum is taken: there is no per-cell
+//     fallback walk at all, not even for a negative plasma heat.
 //   * halos between the lanes of an environment by DPP row shifts, the maximum over them by DPP quad / row mirrors.
 __device__ __forceinline__ float dpp_row_shr1(float old, float x) {  // lane i <- lane i - 1 of its row of 16; lane 0 keeps `old`
     return __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(old), __float_as_int(x), 0x111, 0xF, 0xF, false));
@@ -2366,8 +2368,6 @@ __global__ void __launch_bounds__(256, WEDM_WIDE_MIN_BLOCKS) wedm_step_regs_wide
     const int lloc = (n - 1) & (2 * H - 1);  // the same index, wave-uniform
     const bool last_in_b = lloc >= H;
     const uint32_t last_tile = ((n & 7) == 0) ? (1u << ((lloc & (H - 1)) >> 3)) : 0u;
-    // cells of the two chunks that enter the regular maximum: those that exist, without the wire's last cell
-    const int ivA = min(max(n - 1 - base, 0), H), ivB = min(max(n - 1 - base - H, 0), H);
     // 0 / 1 Joule mask pairs and the convection coefficient pairs of this lane's cells
     f2 jm[H], convc[H];
 #pragma unroll
@@ -2423,11 +2423,8 @@ __global__ void __launch_bounds__(256, WEDM_WIDE_MIN_BLOCKS) wedm_step_regs_wide
                 asm volatile("" : "+s"(nw));
             };
             if (!PLAIN) prep_gw();
-            // a wave with a negative plasma heat walks every cell on the predicated formula (identical results, slower)
-            const bool all_slow = !PLAIN && __any(cf.q < 0.0f);
             const float jf_lane = (!PLAIN && cf.joule_on) ? cf.jf : 0.0f;
             const bool joule_wave = !PLAIN && __any(jf_lane != 0.0f);
-            const uint32_t n_now = all_slow ? 0u : ~0u;
             // the tiles that hold some lane's plasma cell (a lane's own cells only)
             const int pcell = (!PLAIN && cf.pidx >= 1 && cf.pidx >= base && cf.pidx < base + 2 * H) ? cf.pidx - base : -1;  // lane-local
             uint32_t ptiles = 0u;
@@ -2450,7 +2447,7 @@ __global__ void __launch_bounds__(256, WEDM_WIDE_MIN_BLOCKS) wedm_step_regs_wide
                     tp[u] = (j + u + 1 < H) ? P[j + u + 1 < H ? j + u + 1 : 0] : f2{b_first, halo_r};
                 }
                 leftp = tc[7];
-                if ((n_now >> t) & 1u) {
+                {
                     f2 tmA[4], tcA[4], tpA[4], pnA[4], tmB[4], tcB[4], tpB[4], pnB[4], cvA[4], cvB[4];
 #pragma unroll
                     for (int u = 0; u < 4; ++u) {
@@ -2470,17 +2467,17 @@ __global__ void __launch_bounds__(256, WEDM_WIDE_MIN_BLOCKS) wedm_step_regs_wide
 #pragma unroll
                     for (int u = 0; u < 4; ++u) { pn[u] = pnA[u]; pn[4 + u] = pnB[u]; }
                     if (t == 0) pn[0].x = (c == 0) ? spool : pn[0].x;  // wire cell 0
-                    float l7x = pn[7].x, l7y = pn[7].y, extra = spool;
+                    // The cells that are not interior cells take the predicated formula from the same OLD values and replace the
+                    // regular result BEFORE the maximum is taken: the maximum is over the true new temperatures, whatever
+                    // the sign of a plasma heat (no per-cell fallback for a negative one, as the LDS kernels need).
                     if ((odd >> t) & 1u) {
                         if (PLAIN) prep_gw();
-                        // the wire's last cell (last position of its tile): out of the regular maximum, predicated formula
+                        // the wire's last cell (last position of its tile)
                         if ((last_tile >> t) & 1u) {
                             const float x = stencil_cell(base + (last_in_b ? H : 0) + j + 7, nw, last_in_b ? tm[7].y : tm[7].x,
                                                          last_in_b ? tc[7].y : tc[7].x, 0.0f, gw, cw, ps, tref, alpha, tdiel);
                             const bool hx = owns_last && !last_in_b, hy = owns_last && last_in_b;
-                            l7x = hx ? spool : l7x; l7y = hy ? spool : l7y;
                             pn[7].x = hx ? x : pn[7].x; pn[7].y = hy ? x : pn[7].y;
-                            extra = owns_last ? x : extra;
                         }
                         // the wire's last cell inside a tile that the end cuts: the same, at its (uniform) place
                         if ((cut >> t) & 1u) {
@@ -2491,74 +2488,48 @@ __global__ void __launch_bounds__(256, WEDM_WIDE_MIN_BLOCKS) wedm_step_regs_wide
                                 if (lw == j + u) {
                                     const float x = stencil_cell(base + j + u, nw, tm[u].x, tc[u].x, 0.0f, gw, cw, ps, tref, alpha, tdiel);
                                     pn[u].x = owns_last ? x : pn[u].x;
-                                    extra = owns_last ? x : extra;
                                 }
                                 if (lw == H + j + u) {
                                     const float x = stencil_cell(base + H + j + u, nw, tm[u].y, tc[u].y, 0.0f, gw, cw, ps, tref, alpha, tdiel);
                                     pn[u].y = owns_last ? x : pn[u].y;
-                                    extra = owns_last ? x : extra;
                                 }
                             }
                         }
-                        // plasma cells of the lanes that have one in this tile: the predicated formula from the same OLD values
-                        // (the regular value stays in the maximum, as where the LDS kernels patch the cell after the walk)
+                        // plasma cells of the lanes that have one in this tile
                         if (!PLAIN && ((ptiles >> t) & 1u)) {
 #pragma unroll
                             for (int u = 0; u < 8; ++u) {
                                 if (__any(pcell == j + u)) {
                                     const float x = stencil_cell(base + j + u, nw, (base + j + u == 1) ? spool : tm[u].x, tc[u].x, tp[u].x, gw, cf, ps, tref, alpha, tdiel);
                                     pn[u].x = (pcell == j + u) ? x : pn[u].x;
-                                    extra = (pcell == j + u) ? fmax_gt(extra, x) : extra;
                                 }
                                 if (__any(pcell == H + j + u)) {
                                     const float x = stencil_cell(base + H + j + u, nw, tm[u].y, tc[u].y, tp[u].y, gw, cf, ps, tref, alpha, tdiel);
                                     pn[u].y = (pcell == H + j + u) ? x : pn[u].y;
-                                    extra = (pcell == H + j + u) ? fmax_gt(extra, x) : extra;
                                 }
                             }
                         }
                     }
                     float mx, my;
                     if ((cut >> t) & 1u) {
-                        // cell by cell over the cells that exist (the last cell's regular value stays out: `extra` has its own)
+                        // cell by cell over the cells that exist
                         mx = spool; my = spool;
-                        int va = ivA, vb = ivB;  // (opaque for the same reason)
+                        int va = nA, vb = nB;  // (opaque for the same reason)
                         asm volatile("" : "+v"(va), "+v"(vb));
 #pragma unroll
                         for (int u = 0; u < 8; ++u) {
                             mx = (j + u < va) ? fmax_gt(mx, pn[u].x) : mx;
                             my = (j + u < vb) ? fmax_gt(my, pn[u].y) : my;
                         }
-                        // (the patched last cell and plasma cells were written into pn: take the regular values of the
-                        // plasma cells as the other tiles do -- they are below the patched ones -- and the patches by `extra`)
                     } else {
                         // the maximum of the chunk halves that exist (a tile is whole or padding here)
-                        mx = max3_raw(l7x, pn[0].x, pn[1].x); my = max3_raw(l7y, pn[0].y, pn[1].y);
-                        mx = max3_raw(mx, pn[2].x, pn[3].x); my = max3_raw(my, pn[2].y, pn[3].y);
-                        mx = max3_raw(mx, pn[4].x, pn[5].x); my = max3_raw(my, pn[4].y, pn[5].y);
-                        mx = fmax_gt(mx, pn[6].x); my = fmax_gt(my, pn[6].y);
+                        mx = max3_raw(pn[0].x, pn[1].x, pn[2].x); my = max3_raw(pn[0].y, pn[1].y, pn[2].y);
+                        mx = max3_raw(mx, pn[3].x, pn[4].x); my = max3_raw(my, pn[3].y, pn[4].y);
+                        mx = max3_raw(mx, pn[5].x, pn[6].x); my = max3_raw(my, pn[5].y, pn[6].y);
+                        mx = fmax_gt(mx, pn[7].x); my = fmax_gt(my, pn[7].y);
                         mx = nA > j ? mx : spool; my = nB > j ? my : spool;
                     }
-                    if ((odd >> t) & 1u) mx = fmax_gt(mx, extra);
                     tmax = max3_raw(tmax, mx, my);
-                } else {
-                    // a negative plasma heat in the wave: every cell that exists on the predicated formula
-                    if (PLAIN) prep_gw();
-#pragma unroll
-                    for (int u = 0; u < 8; ++u) {
-                        pn[u] = tc[u];
-                        const int ia = base + j + u, ib = base + H + j + u;
-                        {
-                            const float x = (ia >= 1) ? stencil_cell(ia, nw, (ia == 1) ? spool : tm[u].x, tc[u].x, tp[u].x, gw, cw, ps, tref, alpha, tdiel) : spool;
-                            pn[u].x = ia < nw ? x : pn[u].x;
-                            tmax = ia < nw ? fmax_gt(tmax, x) : tmax;
-                        }
-                        {
-                            const float x = stencil_cell(ib, nw, tm[u].y, tc[u].y, tp[u].y, gw, cw, ps, tref, alpha, tdiel);
-                            pn[u].y = ib < nw ? x : pn[u].y;
-                            tmax = ib < nw ? fmax_gt(tmax, x) : tmax;
-                        }
-                    }
                 }
 #pragma unroll
                 for (int u = 0; u < 8; ++u) P[j + u] = pn[u];

@@ -1625,3 +1625,38 @@ def test_wide_register_kernel_config2_batch_densely_sparking_matches_oracle():
     assert "wedm_step_regs_wide<16>" in gpu._backend.last_kernel(), gpu._backend.last_kernel()
     check(gpu, cpu, n)
     assert int(gpu.state.spark_count.sum()) / n / 1.777 > 5.0          # densely sparking indeed
+
+
+@pytest.mark.parametrize("segment_len", [0.2, 0.625])
+def test_negative_plasma_heat_every_kernel_matches_oracle(segment_len):
+    """A negative plasma efficiency makes the plasma heat negative: the plasma cell's true temperature then lies BELOW
+    the interior formula's result, so a kernel that patches the cell after its walk must keep the regular value out
+    of the running maximum (the LDS and two-lane register kernels walk such a wave on the predicated formula; the
+    wide register kernel patches before it takes the maximum).  Densely sparking, hot wire: Tmax, the critical-time
+    counter and every cell against the oracle, every kernel that accepts the shape."""
+    from sparc_amd._lib import WedmError
+
+    n = 200
+    kw = dict(wire_params=WireModuleParameters(segment_len=segment_len, plasma_efficiency=-0.2),
+              config=EnvironmentConfig(target_cutting_distance=5000.0))
+    gpu, cpu = make_pair(n, **kw)
+    ran = 0
+    for variant, lanes in KERNELS + [(0, 0), (7, 0), (8, 0)]:
+        gpu.set_kernel(variant, lanes)
+        for env in (gpu, cpu):
+            env.reset(seed=515)
+            close_gap(env, 18.0, 10.0)
+        try:
+            gpu.step_many(gpu.make_action(0.05, 80.0, 17, 3.0, 15.0), 700)
+            gpu.step(gpu.make_action(0.05, 80.0, 17, 3.0, 15.0))
+        except WedmError as exc:
+            assert "UNSUPPORTED" in str(exc)
+            continue
+        cpu.step_many(cpu.make_action(0.05, 80.0, 17, 3.0, 15.0), 701)
+        torch.cuda.synchronize()
+        diffs = block_diffs(gpu.state.clone_blocks(), cpu.state.clone_blocks(), n)
+        assert not diffs, f"kernel {gpu._backend.last_kernel()}:\n" + "\n".join(diffs[:10])
+        ran += 1
+    assert ran >= 8 and int(cpu.state.spark_count.sum()) > 5 * n
+    T = cpu.state.wire_temperature
+    assert float(torch.as_tensor(T[:, :]).min()) < 293.0      # cells cooled below the spool temperature by the negative heat

@@ -118,7 +118,7 @@ def test_config2_line_is_the_wide_register_kernel_above_the_verdicts_bar():
     assert "BASELINE configs[1]" in b["config"]["workload"] and b["config"]["global_num_envs"] == 4096
     kernel = b["config"]["kernel"]
     assert "wedm_step_regs_wide<16>" in kernel
-    assert b["value"] >= 2.0e9
+    assert b["value"] >= 2.1e9
     alg = b["value"] * (8 * 400 + 208)                                  # B(S) = 8 S + 208 bytes per env-step
     assert alg / 8.0e12 >= 0.6
     valu = recorded("valu.json", kernel)
@@ -127,6 +127,6 @@ def test_config2_line_is_the_wide_register_kernel_above_the_verdicts_bar():
     assert sq["SQ_INSTS_VALU"] == pytest.approx(valu["valu_insts_per_launch"], rel=1e-9)
     assert sq["SQ_INSTS_LDS"] == 0 and sq["SQ_WAVES"] == 1024           # 16 lanes per environment: one wave per SIMD
     per_env_step = valu["valu_insts_per_launch"] / valu["env_steps_per_launch"]
-    assert 140 < per_env_step < 170
+    assert 135 < per_env_step < 160
     # the pipe-occupancy figure of DESIGN.md 4.1b
     assert 0.5 < sq["SQ_ACTIVE_INST_VALU"] / sq["SQ_WAVE_CYCLES"] < 0.65
