@@ -130,3 +130,9 @@ def test_config2_line_is_the_wide_register_kernel_above_the_verdicts_bar():
     assert 135 < per_env_step < 160
     # the pipe-occupancy figure of DESIGN.md 4.1b
     assert 0.5 < sq["SQ_ACTIVE_INST_VALU"] / sq["SQ_WAVE_CYCLES"] < 0.65
+
+
+def test_config2_kernel_duration_by_rocprofv3_agrees_with_the_hip_events():
+    b = bench("bench_config2.json")
+    avg_ms, calls = rocprof_avg_ms("rocprofv3_kernel_stats_config2.csv", "wedm_step_regs_wide<16, 16")
+    assert calls >= 20 and avg_ms == pytest.approx(b["roofline"]["kernel_ms"], rel=0.05)

@@ -57,5 +57,8 @@ cp $(find $OUT/kt -name "*kernel_stats.csv" | head -1) $S/rocprofv3_kernel_stats
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/kt1 -o kt -- python3 bench.py --steps 400 --warmup 50 --substeps 1 --no-cpu-baseline --no-side > $OUT/kt1.log 2>&1
 cp $(find $OUT/kt1 -name "*kernel_stats.csv" | head -1) $S/rocprofv3_kernel_stats_config3_1us.csv
 
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/kt2 -o kt -- python3 bench.py --steps 20 --warmup 2 --workload config2 --no-cpu-baseline --no-side > $OUT/kt2.log 2>&1
+cp $(find $OUT/kt2 -name "*kernel_stats.csv" | head -1) $S/rocprofv3_kernel_stats_config2.csv
+
 echo "[profile] done"; date +%T
 ls -la $S
