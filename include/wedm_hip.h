@@ -122,7 +122,7 @@ enum wedm_i32_field {
     WEDM_I_KEY_HI,             /* Philox key, high 32 bits of the reset seed */
     WEDM_I_SPARK_COUNT,        /* fresh sparks since reset (len(crater_volumes_um3), material.py:133) */
     WEDM_I_TIME_HI,            /* state.time >> 32: bumped by wedm_step when the low word wraps inside a launch (a launch
-                                  advances an environment by less than 2^32 us; n_substeps * dt_us must stay below that) */
+                                  advances an environment by less than 2^31 us: wedm_step refuses n_substeps * dt_us >= 2^31) */
     WEDM_I32_COUNT
 };
 

@@ -55,26 +55,50 @@ _FIELDS = {
 
 
 _BINARY_DUNDERS = ("add", "sub", "mul", "truediv", "radd", "rsub", "rmul", "eq", "ne", "lt", "le", "gt", "ge")
+_INPLACE_DUNDERS = ("iadd", "isub", "imul", "itruediv")
+
+
+def _is_basic_index(idx) -> bool:
+    """Integers, slices, None and Ellipsis: indexing with these yields a VIEW of the indexed tensor."""
+    items = idx if isinstance(idx, tuple) else (idx,)
+    return all(i is None or i is Ellipsis or isinstance(i, (int, slice)) for i in items)
 
 
 class WireTemperature:
     """``state.wire_temperature``: the ``[num_envs, n_seg]`` face of the quad-interleaved ``T`` block.
 
     The block's layout (``T[seg >> 2][env][seg & 3]``) cannot be expressed as ONE strided 2-D view, so this small
-    proxy keeps the reference's indexing on both sides: reading (``wt[e]``, ``wt[2:5, 10:20]``, ``wt.cpu()``, any
-    torch function) gathers a ``[num_envs, n_seg]`` tensor; writing (``wt[: n // 2, 180:186] = 1600.0``,
-    ``wt.copy_(x)``, ``wt.fill_(v)``) gathers, assigns and scatters back, so assignments write through as they
-    do on the reference's NumPy array.  ``wt.quads`` is the zero-copy ``[num_envs, n_seg / 4, 4]`` view."""
+    proxy keeps the reference's indexing on both sides.
 
-    def __init__(self, T: torch.Tensor, num_envs: int, n_seg: int):
-        self._T, self._n, self._s = T, num_envs, n_seg
+    * Reading gathers: ``wt.tensor()``, ``wt.cpu()``, ``np.asarray(wt)``, any torch function and every out-of-place
+      method work on a fresh ``[num_envs, n_seg]`` COPY of the block.
+    * Writing goes through to the block the kernels step, in every form the reference's NumPy array allows:
+      ``wt[: n // 2, 180:186] = 1600.0``, ``wt.copy_(x)``, ``wt.fill_(v)``, ``wt += 5``, every in-place method
+      (``add_``, ``zero_``, ``clamp_``, ``mul_`` ... — gather, operate, scatter), and CHAINED indexing:
+      ``wt[e]`` / ``wt[2:5, 10:20]`` (integers and slices) is again a write-through proxy, so ``wt[1][10] = 999``
+      and ``state.wire_temperature[2].fill_(500)`` change the block.  Indexing with a tensor or a list returns a plain
+      gathered tensor (a copy, as advanced indexing does on a NumPy array too).
+    * ``wt.quads`` is the zero-copy ``[num_envs, n_seg / 4, 4]`` view of the block itself."""
+
+    def __init__(self, T: torch.Tensor, num_envs: int, n_seg: int, _chain=()):
+        self._T, self._n, self._s, self._chain = T, num_envs, n_seg, tuple(_chain)
 
     @property
     def quads(self) -> torch.Tensor:
         return self._T[:, : self._n].permute(1, 0, 2)
 
-    def tensor(self) -> torch.Tensor:
+    def _full(self) -> torch.Tensor:
         return self.quads.reshape(self._n, -1)[:, : self._s]
+
+    @staticmethod
+    def _descend(full: torch.Tensor, chain) -> torch.Tensor:
+        for idx in chain:  # basic indices only: every step is a view of `full`
+            full = full[idx]
+        return full
+
+    def tensor(self) -> torch.Tensor:
+        """The selected cells as a fresh tensor (a copy: writing to it does not change the block)."""
+        return self._descend(self._full(), self._chain)
 
     def _scatter(self, full: torch.Tensor) -> None:
         q = self.quads
@@ -82,7 +106,13 @@ class WireTemperature:
         flat[:, : self._s] = full
         q.copy_(flat.reshape(q.shape))
 
-    shape = property(lambda self: torch.Size((self._n, self._s)))
+    def _update(self, fn) -> None:
+        """gather -> `fn(view of this proxy's cells inside the gathered copy)` -> scatter."""
+        full = self._full()
+        fn(self._descend(full, self._chain))
+        self._scatter(full)
+
+    shape = property(lambda self: self.tensor().shape if self._chain else torch.Size((self._n, self._s)))
     dtype = property(lambda self: self._T.dtype)
     device = property(lambda self: self._T.device)
 
@@ -90,41 +120,67 @@ class WireTemperature:
         return self.shape if dim is None else self.shape[dim]
 
     def __len__(self):
-        return self._n
+        return self.shape[0]
 
     def __getitem__(self, idx):
+        if _is_basic_index(idx):
+            sub = WireTemperature(self._T, self._n, self._s, self._chain + (idx,))
+            return sub if sub.tensor().dim() > 0 else sub.tensor()  # a single cell: a 0-d tensor, as before
         return self.tensor()[idx]
 
     def __setitem__(self, idx, value) -> None:
-        full = self.tensor()
-        full[idx] = value
-        self._scatter(full)
+        if isinstance(value, WireTemperature):
+            value = value.tensor()
+
+        def assign(view):
+            view[idx] = value
+
+        self._update(assign)
 
     def copy_(self, value):
-        self._scatter(torch.as_tensor(value, dtype=torch.float32, device=self._T.device).expand(self._n, self._s))
+        if isinstance(value, WireTemperature):
+            value = value.tensor()
+        self._update(lambda view: view.copy_(torch.as_tensor(value, dtype=torch.float32, device=self._T.device)))
         return self
 
     def fill_(self, value):
-        return self.copy_(torch.as_tensor(float(value)))
+        self._update(lambda view: view.fill_(float(value)))
+        return self
 
     def __array__(self, dtype=None, copy=None):
         a = self.tensor().cpu().numpy()
         return a if dtype is None else a.astype(dtype)
 
-    def __getattr__(self, name):  # everything else (cpu, numpy, clone, max, mean, ...) on the gathered tensor
-        if name.startswith("_"):
+    def __getattr__(self, name):
+        if name.startswith("__") or name in ("_T", "_n", "_s", "_chain"):
             raise AttributeError(name)
+        if name.endswith("_") and not name.endswith("__") and callable(getattr(torch.Tensor, name, None)):
+            # an in-place method (add_, zero_, clamp_, mul_, ...): on the gathered tensor it would change a temporary
+
+            def inplace(*args, **kwargs):
+                conv = lambda a: a.tensor() if isinstance(a, WireTemperature) else a
+                self._update(lambda view: getattr(view, name)(*[conv(a) for a in args], **{k: conv(v) for k, v in kwargs.items()}))
+                return self
+
+            return inplace
+        # everything else (cpu, numpy, clone, max, mean, ...) on the gathered tensor
         return getattr(self.tensor(), name)
 
     @classmethod
     def __torch_function__(cls, func, types, args=(), kwargs=None):
-        conv = lambda a: a.tensor() if isinstance(a, cls) else a
+        def conv(a):  # (also inside lists / tuples: torch.stack([wt[0], wt[1]]))
+            if isinstance(a, cls):
+                return a.tensor()
+            return type(a)(conv(x) for x in a) if type(a) in (list, tuple) else a
+
         return func(*[conv(a) for a in args], **{k: conv(v) for k, v in (kwargs or {}).items()})
 
 
 for _op in _BINARY_DUNDERS:
     setattr(WireTemperature, f"__{_op}__", (lambda op: lambda self, other: getattr(self.tensor(), f"__{op}__")(
         other.tensor() if isinstance(other, WireTemperature) else other))(_op))
+for _op in _INPLACE_DUNDERS:  # `wt += 5`, `wt[3] *= 2`: gather, operate, scatter
+    setattr(WireTemperature, f"__{_op}__", (lambda op: lambda self, other: getattr(self, {"iadd": "add_", "isub": "sub_", "imul": "mul_", "itruediv": "div_"}[op])(other))(_op))
 
 
 # int64 attributes composed from a low-word row and the clock's high word (both clocks advance together, every step
@@ -172,9 +228,17 @@ class BatchedEDMState:
     def __getattr__(self, name: str):
         if name in _FIELDS:
             return self._view(name)
-        if name in _WIDE:  # exact 64-bit clock: (high word << 32) | unsigned low word
-            lo = self._view(_WIDE[name]).to(torch.int64) & 0xFFFFFFFF
+        if name == "time":  # exact 64-bit clock: (high word << 32) | unsigned low word
+            lo = self._view("time_low32").to(torch.int64) & 0xFFFFFFFF
             return (self._view("time_high32").to(torch.int64) << 32) | lo
+        if name == "time_since_open_voltage":
+            # Its row holds the low 32 bits only, and TIME_HI is the high word of `time`.  Both clocks advance together
+            # (every step that is not a wire-break early return, wire_edm.py:135-137), so their distance is constant and the
+            # exact value is `time` minus that distance -- NOT `(TIME_HI << 32) | low word`, which is wrong as soon as the
+            # two low words wrap at different moments (time = 2**32 - 100 assigned, 300 us later: 300, not 2**32 + 300).
+            t = self.time
+            d = (self._view("time_low32").to(torch.int64) - self._view("time_since_open_voltage_low32").to(torch.int64)) & 0xFFFFFFFF
+            return t - d
         derived = self.__dict__.get("derived", {})
         if name in derived:
             return derived[name]()
@@ -184,8 +248,21 @@ class BatchedEDMState:
         if name in _WIDE:
             v = torch.as_tensor(value, dtype=torch.int64, device=self.device).expand(self.num_envs)
             lo = v & 0xFFFFFFFF
+            if name == "time_since_open_voltage":
+                # only the low word is stored (see __getattr__): representable are the values 0 <= time - v < 2**32; the
+                # high word belongs to `time` and is left alone (assigning 7 here used to drop `time` from 2**32 + 200 to 200)
+                d = self.time - v
+                if bool(((d < 0) | (d >= 2**32)).any().item()):
+                    raise ValueError("time_since_open_voltage must lie in (time - 2**32, time]: it is stored as a 32-bit "
+                                     "distance to `time` (assign `time` first)")
+            else:
+                since = self.time_since_open_voltage  # keeps its value: its distance to `time` moves with `time`
+                self._view("time_high32").copy_((v >> 32).to(torch.int32))
             self._view(_WIDE[name]).copy_(torch.where(lo >= 2**31, lo - 2**32, lo).to(torch.int32))
-            self._view("time_high32").copy_((v >> 32).to(torch.int32))
+            if name == "time":
+                back = since.clamp(max=v).clamp(min=v - (2**32 - 1))  # (a distance beyond 32 bits cannot be kept: nearest)
+                blo = back & 0xFFFFFFFF
+                self._view("time_since_open_voltage_low32").copy_(torch.where(blo >= 2**31, blo - 2**32, blo).to(torch.int32))
         elif name in _FIELDS:
             view = self._view(name)
             if torch.is_tensor(value):

@@ -3884,7 +3884,12 @@ int32_t wedm_step(wedm_ctx* ctx, int32_t n_substeps, const wedm_action_ptrs* act
 
     const bool tr = ctx->trace_on && k.trace_next < n_substeps;  // a sample falls into this launch
     // frozen-lane tile code: handles with in-launch autoreset, and any handle one of whose launches has found a terminated
-    // environment (the kernels set the host-visible word; a plain read, no synchronisation: a launch or two late at worst)
+    // environment.  The kernels set the host-visible word; the host reads it without synchronising, so the switch comes as
+    // late as the host runs ahead of the device: every launch ENQUEUED before the first kernel that sets the word has run
+    // still takes the instantiation without the frozen-lane code (whose waves with a frozen lane walk cell by cell: slower,
+    // same results).  A reset of every environment clears the word on the host while kernels queued earlier may still
+    // set it again, and masked resets never clear it: both only keep the FROZEN_OK instantiation (2 % slower on a batch
+    // without frozen environments) longer than needed.  Speed only; no result depends on the word.
     const bool frozen_ok = P.autoreset || (ctx->frozen_seen && *(volatile int32_t*)ctx->frozen_seen != 0);
     LaunchPlan& plan = ctx->plans[n_substeps <= 1 ? 1 : 0][tr ? 1 : 0][frozen_ok ? 1 : 0];
     if (!plan.valid) {

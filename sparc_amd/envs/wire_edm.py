@@ -65,6 +65,34 @@ class DictSpace(dict):
         return {k: v.sample(rng) for k, v in self.items()}
 
 
+class StepInfo(dict):
+    """``info`` of `step`: the reference's five keys (wire_edm.py:150-156) as tensors over the batch.  ``"time"`` is the
+    exact 64-bit clock (`state.time`), composed from its two 32-bit rows when it is READ -- a per-microsecond loop that
+    never looks at it pays nothing.  (`env.state.time_low32` is the zero-copy row itself -- the signed int32 bits of the
+    clock modulo 2**32 -- for loops that want no op at all; the in-kernel trace records that row too.)"""
+
+    __slots__ = ("_state",)
+
+    def __init__(self, base, state):
+        super().__init__(base)  # ("time" is a placeholder entry: membership and key order of the reference's dict)
+        self._state = state
+
+    def __getitem__(self, key):
+        return self._state.time if key == "time" else dict.__getitem__(self, key)
+
+    def get(self, key, default=None):
+        return self[key] if key in self else default
+
+    def items(self):
+        return [(k, self[k]) for k in self]
+
+    def values(self):
+        return [self[k] for k in self]
+
+    def copy(self):
+        return StepInfo({k: dict.__getitem__(self, k) for k in self}, self._state)
+
+
 class DeviceAction:
     """An action already laid out for the kernel: five contiguous length-N device
     tensors (float64 x4, int32).  Build it once with ``env.make_action`` and pass it
@@ -246,6 +274,7 @@ class WireEDMEnv:
         self._reward = self.state.reward[0, : self.num_envs]  # zeros unless reward="progress" (written by the kernels)
         self._truncated = torch.zeros(self.num_envs, dtype=torch.bool, device=self.device)
         self._mask_buf = None
+        self._valid_modes_dev = None
         self._step_out = None
         self._trace = None
         self._seed = int.from_bytes(os.urandom(8), "little")
@@ -297,10 +326,10 @@ class WireEDMEnv:
                 "wire_broken": st.is_wire_broken,
                 "target_reached": st.is_target_distance_reached,
                 "spark_state": st.spark_state,
-                "time": st.time_low32,  # (the zero-cost view: low 32 bits of the clock; `env.state.time` is the exact int64)
+                "time": None,  # the exact int64 clock, composed when it is read (StepInfo)
                 "control_step": st.control_step,
             })
-        return out[0], self._reward, out[1], self._truncated, dict(out[2])
+        return out[0], self._reward, out[1], self._truncated, StepInfo(out[2], self.state)
 
     def step_control(self, action):
         """One control interval (``servo_interval`` physics steps, default 1000)."""
@@ -349,8 +378,25 @@ class WireEDMEnv:
         )
 
     def _validate_modes(self, mode) -> None:
-        """Mirror of material.py:108-113: modes without crater data are an error."""
-        vals = mode.detach().cpu().numpy() if torch.is_tensor(mode) else np.asarray(mode)
+        """Mirror of material.py:108-113: modes without crater data are an error.
+
+        Host-side values (Python numbers, NumPy arrays, CPU tensors) are checked here and raise at once.  A tensor that
+        already lives on the device is checked ON the device and never read back: a policy that emits fresh device
+        tensors every control step must not block on the previous launch (a `.cpu()` here waited for the 4-6 ms
+        launch still in flight).  An invalid entry sets the environment's sticky ERROR flag -- the row the kernels
+        set at the first fresh spark with such a mode -- and `check_errors()` raises for it (deferred raise)."""
+        if torch.is_tensor(mode) and mode.device.type != "cpu":
+            if self._valid_modes_dev is None:
+                self._valid_modes_dev = torch.tensor(VALID_CRATER_MODES, dtype=torch.int64, device=self.device)
+            m = mode.to(self.device).reshape(-1)
+            bad_dev = ~torch.isin(m.to(torch.int64), self._valid_modes_dev)
+            if bad_dev.numel() == 1:
+                bad_dev = bad_dev.expand(self.num_envs)
+            elif bad_dev.numel() != self.num_envs:
+                raise ValueError(f"action leaf has {bad_dev.numel()} values, expected 1 or num_envs={self.num_envs}")
+            self.state.error.logical_or_(bad_dev)  # stream-ordered before the launch that latches the action
+            return
+        vals = mode.detach().numpy() if torch.is_tensor(mode) else np.asarray(mode)
         bad = sorted({int(v) for v in np.unique(vals.reshape(-1)) if int(v) not in VALID_CRATER_MODES})
         if bad:
             raise ValueError(
@@ -368,7 +414,9 @@ class WireEDMEnv:
         """Synchronising check of the sticky per-environment error flag."""
         if bool(self.state.error.any().item()):
             idx = int(torch.nonzero(self.state.error)[0].item())
-            raise ValueError(f"environment {idx}: fresh spark with a current mode that has no crater data")
+            raise ValueError(f"environment {idx}: a current mode that has no crater data was latched / passed in a device "
+                             f"tensor (material.py:108-113 raises at the first fresh spark with it). "
+                             f"Available modes: {[f'I{m}' for m in VALID_CRATER_MODES]}")
 
     def set_kernel(self, variant: int, lanes: int = 0) -> None:
         """0 = auto, 1 = global-memory stencil, 2 = LDS predicated, 3 = LDS fused, 4 = LDS

@@ -24,7 +24,7 @@ from .core.state import _FIELDS
 _BLOCK_COUNT = {"f64": _abi.F64_COUNT, "i32": _abi.I32_COUNT, "i8": _abi.I8_COUNT}
 # the reference logs the [state, y, dur] list, we log its state; the 64-bit clocks are traced by their low 32 bits (the
 # rows the kernels carry through the microsecond loop; the high word, row TIME_HI, is kept per launch)
-_ALIASES = {"spark_status": "spark_state", "time": "time_low32", "time_since_open_voltage": "time_since_open_voltage_low32"}
+_ALIASES = {"spark_status": "spark_state", "time": "time_low32", "time_since_open_voltage": "time_since_open_voltage_low32"}  # (a trace records the 32-bit rows the kernels carry: traced "time" is the clock modulo 2**32, signed int32 bits)
 
 
 class DeviceTrace:

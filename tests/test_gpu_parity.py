@@ -1262,6 +1262,36 @@ def test_vector_env_step_is_one_launch_without_host_sync():
     torch.cuda.synchronize()
     assert "wedm_step_" in env._backend.last_kernel()
     assert bool(term.any() | (env.state.episode > 0).any()) and reward.dtype == torch.float32
+    # ... and with what a policy really hands over (wire_edm.py:116-121,162-170): a FRESH dict of device tensors per control
+    # step -- the servo command a torch function of the observation, the generator settings drawn on the device.  The
+    # current modes are validated on the device (sticky ERROR row, `check_errors()`), not read back.
+    valid = torch.tensor([1, 3, 5, 7, 9, 11, 13, 15, 17], dtype=torch.int32, device="cuda:0")
+    gen = torch.Generator(device="cuda:0").manual_seed(3)
+    torch.cuda.set_sync_debug_mode("error")
+    try:
+        for _ in range(4):
+            gap = obs[:, 0]
+            action = {"servo": torch.clamp(0.02 * (gap - 12.0), -1.0, 1.0),
+                      "generator_control": {"target_voltage": torch.full((4096,), 80.0, device="cuda:0"),
+                                            "current_mode": valid[torch.randint(0, 9, (4096,), device="cuda:0", generator=gen)],
+                                            "ON_time": torch.full((4096, 1), 2.0, device="cuda:0"),
+                                            "OFF_time": torch.full((4096,), 20.0, device="cuda:0")}}
+            obs, reward, term, trunc, info = vec.step(action)
+    finally:
+        torch.cuda.set_sync_debug_mode("default")
+    torch.cuda.synchronize()
+    env.check_errors()                                                    # every mode was a valid one
+    assert int(env.state.current_mode.unique().numel()) > 1             # the drawn modes were latched
+    # an invalid mode in a device tensor: no exception at step() (nothing is read back), the sticky flag and a deferred raise
+    bad = valid[torch.zeros(4096, dtype=torch.int64, device="cuda:0")].clone()
+    bad[77] = 4
+    action["generator_control"]["current_mode"] = bad
+    vec.step(action)
+    assert bool(env.state.error[77]) and int(env.state.error.sum()) == 1
+    with pytest.raises(ValueError, match="environment 77"):
+        env.check_errors()
+    with pytest.raises(ValueError, match="I4 is not available"):      # host-side values still raise at once
+        env.step_many(env.make_action(0.0, 80.0, 4, 2.0, 20.0), 1)
 
 
 @pytest.mark.parametrize("name", ["f16_logger_philox_env3", "f16_logger_velocity_philox_env1"])

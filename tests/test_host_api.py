@@ -45,6 +45,10 @@ def test_env_step_with_sampled_action():
     assert (env.state.time > 0).all()
     assert reward.shape == (4,) and terminated.dtype == torch.bool and truncated.dtype == torch.bool
     assert set(info) == {"wire_broken", "target_reached", "spark_state", "time", "control_step"}
+    # the exact 64-bit clock, composed when it is read (the int32 row read -2**31 once an environment had passed 2**31 us)
+    assert info["time"].dtype == torch.int64 and info["time"].tolist() == [1] * 4 and dict(info.items())["time"] is not None
+    env.state.time = 2**31 + 5
+    assert info["time"].tolist() == [2**31 + 5] * 4 and info.get("time").dtype == torch.int64
 
 
 def test_custom_config():
@@ -333,5 +337,26 @@ def test_wire_temperature_proxy_reads_gather_and_assignments_write_through():
     assert bool((env.state.wire_temperature == 300.0).all())
     pad = env.state.T[32, :5, 1:]                                       # cells 129..131: padding, still what the reset wrote
     assert bool((pad == np.float32(293.15)).all())
+    # chained indexing and in-place methods write through too (a gathered temporary used to swallow them)
+    wt = env.state.wire_temperature
+    wt[1][10] = 999.0
+    assert env.state.T[2, 1, 2] == 999.0
+    wt.add_(5.0)
+    assert env.state.T[2, 1, 2] == 1004.0 and env.state.T[0, 0, 0] == 305.0
+    env.state.wire_temperature[2].fill_(500.0)
+    assert bool((env.state.T[:32, 2, :] == 500.0).all()) and env.state.T[32, 2, 0] == 500.0 and env.state.T[0, 3, 0] == 305.0
+    env.state.wire_temperature[3, 4:8] += 1.0
+    env.state.wire_temperature[4] *= 2.0
+    wt[0:2, 20:24].zero_()
+    assert env.state.T[1, 3, :].tolist() == [306.0] * 4 and env.state.T[7, 4, 1] == 610.0 and env.state.T[5, 1, 0] == 0.0
+    wt[:, 1:].clamp_(max=400.0)
+    assert float(torch.max(wt)) == 610.0 and float(wt[4, 1:].max()) == 400.0  # (column 0 was left out of the clamp)
+    sub = wt[2:4]                                                       # a proxy of rows 2..3: reads gather at the time of the read
+    assert sub.shape == (2, n) and len(sub) == 2 and float(sub[0, 3]) == 400.0
+    picked = wt[torch.tensor([0, 4])]                                   # advanced indexing: a plain copy, as on a NumPy array
+    assert isinstance(picked, torch.Tensor) and picked.shape == (2, n)
+    assert torch.stack([wt[0], wt[1]]).shape == (2, n)
+    assert bool((env.state.T[32, :5, 1:] == np.float32(293.15)).all())  # padding still untouched
+    env.state.wire_temperature = np.full(n, 300.0, dtype=np.float32)
     env.step_many(env.make_action(), 3)                                 # and the kernels' view is the same memory
     assert abs(float(env.state.wire_temperature[0, 64]) - 300.0) < 1.0 and float(env.state.wire_temperature[0, 0]) == np.float32(293.15)

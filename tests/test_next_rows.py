@@ -224,6 +224,18 @@ def test_the_clock_is_64_bit_and_no_launch_count_limits_a_run():
     # assignment through the wide attribute round-trips
     env.state.time = 5
     assert env.state.time.tolist() == [5, 5, 5] and env.state.time_high32.tolist() == [0, 0, 0]
+    # `time_since_open_voltage` is stored as a 32-bit row next to `time`'s 64 bits: its exact value is composed from the
+    # constant distance between the two clocks, not from `time`'s high word (the two low words wrap at different moments)
+    env.state.time_since_open_voltage = 0
+    env.state.time = 2**32 - 100
+    assert env.state.time_since_open_voltage.tolist() == [0, 0, 0]          # assigning `time` leaves the other clock alone
+    env.step_many(act, 300)
+    assert env.state.time.tolist() == [2**32 + 200] * 3
+    assert env.state.time_since_open_voltage.tolist() == [300] * 3            # the reference's value (was 2**32 + 300)
+    env.state.time_since_open_voltage = 2**32 + 7                             # assigning it leaves `time` alone
+    assert env.state.time.tolist() == [2**32 + 200] * 3 and env.state.time_since_open_voltage.tolist() == [2**32 + 7] * 3
+    with pytest.raises(ValueError, match="time_since_open_voltage"):          # further than 32 bits from `time`: refused, loudly
+        env.state.time_since_open_voltage = 7
     # one launch may not span 2**31 us (the high word is carried per launch)
     long_dt = WireEDMEnv(num_envs=1, device="cpu", backend=OracleBackend, config=EnvironmentConfig(dt=4, servo_interval=1000))
     with pytest.raises(ValueError, match="2\\*\\*31"):
