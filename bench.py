@@ -25,9 +25,13 @@ VALU instruction occupies its SIMD-32 for 2 cycles).  The same object carries th
 fraction (PMC bytes / duration / 8 TB/s), the useful-FP32 fraction ((14 S + 120) flop per env-step
 against 157.3 TFLOP/s) and, labelled as an equivalent, the SURVEY.md §8d algorithmic-HBM figure
 B(S) = 8 S + 208 bytes per env-step (what an unfused one-launch-per-microsecond implementation
-would have to move).  ``side`` holds three side measurements of the same build: the reference's
+would have to move).  ``side`` holds side measurements of the same build and run: the reference's
 own one-launch-per-microsecond cadence (there HBM IS the roof), a densely sparking start (15 um
-gap) and the closed loop of the reference's driver with its PI voltage controller on the device.
+gap), the closed loop of the reference's driver with its PI voltage controller on the device, an
+autoreset batch, the same batch with frozen environments, a policy in the loop (a fresh dict of device
+tensors per control step through WireEDMVectorEnv.step), and the other single-GPU BASELINE workloads
+(configs[1], the per-GPU shards of configs[3] and configs[4]) each with its own ``roofline`` block.
+With N > 1 ranks ``per_rank`` lists every rank's own kernel and wall time per step (min / max / slowest rank).
 ``cpu_baseline`` times the CPU oracle (oracle/, OpenMP) on this host.
 """
 from __future__ import annotations
@@ -363,6 +367,99 @@ def side_measurements(n_local, wire, S, device):
     return out
 
 
+def make_workload_env(name, device, rank=0, world=1, n_override=0, **kw):
+    """(env, action mode(s), n_local, label) of one BASELINE workload as `main()` builds it for a rank."""
+    from sparc_amd import EnvironmentConfig, WireEDMEnv
+
+    class A:  # the fields `workload()` reads
+        workload, num_envs = name, n_override
+
+    n_local, wire, label = workload(A)
+    if name == "config5":
+        h, d, mode = config5_draws(world * n_local, rank * n_local, (rank + 1) * n_local)
+        env = WireEDMEnv(num_envs=n_local, device=device, wire_params=wire, env_id_offset=rank * n_local,
+                         workpiece_height=h, wire_diameter=d, config=EnvironmentConfig(target_cutting_distance=5000.0), **kw)
+    else:
+        mode = 5
+        env = WireEDMEnv(num_envs=n_local, device=device, wire_params=wire, env_id_offset=rank * n_local, **kw)
+    return env, mode, n_local, label
+
+
+def other_config_lines(device):
+    """The other single-GPU BASELINE workloads, timed in the SAME driver run as the headline (their published numbers
+    used to exist only as builder runs): configs[1] (4 096 x 400), the per-GPU shard of configs[3] (32 768 x 400) and the
+    per-GPU shard of configs[4] (16 384 environments with per-environment geometry), fused 1000-us launches, each with its
+    own `roofline` block priced from the profiles/ rows of this build."""
+    import torch
+
+    out = []
+    for name, steps in (("config2", 10), ("config4", 6), ("config5", 6)):
+        env, mode, n_local, label = make_workload_env(name, device)
+        env.reset(seed=1234)
+        act = env.make_action(0.1, 80.0, mode, 3.0, 80.0)
+        sec, kname = time_launches(env, act, 1000, steps, 2)
+        line = {"name": f"{label}: num_envs={n_local}, n_segments={env.n_segments}, fresh reset(seed=1234), fused 1000-us launches",
+                "workload": name, "value": n_local * 1000 / sec, "unit": "env-steps/s", "kernel": kname, "kernel_ms": sec * 1e3,
+                "steps": steps, "roofline": roofline_block(kname, sec * 1e3, n_local, 1000, env.n_segments),
+                "check": {"envs_done": int(env.state.done.sum().item()), "sparks": int(env.state.spark_count.sum().item())}}
+        out.append(line)
+        env.close()
+        del env
+        torch.cuda.empty_cache()
+    return out
+
+
+def policy_in_the_loop_line(n_local, wire, device):
+    """The contract an RL loop uses (wire_edm.py:116-121,162-170): per control step a FRESH dict of device tensors --
+    the servo command a small torch function of the observation, the current modes drawn on the device -- through
+    `WireEDMVectorEnv.step` on the autoreset batch of the fourth side line.  No device-to-host read anywhere (the modes
+    are validated on the device); what it costs over the constant pre-built action is the policy's own torch ops."""
+    import torch
+
+    from sparc_amd import EnvironmentConfig, WireEDMEnv, WireEDMVectorEnv
+
+    env = WireEDMEnv(num_envs=n_local, device=device, wire_params=wire, autoreset=True, reward="progress",
+                     config=EnvironmentConfig(target_cutting_distance=50.002))
+    vec = WireEDMVectorEnv(env)
+    obs, _ = vec.reset(seed=7)
+    valid = torch.tensor([5, 5, 5, 3, 7], dtype=torch.int32, device=device)
+    gen = torch.Generator(device=device).manual_seed(11)
+    volt = torch.full((n_local,), 80.0, device=device)
+
+    def policy(o):
+        gap = o[:, 0]
+        return {"servo": torch.clamp(0.1 + 0.002 * (gap - 50.0), -1.0, 1.0),
+                "generator_control": {"target_voltage": volt, "ON_time": torch.full((n_local,), 3.0, device=device),
+                                      "OFF_time": torch.full((n_local,), 80.0, device=device),
+                                      "current_mode": valid[torch.randint(0, 5, (n_local,), device=device, generator=gen)]}}
+
+    for _ in range(20):
+        obs, reward, term, trunc, info = vec.step(policy(obs))
+    torch.cuda.synchronize()
+    e0 = int(env.state.episode.sum().item())
+    prev = torch.cuda.get_sync_debug_mode()
+    torch.cuda.set_sync_debug_mode("error")  # a synchronising call inside the loop fails the bench, loudly
+    try:
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        a.record()
+        for _ in range(20):
+            obs, reward, term, trunc, info = vec.step(policy(obs))
+        b.record()
+    finally:
+        torch.cuda.set_sync_debug_mode(prev)
+    torch.cuda.synchronize()
+    dt = a.elapsed_time(b) * 1e-3
+    env.check_errors()
+    line = {"name": "policy in the loop: a fresh dict of device tensors per control step through WireEDMVectorEnv.step "
+                    "(servo = f(obs), current modes drawn on the device), autoreset batch",
+            "value": n_local * 20 * 1000 / dt, "unit": "env-steps/s", "kernel": env._backend.last_kernel(),
+            "ms_per_control_interval": dt / 20 * 1e3,
+            "resets_per_env_per_launch": (int(env.state.episode.sum().item()) - e0) / n_local / 20.0,
+            "timing": "HIP events around 20 control intervals under torch's sync-debug mode 'error' (no host read in the loop)"}
+    env.close()
+    return line
+
+
 def main():
     args = parse_args()
     import torch
@@ -452,11 +549,21 @@ def main():
     if use_dist:
         dist.barrier()
     elapsed = time.perf_counter() - t0
+    elapsed_local = elapsed
     if use_dist:
         tmax = torch.tensor([elapsed], dtype=torch.float64, device=device)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         elapsed = float(tmax.item())
     kernel_ms = sum(s.elapsed_time(e) for s, e in zip(starts, ends)) / args.steps
+    # every rank's own kernel time and wall time (the first multi-GPU run should show stragglers, not only the maximum)
+    per_rank = None
+    if use_dist:
+        mine = torch.tensor([kernel_ms, elapsed_local * 1e3 / args.steps], dtype=torch.float64, device=device)
+        allr = [torch.zeros_like(mine) for _ in range(world)]
+        dist.all_gather(allr, mine)
+        km = [float(x[0].item()) for x in allr]
+        per_rank = {"kernel_ms": km, "kernel_ms_min": min(km), "kernel_ms_max": max(km), "slowest_rank": km.index(max(km)),
+                    "wall_ms_per_step": [float(x[1].item()) for x in allr]}
 
     done = int(env.state.done.sum().item())
     broken = int(env.state.is_wire_broken.sum().item())
@@ -486,6 +593,7 @@ def main():
                 **({"initial_gap_um": args.gap} if args.gap is not None else {}),
             },
             "roofline": roofline_block(kname, kernel_ms, n_local, n_sub, S, args.traffic),
+            **({"per_rank": per_rank} if per_rank is not None else {}),
             "check": {"envs_done": done, "envs_wire_broken": broken, "envs_target_reached": reached, "sparks": sparks,
                       **({"note": "per-environment draws that pair the thinnest wires (0.10 mm) with the highest current modes "
                                   "overheat the wire (Tmax > breaking temperature, wire.py:376-388) within the window: the "
@@ -496,6 +604,8 @@ def main():
         if world == 1 and not args.no_side and args.workload == "config3" and args.trace == "off" and args.gap is None \
                 and not args.num_envs and args.kernel == 0 and args.stencil_dtype == "float32":
             out["side"] = side_measurements(n_local, wire, S, device)
+            out["side"].append(policy_in_the_loop_line(n_local, wire, device))
+            out["side"] += other_config_lines(device)
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(wire, n_local, n_sub, args.cpu_seconds)
             out["cpu_baseline"]["reference_python"] = (

@@ -1205,6 +1205,74 @@ def test_config5_shard_of_rank_5_matches_oracle():
     assert int(gpu.state.spark_count.sum()) > 50000 and len(set(gpu._geom_i32[0, :n].cpu().tolist())) > 50
 
 
+def _shards_in_turn_equal_one_batch(n_shard, world, make_env, action_of, T_rows_of=None):
+    """BASELINE configs[3] / configs[4] at their OWN size on one GPU: the whole batch stepped as ONE environment object
+    against its `world` shards stepped one after the other, each with `env_id_offset = r * n_shard` exactly as
+    `bench.py --gpus 8` cuts them.  Every byte of every state block must agree (1 000 us fused + 3 single microseconds):
+    results do not depend on how the batch is sharded, nor on the kernel / lane count the launch plan picks for a size."""
+    n_all = n_shard * world
+    full = make_env(n_all, 0, 0, n_all)
+    full.reset(seed=1234)
+    close_gap(full, 25.0, 10.0)
+    act = action_of(full, 0, n_all)
+    full.step_many(act, 1000)
+    kernels = {full._backend.last_kernel()}
+    for _ in range(3):
+        full.step(act)
+    torch.cuda.synchronize()
+    want = full.state.clone_blocks()
+    sparks = int(full.state.spark_count.sum())
+    n_seg_full = full.n_segments
+    full.close()
+    del full
+    for r in range(world):
+        lo, hi = r * n_shard, (r + 1) * n_shard
+        env = make_env(n_shard, r * n_shard, lo, hi)
+        env.reset(seed=1234)
+        close_gap(env, 25.0, 10.0)
+        act = action_of(env, lo, hi)
+        env.step_many(act, 1000)
+        kernels.add(env._backend.last_kernel())
+        for _ in range(3):
+            env.step(act)
+        torch.cuda.synchronize()
+        got = env.state.clone_blocks()
+        assert env.n_segments <= n_seg_full
+        assert_blocks_equal(got, {k: v[:, lo:hi] for k, v in want.items()}, n_shard,
+                            T_rows=(T_rows_of(env) if T_rows_of else None))
+        env.close()
+    return sparks, kernels
+
+
+def test_config4_at_full_size_all_eight_shards_in_turn_equal_one_batch():
+    """BASELINE configs[3]: 262 144 environments x 400 segments as ONE batch == its 8 shards of 32 768."""
+    sparks, kernels = _shards_in_turn_equal_one_batch(
+        32768, 8, lambda n, off, lo, hi: WireEDMEnv(num_envs=n, device="cuda:0", env_id_offset=off),
+        lambda env, lo, hi: env.make_action(0.1, 80.0, 5, 3.0, 80.0))
+    assert sparks > 400000, sparks
+    assert any("<<<" in k for k in kernels)
+
+
+def test_config5_at_full_size_all_eight_shards_in_turn_equal_one_batch():
+    """BASELINE configs[4]: 131 072 environments with per-environment workpiece height / wire diameter / current mode
+    (bench.config5_draws: numpy.default_rng(2024)) as ONE batch == its 8 shards of 16 384.  The full batch
+    and the shards run different lane counts of the per-environment-geometry kernel (the plan follows the batch size)."""
+    import bench
+
+    world, n = 8, 16384
+    H, D, M = bench.config5_draws(world * n, 0, world * n)
+
+    def make_env(num, off, lo, hi):
+        return WireEDMEnv(num_envs=num, device="cuda:0", env_id_offset=off, workpiece_height=H[lo:hi], wire_diameter=D[lo:hi],
+                          config=EnvironmentConfig(target_cutting_distance=5000.0))
+
+    sparks, kernels = _shards_in_turn_equal_one_batch(
+        n, world, make_env, lambda env, lo, hi: env.make_action(0.1, 80.0, M[lo:hi], 3.0, 80.0),
+        T_rows_of=lambda env: env.n_segments)
+    assert sparks > 200000, sparks
+    assert len(kernels) >= 2, kernels  # (wedm_step_lanes<4> for the whole batch, <8> for a shard)
+
+
 # ------------------------------------------------------------------ auto-reset / reward / voltage sum inside the launch
 @pytest.mark.parametrize("variant,lanes", [(0, 0), (2, 4), (3, 8), (4, 4), (1, 0), (5, 0), (6, 8)])
 def test_in_kernel_autoreset_and_reward_match_oracle_and_host_path(variant, lanes):

@@ -136,3 +136,12 @@ def test_config2_kernel_duration_by_rocprofv3_agrees_with_the_hip_events():
     b = bench("bench_config2.json")
     avg_ms, calls = rocprof_avg_ms("rocprofv3_kernel_stats_config2.csv", "wedm_step_regs_wide<16, 16")
     assert calls >= 20 and avg_ms == pytest.approx(b["roofline"]["kernel_ms"], rel=0.05)
+
+
+def test_every_committed_bench_record_is_one_line_of_json():
+    """`json.load` of every profiles/*/bench_*.json (an RCCL version banner once preceded the line of a record)."""
+    files = sorted((ROOT / "profiles").glob("*/bench_*.json"))
+    assert len(files) >= 10
+    for f in files:
+        b = json.loads(f.read_text())
+        assert b["unit"] == "env-steps/s" and b["value"] > 0 and "roofline" in b, f.name
