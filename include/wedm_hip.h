@@ -403,7 +403,11 @@ int64_t wedm_trace_samples(wedm_ctx* ctx);
  * with the wire in their registers and per-cell zone / contact coefficients: no LDS, no tile table; uniform geometry,
  * 9 to 512 segments, float32 stencil; the automatic choice for fused launches of a batch that one round of blocks
  * covers: environments x lanes <= 65 536; own instantiations for wires whose length is not a multiple of 8 and for
- * launches with a trace sample).  All variants produce bit-identical results.  With wedm_params.stencil_mode 1 only 0, 1, 2 and 3 are accepted (3: the tile walk with
+ * launches with a trace sample), 9 = served kernel (kernel 4's walk -- 4 or 8 lanes per environment, the wire in LDS --
+ * with the float64 scalar physics of a block's environments on a FIFTH wave of the block, one lane per environment, one
+ * microsecond ahead of the four walking waves where it can prove that the step does not break the wire; coefficients and
+ * maxima cross through LDS; uniform geometry, float32 stencil, freeze-on-termination; launches with a trace sample take
+ * kernel 4).  All variants produce bit-identical results.  With wedm_params.stencil_mode 1 only 0, 1, 2 and 3 are accepted (3: the tile walk with
  * per-cell coefficients, no stage-major / packed form).                                          */
 int32_t wedm_set_kernel(wedm_ctx* ctx, int32_t variant);
 

@@ -1256,12 +1256,21 @@ __device__ __forceinline__ float interior_cell_f64(float tm1, float tc, float tp
 
 // ------------------------------------------- scalar epilogue (modules 4b, 5, env)
 // wire.py:376-388, wire_edm.py:129-146,172-179, mechanics.py:79-114
-__device__ __forceinline__ void scalar_epilogue(const Hot& p, Env& s, float tmax) {
+// Two halves.  The MONITOR is everything that reads the step's maximum temperature (wire.py:376-388: time above the critical
+// temperature, the break test); the MOTION is what follows a step whose wire did not break (the driver's voltage sum,
+// mechanics, clocks, termination) and reads nothing the monitor writes except `broken`.  scalar_epilogue() is the two in the
+// reference's order; a kernel whose scalar physics runs ahead of its stencil (wedm_step_served) calls the motion half first
+// where it can PROVE that the step cannot break the wire, and the monitor half when the maximum arrives.
+__device__ __forceinline__ void epilogue_voltage_sum(Env& s) {
     // the driver appends state.voltage after EVERY step(), the early-return one included
     // (experiments/run_simulation.py:256-264): running sum in step order
 #ifndef WEDM_ABL_NO_VACC
     s.vacc = s.vacc + s.V;
 #endif
+}
+
+// wire.py:376-388 (`_check_wire_breaking`); returns with s.broken set when the wire broke in this step
+__device__ __forceinline__ void epilogue_monitor(const Hot& p, Env& s, float tmax) {
     int32_t tcrit = tmax > p.tcrit ? s.tcrit + 1 : 0;
     // keep_stepping_terminated only (elsewhere a broken wire is frozen and never gets here): the wire module returns at
     // once on a broken wire (wire.py:260-261) -- no stencil (the caller's walk left this lane's wire alone and its `tmax`
@@ -1273,10 +1282,10 @@ __device__ __forceinline__ void scalar_epilogue(const Hot& p, Env& s, float tmax
     s.tmax = tmax;
     s.tcrit = tcrit;
     if (tmax > p.tbreak) s.broken = 1;
-    if (s.broken) {  // early return before mechanics and clocks
-        s.done = p.done_value;
-        return;
-    }
+}
+
+// mechanics.py:79-114, wire_edm.py:135-146,172-179 for a step whose wire is not broken
+__device__ __forceinline__ void epilogue_motion(const Hot& p, Env& s) {
 #ifndef WEDM_ABL_NO_MECH
     {
         double x = s.x, v = s.v, a_nom;
@@ -1308,6 +1317,16 @@ __device__ __forceinline__ void scalar_epilogue(const Hot& p, Env& s, float tmax
     else { s.tse += p.dt_us; s.tsi = 0; }
     if (s.x > s.wp + 100) { s.broken = 1; s.done = p.done_value; }
     else if (s.wp >= s.tpos) { s.reached = 1; s.done = p.done_value; }
+}
+
+__device__ __forceinline__ void scalar_epilogue(const Hot& p, Env& s, float tmax) {
+    epilogue_voltage_sum(s);
+    epilogue_monitor(p, s, tmax);
+    if (s.broken) {  // early return before mechanics and clocks
+        s.done = p.done_value;
+        return;
+    }
+    epilogue_motion(p, s);
 }
 
 // The wire of a lane whose wire is broken stays as it is: around its walk a kernel ORs `broken` into the lane's frozen

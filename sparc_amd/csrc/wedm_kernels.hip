@@ -3026,6 +3026,8 @@ __global__ void __launch_bounds__(256, WEDM_PACKED_MIN_BLOCKS) wedm_step_packed(
 }
 
 
+#include "wedm_served.h"
+
 // ------------------------------------------------------------ translation-unit parts (build time only)
 // The packed and fused kernels exist in 32 and 40 instantiations and take hipcc two minutes in one translation unit.
 // __graft_entry__.build_hip() compiles this file three times in parallel: -DWEDM_PART=1 emits the packed instantiations
@@ -3044,16 +3046,23 @@ __global__ void __launch_bounds__(256, WEDM_PACKED_MIN_BLOCKS) wedm_step_packed(
 #define WEDM_EXT_FUSED_F64(L, tr) extern template __global__ void wedm_step_fused<L, tr, true, false, true>(const KArgs);
 #define WEDM_EXT_PACKED(L, a, b, c) extern template __global__ void wedm_step_packed<L, a, b, c>(const KArgs);
 #define WEDM_EXT_FUSED(L, a, b, c) extern template __global__ void wedm_step_fused<L, a, b, c>(const KArgs);
+// the served kernels (wedm_served.h): <L, EXTRA>
+#define WEDM_SERVED_LIST(X) X(4, false) X(4, true) X(8, false) X(8, true)
+#define WEDM_INST_SERVED(L, ex) template __global__ void wedm_step_served<L, ex>(const KArgs);
+#define WEDM_EXT_SERVED(L, ex) extern template __global__ void wedm_step_served<L, ex>(const KArgs);
 #if defined(WEDM_PART) && WEDM_PART == 1
 WEDM_PACKED_LIST(WEDM_INST_PACKED)
 #elif defined(WEDM_PART) && WEDM_PART == 2
 WEDM_FUSED_LIST(WEDM_INST_FUSED)
 WEDM_FUSED_F64_LIST(WEDM_INST_FUSED_F64)
+#elif defined(WEDM_PART) && WEDM_PART == 3
+WEDM_SERVED_LIST(WEDM_INST_SERVED)
 #else
 #if defined(WEDM_PART)
 WEDM_PACKED_LIST(WEDM_EXT_PACKED)
 WEDM_FUSED_LIST(WEDM_EXT_FUSED)
 WEDM_FUSED_F64_LIST(WEDM_EXT_FUSED_F64)
+WEDM_SERVED_LIST(WEDM_EXT_SERVED)
 #endif
 
 __global__ void __launch_bounds__(256)
@@ -3153,6 +3162,7 @@ struct LaunchPlan {
     bool valid = false;
     const void* fn = nullptr;
     int grid = 0;
+    int block = 256;
     size_t lds = 0;
     const WalkTable* walk = nullptr;
     char name[160] = {0};
@@ -3333,6 +3343,13 @@ template <bool TR, bool FZ> static const void* pick_packed(int L, bool extra) {
     return extra ? pick_packed<TR, FZ, true>(L) : pick_packed<TR, FZ, false>(L);
 }
 
+static const void* pick_served(int L, bool extra) {
+    switch (L) {
+        case 4: return extra ? (const void*)wedm_step_served<4, true> : (const void*)wedm_step_served<4, false>;
+        default: return extra ? (const void*)wedm_step_served<8, true> : (const void*)wedm_step_served<8, false>;
+    }
+}
+
 // A handle belongs to the device that was current in wedm_create: its parameter / table / walk buffers
 // live there and its launches must go to a stream of that device.  Launching with another device
 // current would hand hipLaunchKernel a foreign stream (hipErrorInvalidResourceHandle at best).
@@ -3488,6 +3505,17 @@ static int32_t plan_launch(wedm_ctx* ctx, bool single, bool tr, bool frozen_ok, 
         else if (fused_ok) variant = 3;
         else variant = lanes_ok ? 2 : 1;
     }
+    // kernel 9 (served packed kernel, wedm_served.h): the packed walk with the scalar physics on a fifth wave of the block;
+    // 2, 4 or 8 lanes per environment; no trace point and no keep_stepping_terminated (such launches stay on kernel 4)
+    const int svl = (ctx->lanes == 4 || ctx->lanes == 8) ? ctx->lanes : (planes == 4 ? 4 : 8);
+    const int svi = lanes_index(2 * svl);
+    const size_t sv_box = svl == 8 ? sizeof(ServedBox<32>) : sizeof(ServedBox<64>);
+    const bool served_ok = uniform && !f64 && !ctx->replay && !P.keep_stepping_terminated && (ctx->lanes == 0 || ctx->lanes == svl) &&
+                           svi >= 0 && ctx->walk_ok[svi] &&
+                           (2 * (size_t)ctx->walk_C[svi] + 2) * 1024 + sv_box <= (size_t)ctx->lds_limit;
+    if (variant == 9 && !served_ok)
+        return fail(ctx, WEDM_ERR_UNSUPPORTED, "wedm_step: served kernel needs uniform geometry, the float32 stencil, lanes 4 or 8, two chunks that fit in LDS and freeze_terminated");
+    if (variant == 9 && tr) variant = packed_ok ? 4 : fused_ok ? 3 : lanes_ok ? 2 : 1;
     if (variant == 7 && !regs_ok)
         return fail(ctx, WEDM_ERR_UNSUPPORTED, "wedm_step: register kernel needs uniform geometry, at most 128 segments and the float32 stencil");
     if (variant == 7 && tr) variant = packed_ok ? 4 : fused_ok ? 3 : lanes_ok ? 2 : 1;
@@ -3546,6 +3574,14 @@ static int32_t plan_launch(wedm_ctx* ctx, bool single, bool tr, bool frozen_ok, 
         fn = f64 ? (tr ? pick_lanes<true, true>(glanes) : pick_lanes<false, true>(glanes))
                  : (tr ? pick_lanes<true, false>(glanes) : pick_lanes<false, false>(glanes));
         std::snprintf(out.name, sizeof(out.name), "wedm_step_lanes<%d>%s<<<%d,256,%zuB>>>", glanes, f64 ? "[f64 stencil]" : "", grid, fl);
+    } else if (variant == 9) {
+        grid = (ctx->num_envs + 256 / svl - 1) / (256 / svl);
+        fl = (2 * (size_t)ctx->walk_C[svi] + 2) * 1024 + sv_box;
+        out.walk = ctx->walk_dev + svi;
+        out.block = 320;  // four walker waves + the scalar wave
+        const bool extra = ((ctx->walk_n1z >> svi) & 1u) || ((ctx->walk_C[svi] > 8) && (ctx->walk_C[svi] & 7) >= 1 && (ctx->walk_C[svi] & 7) <= 2);
+        fn = pick_served(svl, extra);
+        std::snprintf(out.name, sizeof(out.name), "wedm_step_served<%d><<<%d,320,%zuB>>>", svl, grid, fl);
     } else if (variant == 4) {
         grid = (ctx->num_envs + 256 / planes - 1) / (256 / planes);
         fl = (2 * (size_t)ctx->walk_C[pli] + 2) * 1024;
@@ -3577,6 +3613,7 @@ static int32_t plan_launch(wedm_ctx* ctx, bool single, bool tr, bool frozen_ok, 
     }
     out.fn = fn;
     out.grid = grid;
+    if (variant != 9) out.block = 256;
     out.lds = fl;
     out.valid = true;
     return WEDM_OK;
@@ -3786,7 +3823,7 @@ int32_t wedm_bind_rng_replay(wedm_ctx* ctx, const double* table, int64_t n_steps
 
 int32_t wedm_set_kernel(wedm_ctx* ctx, int32_t variant) {
     if (!ctx) return WEDM_ERR_BAD_ARG;
-    if (variant < 0 || variant > 8) return fail(ctx, WEDM_ERR_BAD_ARG, "wedm_set_kernel: variant must be 0..8");
+    if (variant < 0 || variant > 9) return fail(ctx, WEDM_ERR_BAD_ARG, "wedm_set_kernel: variant must be 0..9");
     ctx->variant = variant;
     ctx->invalidate_plans();
     return WEDM_OK;
@@ -3897,7 +3934,7 @@ int32_t wedm_step(wedm_ctx* ctx, int32_t n_substeps, const wedm_action_ptrs* act
     }
     k.walk = plan.walk;
     void* kargs[] = {(void*)&k};
-    hipError_t el = hipLaunchKernel(plan.fn, dim3(plan.grid), dim3(256), kargs, plan.lds, (hipStream_t)stream);
+    hipError_t el = hipLaunchKernel(plan.fn, dim3(plan.grid), dim3(plan.block), kargs, plan.lds, (hipStream_t)stream);
     if (el != hipSuccess) return hip_fail(ctx, el, "wedm_step launch");
     ctx->last_plan = &plan;
     ctx->last_n_sub = n_substeps;

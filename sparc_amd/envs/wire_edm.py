@@ -32,7 +32,7 @@ from ..core import derive
 from ..core.env_config import EnvironmentConfig
 from ..core.material_db import get_material_db
 from ..core.state import BatchedEDMState
-from ..core.tables import CRATER, MODE_CURRENT, VALID_CRATER_MODES
+from ..core.tables import CRATER, MAX_MODE, MODE_CURRENT, VALID_CRATER_MODES
 from ..modules.parameters import (
     DielectricModuleParameters,
     IgnitionModuleParameters,
@@ -274,7 +274,8 @@ class WireEDMEnv:
         self._reward = self.state.reward[0, : self.num_envs]  # zeros unless reward="progress" (written by the kernels)
         self._truncated = torch.zeros(self.num_envs, dtype=torch.bool, device=self.device)
         self._mask_buf = None
-        self._valid_modes_dev = None
+        # current modes with crater data (material.py:108-113) as a device-side lookup table: index mode, clamped to [0, 20]
+        self._valid_modes_dev = torch.tensor([m in VALID_CRATER_MODES for m in range(MAX_MODE + 2)], dtype=torch.bool).to(self.device)
         self._step_out = None
         self._trace = None
         self._seed = int.from_bytes(os.urandom(8), "little")
@@ -386,10 +387,8 @@ class WireEDMEnv:
         launch still in flight).  An invalid entry sets the environment's sticky ERROR flag -- the row the kernels
         set at the first fresh spark with such a mode -- and `check_errors()` raises for it (deferred raise)."""
         if torch.is_tensor(mode) and mode.device.type != "cpu":
-            if self._valid_modes_dev is None:
-                self._valid_modes_dev = torch.tensor(VALID_CRATER_MODES, dtype=torch.int64, device=self.device)
-            m = mode.to(self.device).reshape(-1)
-            bad_dev = ~torch.isin(m.to(torch.int64), self._valid_modes_dev)
+            m = mode.to(self.device).reshape(-1).to(torch.int64)
+            bad_dev = ~self._valid_modes_dev[torch.clamp(m, 0, MAX_MODE + 1)]  # (table built at construction: no upload here)
             if bad_dev.numel() == 1:
                 bad_dev = bad_dev.expand(self.num_envs)
             elif bad_dev.numel() != self.num_envs:
@@ -425,7 +424,9 @@ class WireEDMEnv:
         kernel (one environment per lane, its whole wire in registers: wires of at most 128 segments,
         uniform geometry), 8 = wide register kernel (4 / 8 / 16 lanes per environment with 32 cells each in
         registers: wires of 9 to 512 segments, uniform geometry; auto picks it for fused launches of small
-        batches); ``lanes`` lanes per environment for 2/3/4/6/8 (0 = auto).  All variants are bit-identical."""
+        batches), 9 = served kernel (kernel 4's walk with the float64 scalar physics of a block's environments on a wave
+        of its own, one microsecond ahead of the walking waves: 4 or 8 lanes per environment, uniform geometry);
+        ``lanes`` lanes per environment for 2/3/4/6/8/9 (0 = auto).  All variants are bit-identical."""
         self._backend.set_kernel(variant)
         if hasattr(self._backend, "set_lanes"):
             self._backend.set_lanes(lanes)

@@ -131,9 +131,11 @@ def test_device_math_primitives_match_cpu_bit_for_bit(orc, kind):
 
 
 KERNELS = [(1, 0), (5, 0), (6, 0), (6, 4), (6, 16), (2, 0), (3, 1), (3, 2), (3, 4), (3, 8), (3, 16), (4, 1), (4, 2), (4, 4), (4, 8)]
+# the served kernels (wedm_served.h: the scalar physics of a block's environments on a wave of its own, one step ahead)
+SERVED = [(9, 4), (9, 8)]
 
 
-@pytest.mark.parametrize("variant,lanes", KERNELS)
+@pytest.mark.parametrize("variant,lanes", KERNELS + SERVED)
 def test_default_config_fused_matches_oracle(variant, lanes):
     """BASELINE config 2 shape (S=400): 3 control intervals, every kernel variant."""
     n = 320
@@ -177,7 +179,7 @@ def test_single_microsecond_steps_with_changing_actions():
     assert torch.equal(tg.cpu(), tc)
 
 
-@pytest.mark.parametrize("variant,lanes", KERNELS + [(7, 0)])
+@pytest.mark.parametrize("variant,lanes", KERNELS + [(7, 0)] + SERVED)
 def test_config3_grid_128_segments(variant, lanes):
     """BASELINE config 3: segment_len 0.625 -> 128 segments."""
     n = 1024
@@ -193,7 +195,7 @@ def test_config3_grid_128_segments(variant, lanes):
     check(gpu, cpu, n)
 
 
-@pytest.mark.parametrize("variant,lanes", [(3, 4), (3, 8), (3, 16), (4, 4), (4, 8), (6, 4), (6, 8), (2, 8)])
+@pytest.mark.parametrize("variant,lanes", [(3, 4), (3, 8), (3, 16), (4, 4), (4, 8), (6, 4), (6, 8), (2, 8), (9, 4), (9, 8)])
 def test_fused_kernel_with_ragged_chunks_and_heavy_sparking(variant, lanes):
     """361 segments (not divisible by any lane count), thin wire + I17: Joule heating,
     plasma cells at chunk edges, wire breaks and frozen environments inside live waves."""
@@ -211,7 +213,7 @@ def test_fused_kernel_with_ragged_chunks_and_heavy_sparking(variant, lanes):
         env.step_many(a, 700)
     check(gpu, cpu, n)
     want = {3: f"wedm_step_fused<{lanes}>", 4: f"wedm_step_packed<{lanes}>", 6: f"wedm_step_stream<{lanes}>",
-            2: f"wedm_step_lanes<{lanes}>"}[variant]
+            2: f"wedm_step_lanes<{lanes}>", 9: f"wedm_step_served<{lanes}>"}[variant]
     assert want in gpu._backend.last_kernel()
     assert bool(gpu.state.is_wire_broken.any()) and not bool(gpu.state.is_wire_broken.all())
 
@@ -510,7 +512,7 @@ def test_tiny_wires_all_kernels(segment_len, n_seg):
     from sparc_amd._lib import WedmError
 
     ran = 0
-    for variant, lanes in KERNELS + [(7, 0), (8, 0)]:
+    for variant, lanes in KERNELS + [(7, 0), (8, 0)] + SERVED:
         gpu.set_kernel(variant, lanes)
         a_g, a_c = gpu.make_action(0.1, 80.0, 9, 3.0, 30.0), cpu.make_action(0.1, 80.0, 9, 3.0, 30.0)
         try:
@@ -843,7 +845,10 @@ def test_randomized_configurations_all_kernels_bit_exact(case):
         servo = servo * rng.choice([1.0, 1.0, 20.0, -3.0], n)
     modes = rng.choice([15, 17] if extreme else [1, 3, 5, 7, 9, 11, 13, 15, 17], n).astype(np.int32)
     ran = 0
-    for variant, lanes in [variants[i] for i in rng.permutation(len(variants))[:4]]:
+    drawn = [variants[i] for i in rng.permutation(len(variants))[:4]]
+    if not per_env:   # every uniform-geometry case also runs a served kernel, last (the draws of the earlier rounds stay as they were)
+        drawn.append(SERVED[case % 2])
+    for variant, lanes in drawn:
         gpu.set_kernel(variant, lanes)
         k = int(rng.choice([1, 7, 400, 1300]))
         if ran == 0:
@@ -873,7 +878,7 @@ def test_randomized_configurations_all_kernels_bit_exact(case):
     assert ran >= (2 if case < 20 else 1)   # (a widened hunt may draw three kernels that do not fit the geometry)
 
 
-@pytest.mark.parametrize("variant,lanes", [(1, 0), (2, 4), (3, 8), (4, 4), (5, 0), (6, 8), (7, 0)])
+@pytest.mark.parametrize("variant,lanes", [(1, 0), (2, 4), (3, 8), (4, 4), (5, 0), (6, 8), (7, 0), (9, 8)])
 def test_clock_high_word_across_the_32_bit_wrap_matches_oracle(variant, lanes):
     """`state.time` past 2**31 and 2**32 us: the kernels carry the low word (also the Philox counter word) through the
     launch and bump row TIME_HI when it wrapped inside it; every kernel == the oracle on every byte, in fused and in
@@ -1274,7 +1279,7 @@ def test_config5_at_full_size_all_eight_shards_in_turn_equal_one_batch():
 
 
 # ------------------------------------------------------------------ auto-reset / reward / voltage sum inside the launch
-@pytest.mark.parametrize("variant,lanes", [(0, 0), (2, 4), (3, 8), (4, 4), (1, 0), (5, 0), (6, 8)])
+@pytest.mark.parametrize("variant,lanes", [(0, 0), (2, 4), (3, 8), (4, 4), (1, 0), (5, 0), (6, 8), (9, 8), (9, 4)])
 def test_in_kernel_autoreset_and_reward_match_oracle_and_host_path(variant, lanes):
     """wedm_params.autoreset + reward_mode: environments that reach their cutting target are
     re-initialised by the NEXT launch itself (Philox episode + 1, fresh module state, spool-temperature wire,
@@ -1739,7 +1744,7 @@ def test_negative_plasma_heat_every_kernel_matches_oracle(segment_len):
               config=EnvironmentConfig(target_cutting_distance=5000.0))
     gpu, cpu = make_pair(n, **kw)
     ran = 0
-    for variant, lanes in KERNELS + [(0, 0), (7, 0), (8, 0)]:
+    for variant, lanes in KERNELS + [(0, 0), (7, 0), (8, 0)] + SERVED:
         gpu.set_kernel(variant, lanes)
         for env in (gpu, cpu):
             env.reset(seed=515)

@@ -20,7 +20,7 @@ obj_dir.mkdir(parents=True, exist_ok=True)
 out.parent.mkdir(parents=True, exist_ok=True)
 flags = [f for f in g.HIPCC_FLAGS if f != "-shared"] + ["-w", f'-DWEDM_BUILD_ID="{g.kernel_build_id()}+{tag}"'] + extra
 procs, objs = [], []
-for part in (1, 2, 0):
+for part in (1, 2, 0, 3):
     obj = obj_dir / f"part{part}.o"
     objs.append(obj)
     procs.append(subprocess.Popen(["/opt/rocm/bin/hipcc", *flags, f"-DWEDM_PART={part}", "-c", "-o", str(obj), str(g.HIP_SRC)],
