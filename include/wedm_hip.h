@@ -398,7 +398,7 @@ int64_t wedm_trace_samples(wedm_ctx* ctx);
  * chunk of a lane requested up front, tile walk in LDS, no barrier; the automatic choice for
  * n_substeps == 1 where one round of blocks covers the batch), 7 = register kernel (one environment per
  * lane with its whole wire in registers: no LDS, the scalar physics once per environment; uniform geometry,
- * at most 128 segments, float32 stencil; launches with a trace sample take the LDS kernels),
+ * at most 128 segments, float32 stencil; own instantiation for launches with a trace sample),
  * 8 = wide register kernel (4, 8 or 16 lanes per environment -- the fewest that hold the wire at 32 cells per lane --
  * with the wire in their registers and per-cell zone / contact coefficients: no LDS, no tile table; uniform geometry,
  * 9 to 512 segments, float32 stencil; the automatic choice for fused launches of a batch that one round of blocks
@@ -423,6 +423,11 @@ const char* wedm_last_error(wedm_ctx* ctx);
 
 /* sizeof(wedm_params) the library was compiled with (layout cross-check for bindings) */
 int64_t wedm_sizeof_params(void);
+
+/* Blocks of the last launch's kernel that the occupancy API admits per compute unit at that launch's block size and
+ * dynamic LDS (hipOccupancyMaxActiveBlocksPerMultiprocessor), or a negative status.  Diagnostic: measurement scripts
+ * record it next to a kernel's name; nothing in the library depends on it.                                          */
+int32_t wedm_last_occupancy(wedm_ctx* ctx);
 
 /* TEST HOOK: evaluates one of the device math primitives the physics relies on,
  * element-wise on device arrays, so tests can compare them bit for bit with the CPU.

@@ -70,6 +70,8 @@ def load() -> C.CDLL:
     L.wedm_last_error.restype = C.c_char_p
     L.wedm_last_kernel.argtypes = [ctx]
     L.wedm_last_kernel.restype = C.c_char_p
+    L.wedm_last_occupancy.argtypes = [ctx]
+    L.wedm_last_occupancy.restype = C.c_int32
     L.wedm_debug_math.argtypes = [C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p]
     L.wedm_debug_math.restype = C.c_int32
     L.wedm_debug_poison_lds.argtypes = [C.c_float, C.c_void_p]
@@ -82,7 +84,7 @@ def load() -> C.CDLL:
 
 EXPORTS = (
     "wedm_abi_version", "wedm_create", "wedm_destroy", "wedm_bind_state", "wedm_bind_geometry",
-    "wedm_reset", "wedm_step", "wedm_bind_trace", "wedm_bind_rng_replay", "wedm_trace_samples", "wedm_set_kernel", "wedm_set_lanes", "wedm_last_kernel", "wedm_last_error",
+    "wedm_reset", "wedm_step", "wedm_bind_trace", "wedm_bind_rng_replay", "wedm_trace_samples", "wedm_set_kernel", "wedm_set_lanes", "wedm_last_kernel", "wedm_last_error", "wedm_last_occupancy",
     "wedm_sizeof_params", "wedm_debug_math", "wedm_debug_poison_lds", "wedm_build_id",
 )
 
@@ -182,6 +184,10 @@ class HipBackend:
 
     def last_kernel(self) -> str:
         return (self._L.wedm_last_kernel(self._ctx) or b"").decode()
+
+    def last_occupancy(self) -> int:
+        """Blocks per CU the occupancy API admits for the last launch's kernel, block size and LDS (diagnostic)."""
+        return int(self._L.wedm_last_occupancy(self._ctx))
 
     def build_id(self) -> str:
         return build_id()

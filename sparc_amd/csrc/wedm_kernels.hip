@@ -1952,7 +1952,9 @@ __device__ __forceinline__ float max3_raw(float a, float b, float c) {
 #ifndef WEDM_REGS_PIN2
 #define WEDM_REGS_PIN2 1
 #endif
-template <int CELLS, int L>
+// TRACE: the instantiation with the signal-trace point (a launch into which a sample falls: the reference's logger samples
+// after every step, utils/logger.py:110-160); launches without a sample run the instantiation without it.
+template <int CELLS, int L, bool TRACE = false>
 __global__ void __launch_bounds__(256, L) wedm_step_regs(const KArgs k) {
     // L = 1: one environment per lane (H = 64 pairs, one wave per SIMD at a 512-register budget);
     // L = 2: two lanes per environment, each with half of the wire (H = 32 pairs, two waves per SIMD, the scalar physics
@@ -2048,9 +2050,12 @@ __global__ void __launch_bounds__(256, L) wedm_step_regs(const KArgs k) {
             convp[t] = f2{((zoneA >> t) & 1u) ? ps.conv_zone : ps.conv_base, ((zoneB >> t) & 1u) ? ps.conv_zone : ps.conv_base};
     };
     build_conv();
+    const bool tracing = WEDM_TRACING(k);
+    int trace_next = k.trace_next, trace_slot = k.trace_slot;
+    (void)trace_next; (void)trace_slot;
 
     for (int it = 0; it < k.n_substeps; ++it) {
-        if (__all(s.done)) break;
+        if (__all(s.done) && !tracing) break;  // (terminated environments keep being sampled: their frozen state)
         Coef cf{0.0f, 0.0f, 0, -1};
         QuietTry qt;
         const bool was_quiet = quiet_prelude_t<WEDM_REGS_DENSE>(hv, cold, g, e, gid, s, qt, cf);
@@ -2217,6 +2222,18 @@ __global__ void __launch_bounds__(256, L) wedm_step_regs(const KArgs k) {
             scalar_epilogue(hv, s, tmax);
             if (s.ctrl) control_step_outputs(cold, e, s, writer);
         }
+        WEDM_TRACE_POINT(k, it, e, s, writer,
+                         // (unrolled: a register file has no dynamic index; two running pointers made opaque after every pair,
+                         // or the 2 H addresses are all computed up front and kept: 244 spilled registers in the two-lane form)
+                         float* pa = tT + (int64_t)base * tcnt; float* pb = pa + (int64_t)H * tcnt;
+                         int na = n - base; int nb = na - H;   // cells of this lane's two chunks that exist
+                         asm volatile("" : "+v"(na), "+v"(nb));   // (opaque: or the 2 H store predicates are made before the loop and kept)
+                         _Pragma("unroll") for (int m = 0; m < H; ++m) {
+                             if (m < na) *pa = P[m].x;
+                             if (m < nb) *pb = P[m].y;
+                             pa += tcnt; pb += tcnt;
+                             asm volatile("" : "+v"(pa), "+v"(pb));
+                         });
     }
 
     if (live) {
@@ -3487,14 +3504,14 @@ static int32_t plan_launch(wedm_ctx* ctx, bool single, bool tr, bool frozen_ok, 
     if (variant == 8 && !wide_ok)
         return fail(ctx, WEDM_ERR_UNSUPPORTED, "wedm_step: wide register kernel needs uniform geometry, 9 to 512 segments, the float32 stencil and lanes 0, 4, 8 or 16 with 32 cells per lane covering the wire");
     // kernel 7 (register kernel): one or two lanes per environment with the wire in their registers; wires of at most 128
-    // segments, uniform geometry, float32 stencil; it has no trace point: a launch with a trace sample takes the LDS kernels
+    // segments, uniform geometry, float32 stencil; a launch with a trace sample runs its TRACE instantiation
     const bool regs_ok = uniform && ctx->walk_regs_ok && ctx->n_seg_max <= 128 && !f64 && !ctx->replay;
     if (variant == 0) {
         // fused launches of a batch that gives most CUs a block of the register kernel (measured, 128 segments, two lanes
         // per environment against the best LDS kernel: 8 192 environments 2.8e9 vs 3.5e9, 16 384: 5.5e9 vs 6.1e9,
         // 24 576: 8.3e9 vs 7.4e9, 32 768: 1.10e10 vs 9.9e9, 65 536: 1.67e10 vs 1.44e10, 131 072: 1.76e10 vs 1.50e10;
         // up to 16 384 environments the wide register kernel above has taken the launch: 8.1e9 there)
-        if (!single && !tr && regs_ok && ctx->lanes == 0 && ctx->num_envs >= 20480) variant = 7;
+        if (!single && regs_ok && ctx->lanes == 0 && ctx->num_envs >= 20480) variant = 7;
     }
     if (variant == 0) {
         // single-microsecond launches: the stream kernel where one round of blocks covers the batch with chunks of
@@ -3518,7 +3535,6 @@ static int32_t plan_launch(wedm_ctx* ctx, bool single, bool tr, bool frozen_ok, 
     if (variant == 9 && tr) variant = packed_ok ? 4 : fused_ok ? 3 : lanes_ok ? 2 : 1;
     if (variant == 7 && !regs_ok)
         return fail(ctx, WEDM_ERR_UNSUPPORTED, "wedm_step: register kernel needs uniform geometry, at most 128 segments and the float32 stencil");
-    if (variant == 7 && tr) variant = packed_ok ? 4 : fused_ok ? 3 : lanes_ok ? 2 : 1;
     if (variant == 3 && !fused_ok)
         return fail(ctx, WEDM_ERR_UNSUPPORTED, "wedm_step: fused kernel needs uniform geometry and a chunk that fits in LDS");
     if (variant == 4 && !packed_ok)
@@ -3542,7 +3558,8 @@ static int32_t plan_launch(wedm_ctx* ctx, bool single, bool tr, bool frozen_ok, 
         const int rl = ctx->lanes == 1 ? 1 : 2;  // lanes per environment (default 2: two waves per SIMD)
         grid = (ctx->num_envs + 256 / rl - 1) / (256 / rl);
         out.walk = ctx->walk_dev + (rl == 1 ? 10 : 11);  // two chunks of 64 cells / four of 32
-        fn = rl == 1 ? (const void*)wedm_step_regs<128, 1> : (const void*)wedm_step_regs<128, 2>;
+        fn = tr ? (rl == 1 ? (const void*)wedm_step_regs<128, 1, true> : (const void*)wedm_step_regs<128, 2, true>)
+                : (rl == 1 ? (const void*)wedm_step_regs<128, 1> : (const void*)wedm_step_regs<128, 2>);
         std::snprintf(out.name, sizeof(out.name), "wedm_step_regs<%d><<<%d,256>>>", rl, grid);
     } else if (variant == 8) {
         grid = (ctx->num_envs + 256 / wl - 1) / (256 / wl);
@@ -3635,6 +3652,14 @@ const char* wedm_last_kernel(wedm_ctx* ctx) {
     if (!ctx) return "";
     if (ctx->last_plan) ctx->last_kernel = std::string(ctx->last_plan->name) + " n_sub=" + std::to_string(ctx->last_n_sub);
     return ctx->last_kernel.c_str();
+}
+
+int32_t wedm_last_occupancy(wedm_ctx* ctx) {
+    if (!ctx || !ctx->last_plan) return WEDM_ERR_BAD_ARG;
+    int n = 0;
+    hipError_t e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, ctx->last_plan->fn, ctx->last_plan->block, ctx->last_plan->lds);
+    if (e != hipSuccess) return hip_fail(ctx, e, "hipOccupancyMaxActiveBlocksPerMultiprocessor");
+    return (int32_t)n;
 }
 
 int32_t wedm_create(const wedm_params* params, int32_t num_envs, int32_t n_seg_max, wedm_ctx** out) {

@@ -48,6 +48,17 @@ struct ServedBox {   // lives in LDS behind the wire image
     float adv[EPB];
 };
 
+// diagnostic build -DWEDM_STAMPS (tools/stamps_served.py): per wave {HW_ID, XCC_ID, start, end (100 MHz clock all XCDs
+// share), shader-clock cycles spent spinning, shader-clock cycles in the loop, steps speculated}
+#ifdef WEDM_STAMPS
+#define WEDM_SV_CLOCK(var) asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(var)::"memory")
+#define WEDM_SV_WAIT_BEGIN() unsigned long long sv_w0_; WEDM_SV_CLOCK(sv_w0_)
+#define WEDM_SV_WAIT_END() do { unsigned long long sv_w1_; WEDM_SV_CLOCK(sv_w1_); sv_wait_acc += sv_w1_ - sv_w0_; } while (0)
+#else
+#define WEDM_SV_WAIT_BEGIN() do { } while (0)
+#define WEDM_SV_WAIT_END() do { } while (0)
+#endif
+
 __device__ __forceinline__ void sv_wait(const volatile uint32_t* p, uint32_t want) {
     // wave-uniform spin on an LDS word another wave of the block advances (monotone counters: signed distance)
     for (;;) {
@@ -95,6 +106,19 @@ __global__ void __launch_bounds__(320, WEDM_SERVED_WAVES_PER_EU) wedm_step_serve
     volatile Box* const box = (volatile Box*)(lds + (size_t)(R + 2) * 256);
     const float spool = k.hot.spool, tref = k.hot.tref, alpha = k.hot.alpha, tdiel = k.hot.tdiel;
     const bool scalar_wave = tid >= 256;
+#ifdef WEDM_STAMPS
+    unsigned long long sv_wait_acc = 0, sv_t0 = 0, sv_t1 = 0, sv_c0 = 0, sv_c1 = 0, sv_spec = 0;
+    uint32_t sv_hwid = 0, sv_xcc = 0;
+    asm volatile("s_getreg_b32 %0, hwreg(4)\n\ts_getreg_b32 %1, hwreg(20)" : "=s"(sv_hwid), "=s"(sv_xcc));
+    asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(sv_t0)::"memory");
+#define WEDM_SV_STAMP_OUT() do { \
+        asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(sv_t1)::"memory"); \
+        if (k.dbg && (tid & 63) == 0) { \
+            unsigned long long* o = k.dbg + ((size_t)blockIdx.x * 5 + (tid >> 6)) * 8; \
+            o[0] = sv_hwid; o[1] = sv_xcc; o[2] = sv_t0; o[3] = sv_t1; o[4] = sv_wait_acc; o[5] = sv_c1 - sv_c0; o[6] = sv_spec; } } while (0)
+#else
+#define WEDM_SV_STAMP_OUT() do { } while (0)
+#endif
 
     if (tid == 0) { box->cf_seq = 0u; box->tm_seq[0] = 0u; box->tm_seq[1] = 0u; box->tm_seq[2] = 0u; box->tm_seq[3] = 0u; }
 
@@ -103,10 +127,14 @@ __global__ void __launch_bounds__(320, WEDM_SERVED_WAVES_PER_EU) wedm_step_serve
 #ifdef WEDM_SV_NO_SCALAR  // (register-pressure probes of the two roles: tools/kernel_resources.py -DWEDM_SV_NO_...)
         return;
 #endif
+#ifndef WEDM_SV_NO_PRIO
         __builtin_amdgcn_s_setprio(3);  // its chain is on the critical path of four walker waves
+#endif
         Hot hv = k.hot;
+#ifndef WEDM_SV_NO_PIN
         pin_mechanics_in_vgprs(hv);
         pin_quiet_in_vgprs(hv);
+#endif
         const int sl = tid - 256;
         const int64_t e = e0 + (sl < EPB ? sl : 0);
         const bool live = sl < EPB && e0 + sl < k.num_envs;
@@ -134,6 +162,9 @@ __global__ void __launch_bounds__(320, WEDM_SERVED_WAVES_PER_EU) wedm_step_serve
         bool have_m = false;       // max(T) of the wire as it is now is known (wave-uniform): not in a launch's first step
         float M = spool;
         int it = 0;
+#ifdef WEDM_STAMPS
+        WEDM_SV_CLOCK(sv_c0);
+#endif
         for (; it < k.n_substeps; ++it) {
             const int slot = it & 1;
             if (__all(s.done != 0)) {  // every environment of the block is terminated: the walkers stop too
@@ -145,7 +176,9 @@ __global__ void __launch_bounds__(320, WEDM_SERVED_WAVES_PER_EU) wedm_step_serve
             Coef cf{0.0f, 0.0f, 0, -1};
             QuietTry qt;
             const bool was_quiet = quiet_prelude_t<WEDM_PACKED_DENSE>(hv, cold, g, e, gid, s, qt, cf);
+#ifndef WEDM_SV_NO_GENERAL
             if (!was_quiet && !s.done) cf = scalar_prelude(hv, cold, g, e, gid, s, ps, true, qt);
+#endif
             const float jf_eff = (cf.joule_on && !s.done) ? cf.jf : 0.0f;
             if (sl < EPB) {
                 box->jf[slot][sl] = cf.jf; box->q[slot][sl] = cf.q; box->pidx[slot][sl] = cf.pidx;
@@ -156,7 +189,7 @@ __global__ void __launch_bounds__(320, WEDM_SERVED_WAVES_PER_EU) wedm_step_serve
             if (sl == 0) box->cf_seq = (uint32_t)it + 1u;
             // ---- the previous step's temperature monitor, now that its maximum is there (the walkers had a prelude's time)
             if (pending) {
-                sv_wait_lanes(&box->tm_seq[(sl < EPB ? sl * L : 0) >> 6], (uint32_t)it);
+                { WEDM_SV_WAIT_BEGIN(); sv_wait_lanes(&box->tm_seq[(sl < EPB ? sl * L : 0) >> 6], (uint32_t)it); WEDM_SV_WAIT_END(); }
                 const float tm = sl < EPB ? box->tmax[slot ^ 1][sl] : spool;
                 if (pend_live) {
                     s.tcrit = tm > hv.tcrit ? s.tcrit + 1 : 0;
@@ -174,16 +207,23 @@ __global__ void __launch_bounds__(320, WEDM_SERVED_WAVES_PER_EU) wedm_step_serve
                                    ps.adv >= 0.0f && jf_eff >= 0.0f && tuf * (2.0f * kf + conv_max + ps.adv) <= 1.0f;
             const float rise = tuf * (jf_eff * (1.0f + alpha * (Mb - tref)) + fmaxf(cf.q, 0.0f));
             const bool safe = s.done || (scheme_ok && !s.ctrl && Mb + rise + 1.0f < hv.tbreak);  // (a NaN anywhere: not safe)
+#ifdef WEDM_SV_NO_SPEC  // (ablation: never ahead -- every step waits for its maximum, as an unserved kernel does)
+            if (false) {
+#else
             if (have_m && __all(safe)) {
+#endif
                 // proven: no lane's wire breaks in this step -> the rest of the epilogue now, the monitor when the maximum arrives
                 pend_live = !s.done;
+#ifdef WEDM_STAMPS
+                ++sv_spec;
+#endif
                 if (!s.done) {
                     epilogue_voltage_sum(s);
                     epilogue_motion(hv, s);
                 }
                 pending = true;
             } else {
-                sv_wait_lanes(&box->tm_seq[(sl < EPB ? sl * L : 0) >> 6], (uint32_t)it + 1u);
+                { WEDM_SV_WAIT_BEGIN(); sv_wait_lanes(&box->tm_seq[(sl < EPB ? sl * L : 0) >> 6], (uint32_t)it + 1u); WEDM_SV_WAIT_END(); }
                 const float tm = sl < EPB ? box->tmax[slot][sl] : spool;
                 if (!s.done) {
                     scalar_epilogue(hv, s, tm);
@@ -202,6 +242,10 @@ __global__ void __launch_bounds__(320, WEDM_SERVED_WAVES_PER_EU) wedm_step_serve
                 if (tm > hv.tbreak) { s.err = 1; s.broken = 1; s.done = hv.done_value; }
             }
         }
+#ifdef WEDM_STAMPS
+        WEDM_SV_CLOCK(sv_c1);
+#endif
+        WEDM_SV_STAMP_OUT();
         __builtin_amdgcn_s_setprio(0);
         __syncthreads();  // (B) the walkers' last step is in LDS
         if (live) {
@@ -279,9 +323,12 @@ __global__ void __launch_bounds__(320, WEDM_SERVED_WAVES_PER_EU) wedm_step_serve
         }
     }
 
+#ifdef WEDM_STAMPS
+    WEDM_SV_CLOCK(sv_c0);
+#endif
     for (int it = 0; it < k.n_substeps; ++it) {
         const int slot = it & 1;
-        sv_wait(&box->cf_seq, (uint32_t)it + 1u);
+        { WEDM_SV_WAIT_BEGIN(); sv_wait(&box->cf_seq, (uint32_t)it + 1u); WEDM_SV_WAIT_END(); }
         const int32_t fl = box->flags[slot][el];
         if (fl & SV_STOP) break;  // (block-wide: every lane reads it)
         Coef cf{box->jf[slot][el], box->q[slot][el], (fl & SV_JOULE) ? 1 : 0, box->pidx[slot][el]};
@@ -532,6 +579,10 @@ __global__ void __launch_bounds__(320, WEDM_SERVED_WAVES_PER_EU) wedm_step_serve
         if ((tid & 63) == 0) box->tm_seq[wave] = (uint32_t)it + 1u;
     }
 
+#ifdef WEDM_STAMPS
+    WEDM_SV_CLOCK(sv_c1);
+#endif
+    WEDM_SV_STAMP_OUT();
     __syncthreads();  // (B)
     copy_wire<L, false>(cold->s.T, stride, e0, k.num_envs, n, tid, lds, wire_slot);
 }

@@ -550,12 +550,13 @@ def assert_rings_equal(tg, tc, rows=None):
         assert torch.equal(G, Cc), f"trace T: {int((G != Cc).sum())} of {G.numel()} differ"
 
 
-@pytest.mark.parametrize("variant,lanes", KERNELS + [(8, 0)])
+@pytest.mark.parametrize("variant,lanes", KERNELS + [(8, 0), (7, 0), (7, 1)])
 def test_device_trace_ring_matches_oracle(variant, lanes):
     """The ring the kernels fill inside fused launches == the ring the oracle seam fills by
     sampling after single microseconds: every slot, every traced row, wire temperature included."""
     n = 200
-    gpu, cpu = make_pair(n)
+    # (the register kernel holds wires of at most 128 segments: its TRACE instantiation, one and two lanes per environment)
+    gpu, cpu = make_pair(n, **(dict(wire_params=WireModuleParameters(segment_len=0.625)) if variant == 7 else {}))
     gpu.set_kernel(variant, lanes)
     both((gpu, cpu), lambda e: (e.reset(seed=321), close_gap(e)))
     if (variant == 3 and (-(-gpu.n_segments // lanes) + 1) > 160) or \
@@ -575,6 +576,8 @@ def test_device_trace_ring_matches_oracle(variant, lanes):
     got = traces[0].read()
     assert bool(got["done"][-1, 7]) and int((got["spark_state"] == 1).sum()) > 0
     assert got["wire_temperature"].shape == (300, 150, gpu.n_segments)
+    if variant == 7:
+        assert "wedm_step_regs<" in gpu._backend.last_kernel()
     # no trace bound -> the instantiation without the trace point runs, results unchanged
     for env in (gpu, cpu):
         env.unbind_trace()

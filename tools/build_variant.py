@@ -14,6 +14,13 @@ sys.path.insert(0, str(ROOT))
 import __graft_entry__ as g  # noqa: E402
 
 tag, extra = sys.argv[1], sys.argv[2:]
+# `--only-part N`: compile translation unit N with the extra flags and take the other units' objects from the in-tree build
+# (build/obj/wedm_kernels.part*.o) -- for switches that concern one kernel family only (3 = the served kernels)
+only = None
+if "--only-part" in extra:
+    i = extra.index("--only-part")
+    only = int(extra[i + 1])
+    extra = extra[:i] + extra[i + 2:]
 out = ROOT / "build" / "ablate" / f"libwedm_{tag}.so"
 obj_dir = ROOT / "build" / "obj" / tag
 obj_dir.mkdir(parents=True, exist_ok=True)
@@ -21,6 +28,9 @@ out.parent.mkdir(parents=True, exist_ok=True)
 flags = [f for f in g.HIPCC_FLAGS if f != "-shared"] + ["-w", f'-DWEDM_BUILD_ID="{g.kernel_build_id()}+{tag}"'] + extra
 procs, objs = [], []
 for part in (1, 2, 0, 3):
+    if only is not None and part != only:
+        objs.append(ROOT / "build" / "obj" / f"wedm_kernels.part{part}.o")
+        continue
     obj = obj_dir / f"part{part}.o"
     objs.append(obj)
     procs.append(subprocess.Popen(["/opt/rocm/bin/hipcc", *flags, f"-DWEDM_PART={part}", "-c", "-o", str(obj), str(g.HIP_SRC)],
