@@ -3400,6 +3400,7 @@ static int32_t plan_launch(wedm_ctx* ctx, bool single, bool tr, bool frozen_ok, 
         const int rest = C & 7;
         return (double)(C / 8) + (rest == 0 ? 0.0 : (C > 8 && rest <= 2) ? 0.25 : 1.0);
     };
+    double best_lds_cost = 1e300;  // cycles per microsecond of the whole batch on the better of kernels 3 / 4, by the model above
     {
         double best3 = 1e300, best4 = 1e300;
         int l3 = 0, l4 = 0;
@@ -3430,6 +3431,7 @@ static int32_t plan_launch(wedm_ctx* ctx, bool single, bool tr, bool frozen_ok, 
         if (!lanes) lanes = l3;
         if (!planes) planes = l4;
         ctx->auto_prefers_packed = best4 <= best3;
+        best_lds_cost = std::min(best3, best4);
     }
     const int li = lanes_index(lanes);
     const bool fused_ok = uniform && li >= 0 && ctx->walk_ok[li] &&
@@ -3513,6 +3515,43 @@ static int32_t plan_launch(wedm_ctx* ctx, bool single, bool tr, bool frozen_ok, 
         // up to 16 384 environments the wide register kernel above has taken the launch: 8.1e9 there)
         if (!single && regs_ok && ctx->lanes == 0 && ctx->num_envs >= 20480) variant = 7;
     }
+    // kernel 9 (served packed kernel, wedm_served.h): the packed walk on three waves of a block, the scalar physics on the fourth;
+    // 4 or 8 lanes per environment; no trace point and no keep_stepping_terminated (such launches stay on kernel 4).
+    // Cost model (cycles per microsecond of the whole batch, same unit as the model of kernels 3 / 4; fitted to
+    // profiles/r4/plan_sweep.txt): a block's chain c = 1300 + 950 x tiles per lane; j blocks resident together on a CU take
+    // c x f(j), f = 1, 1.49, 1.80 (three fit the 168-register budget, fewer where the LDS image is large); blocks are
+    // dispatched as CUs free up, so the busiest CU runs b = ceil(blocks / 256) of them in groups of at most `rb`.
+    auto served_cost = [&](int L) -> double {
+        const int ti = lanes_index(2 * L);
+        if (ti < 0 || !ctx->walk_ok[ti]) return 1e300;
+        const size_t lds = (2 * (size_t)ctx->walk_C[ti] + 2) * 768 + (L == 8 ? sizeof(ServedBox<24>) : sizeof(ServedBox<48>));
+        if (lds > (size_t)ctx->lds_limit) return 1e300;
+        const long rb = std::min<long>(3, (long)(160 * 1024 / lds));
+        const long blocks = (ctx->num_envs + (192 / L) - 1) / (192 / L);
+        const long b = (blocks + 255) / 256;
+        static const double f[4] = {0.0, 1.0, 1.49, 1.80};
+        const double c = 1300.0 + 950.0 * eff_tiles(ctx->walk_C[ti]);
+        return (double)(b / rb) * c * f[rb] + ((b % rb) ? c * f[b % rb] : 0.0);
+    };
+    const double sv_cost4 = served_cost(4), sv_cost8 = served_cost(8);
+    const int svl = (ctx->lanes == 4 || ctx->lanes == 8) ? ctx->lanes : (sv_cost4 < sv_cost8 ? 4 : 8);
+    const int svi = lanes_index(2 * svl);
+    const size_t sv_box = svl == 8 ? sizeof(ServedBox<24>) : sizeof(ServedBox<48>);  // three walker waves: 24 / 48 environments per block
+    const bool served_ok = uniform && !f64 && !ctx->replay && !P.keep_stepping_terminated && (ctx->lanes == 0 || ctx->lanes == svl) &&
+                           svi >= 0 && ctx->walk_ok[svi] &&
+                           (2 * (size_t)ctx->walk_C[svi] + 2) * 768 + sv_box <= (size_t)ctx->lds_limit;
+    // the served kernel where its model beats what the choice so far would take (measured over 2 048 ... 131 072 environments x
+    // 128 ... 512 segments, profiles/r4/plan_sweep.txt: blocks of 24 / 48 environments, three to a CU, fill the chip where
+    // blocks of 32 ... 128 leave a ragged second round, and a sixth fewer instructions)
+    if (!single && !tr && served_ok && ctx->lanes == 0 && (variant == 0 || (variant == 7 && ctx->variant == 0))) {
+        const double sv = std::min(sv_cost4, sv_cost8);
+        double other = best_lds_cost;
+        if (variant == 7) {  // the two-lane register kernel: 128 environments per block, two blocks per CU (6 050 / 7 800 cycles)
+            const long b = ((ctx->num_envs + 127) / 128 + 255) / 256;
+            other = (double)(b / 2) * 7800.0 + (double)(b % 2) * 6050.0;
+        }
+        if (sv < other) variant = 9;
+    }
     if (variant == 0) {
         // single-microsecond launches: the stream kernel where one round of blocks covers the batch with chunks of
         // at most 64 cells (measured: 27.5 vs 30.3 us at 65 536 x 128, 20.5 vs 24.9 us at 4 096 x 400), else the
@@ -3522,14 +3561,6 @@ static int32_t plan_launch(wedm_ctx* ctx, bool single, bool tr, bool frozen_ok, 
         else if (fused_ok) variant = 3;
         else variant = lanes_ok ? 2 : 1;
     }
-    // kernel 9 (served packed kernel, wedm_served.h): the packed walk with the scalar physics on a fifth wave of the block;
-    // 2, 4 or 8 lanes per environment; no trace point and no keep_stepping_terminated (such launches stay on kernel 4)
-    const int svl = (ctx->lanes == 4 || ctx->lanes == 8) ? ctx->lanes : (planes == 4 ? 4 : 8);
-    const int svi = lanes_index(2 * svl);
-    const size_t sv_box = svl == 8 ? sizeof(ServedBox<32>) : sizeof(ServedBox<64>);
-    const bool served_ok = uniform && !f64 && !ctx->replay && !P.keep_stepping_terminated && (ctx->lanes == 0 || ctx->lanes == svl) &&
-                           svi >= 0 && ctx->walk_ok[svi] &&
-                           (2 * (size_t)ctx->walk_C[svi] + 2) * 1024 + sv_box <= (size_t)ctx->lds_limit;
     if (variant == 9 && !served_ok)
         return fail(ctx, WEDM_ERR_UNSUPPORTED, "wedm_step: served kernel needs uniform geometry, the float32 stencil, lanes 4 or 8, two chunks that fit in LDS and freeze_terminated");
     if (variant == 9 && tr) variant = packed_ok ? 4 : fused_ok ? 3 : lanes_ok ? 2 : 1;
@@ -3592,13 +3623,13 @@ static int32_t plan_launch(wedm_ctx* ctx, bool single, bool tr, bool frozen_ok, 
                  : (tr ? pick_lanes<true, false>(glanes) : pick_lanes<false, false>(glanes));
         std::snprintf(out.name, sizeof(out.name), "wedm_step_lanes<%d>%s<<<%d,256,%zuB>>>", glanes, f64 ? "[f64 stencil]" : "", grid, fl);
     } else if (variant == 9) {
-        grid = (ctx->num_envs + 256 / svl - 1) / (256 / svl);
-        fl = (2 * (size_t)ctx->walk_C[svi] + 2) * 1024 + sv_box;
+        grid = (ctx->num_envs + 192 / svl - 1) / (192 / svl);
+        fl = (2 * (size_t)ctx->walk_C[svi] + 2) * 768 + sv_box;
         out.walk = ctx->walk_dev + svi;
-        out.block = 320;  // four walker waves + the scalar wave
+        out.block = 256;  // three walker waves + the scalar wave
         const bool extra = ((ctx->walk_n1z >> svi) & 1u) || ((ctx->walk_C[svi] > 8) && (ctx->walk_C[svi] & 7) >= 1 && (ctx->walk_C[svi] & 7) <= 2);
         fn = pick_served(svl, extra);
-        std::snprintf(out.name, sizeof(out.name), "wedm_step_served<%d><<<%d,320,%zuB>>>", svl, grid, fl);
+        std::snprintf(out.name, sizeof(out.name), "wedm_step_served<%d><<<%d,256,%zuB>>>", svl, grid, fl);
     } else if (variant == 4) {
         grid = (ctx->num_envs + 256 / planes - 1) / (256 / planes);
         fl = (2 * (size_t)ctx->walk_C[pli] + 2) * 1024;

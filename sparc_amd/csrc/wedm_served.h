@@ -6,10 +6,13 @@
 // the stencil: ~340 wave-level instructions, most of them float64) is executed by every lane of the environment -- once per
 // WAVE, i.e. per 64 / L environments: 43 of the 103 wave-instructions per env-step of wedm_step_packed<8> at 32 768 x 400, 85 of
 // the 214 of wedm_step_lanes<8> (profiles/valu.json, round 3).  The reference runs that chain once per environment-step.  Here
-// a block has one more wave, the SCALAR wave: lane i of it owns environment i of the block (its whole Env in registers) and
-// runs prelude and epilogue once per environment and microsecond; the four WALKER waves own the wire (in LDS, as in
-// wedm_step_packed) and nothing else -- no Env, no float64 -- and get the six stencil coefficients of a microsecond through
-// a mailbox in LDS.
+// a block's last wave is the SCALAR wave: lane i of it owns environment i of the block (its whole Env in registers) and
+// runs prelude and epilogue once per environment and microsecond; the other WW (three) waves are WALKER waves: they own the
+// wire (in LDS, as in wedm_step_packed) and nothing else -- no Env, no float64 -- and get the six stencil coefficients of a
+// microsecond through a mailbox in LDS.  Blocks of FOUR waves (3 walkers + 1 scalar, 24 environments at 8 lanes each), three
+// of them per CU at a 168-register budget: a block of 4 + 1 waves is admitted only ONCE per CU at that budget although the
+// occupancy API answers 2 (census by HW_ID, tools/stamps_served.py: the dispatcher wants room for ceil(5 / 4) = 2 waves on
+// EVERY SIMD per block), and one such block per CU is as fast as wedm_step_packed and no faster.
 //
 // Protocol (LDS operations of one wave are processed in order; all waves of a block are resident together):
 //   scalar wave, step k : prelude(k) -> cf[k & 1][env] (jf, q, plasma cell, flags, convection pair) -> cf_seq = k + 1
@@ -40,7 +43,7 @@ enum { SV_JOULE = 1, SV_DONE = 2, SV_STOP = 4, SV_ADV = 8 };
 template <int EPB>
 struct ServedBox {   // lives in LDS behind the wire image
     uint32_t cf_seq;          // steps whose coefficients are published
-    uint32_t tm_seq[4];       // per walker wave: steps whose maxima are published
+    uint32_t tm_seq[4];       // per walker wave (at most four): steps whose maxima are published
     uint32_t pad_[3];
     float jf[2][EPB], q[2][EPB], conv_base[2][EPB], conv_zone[2][EPB];
     int32_t pidx[2][EPB], flags[2][EPB];
@@ -81,18 +84,75 @@ __device__ __forceinline__ void sv_wait_lanes(const volatile uint32_t* p, uint32
 
 }  // namespace wedm
 
-// ============================================ served packed kernel: L lanes / env, 2 cells / op, scalar physics on a fifth wave
+// -DWEDM_SV_CALL_GENERAL (tried, slower, kept as a switch): the GENERAL prelude (a lane ignites, a short, a control-step
+// latch: a few per cent of a batch's microseconds) as a real function call.  Inlined, its ~100 temporaries on top of the Env
+// cost the scalar wave 46-62 spilled registers at the 168 registers three blocks per CU leave a wave.  Called, what it takes
+// by reference lives in the stack frame around the call only -- but every other value that lives across the call is spilled
+// around it, in the hot loop too, and the chain of the scalar wave got longer, not shorter.
+// (Arguments of a function are vector registers: what is uniform -- the every-step parameters, the pointer block, the
+// geometry -- is read again from the kernel-argument segment inside, into scalar registers, as the kernels read it.  The
+// segment's address is handed over by the caller: in a function __builtin_amdgcn_kernarg_segment_ptr() is a NULL pointer.)
+__device__ __attribute__((noinline)) void sv_general_prelude(uint64_t kernarg_addr, int64_t e, uint32_t gid, Env& s, Persist& ps,
+                                                             const QuietTry& qt, Coef& out) {
+#if defined(__HIP_DEVICE_COMPILE__)  // (the host pass of hipcc cannot copy a struct out of the constant address space)
+    const uint32_t ka_lo = __builtin_amdgcn_readfirstlane((uint32_t)kernarg_addr), ka_hi = __builtin_amdgcn_readfirstlane((uint32_t)(kernarg_addr >> 32));
+    const WEDM_AS4 KArgs* const ka = (const WEDM_AS4 KArgs*)(((uint64_t)ka_hi << 32) | ka_lo);
+    const Hot hot = ka->hot;
+    const ColdRef cold{(ColdPtr)((const WEDM_AS4 char*)ka + offsetof(KArgs, cold))};
+    Geom g;
+    load_geom(hot, cold, e, g);
+    out = scalar_prelude(hot, cold, g, e, gid, s, ps, true, qt);
+#endif
+}
+
+// copy_wire() for a block whose first NT threads (NT = L x environments per block) move the wire; LDS rows of NT floats
+template <int L, int NT, bool TO_LDS, class Slot>
+__device__ __forceinline__ void copy_wire_nt(float* T, int64_t stride, int64_t e0, int num_envs, int n, int tid, float* lds, Slot slot) {
+    constexpr int EPB = NT / L;
+    const int qr = tid / EPB, sel = tid % EPB;  // L quads per iteration
+    if (e0 + sel >= num_envs) return;
+    float* const base = T + 4 * (e0 + sel);
+    const int64_t qstride = 4 * stride;
+    const int nq = (n + 3) >> 2;
+    for (int q = qr; q < nq; q += L) {
+        float* const g = base + (int64_t)q * qstride;
+        if (TO_LDS) {
+            const f4v v = *(const f4v*)g;
+#pragma unroll
+            for (int k = 0; k < 4; ++k)
+                if (4 * q + k < n) lds[slot(4 * q + k) + sel * L] = v[k];
+        } else if (4 * q + 3 < n) {
+            f4v v;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) v[k] = lds[slot(4 * q + k) + sel * L];
+            *(f4v*)g = v;
+        } else {
+#pragma unroll
+            for (int k = 0; k < 4; ++k)
+                if (4 * q + k < n) g[k] = lds[slot(4 * q + k) + sel * L];
+        }
+    }
+}
+
+// ============================================ served packed kernel: L lanes / env, 2 cells / op, scalar physics on a wave of its own
 // Walk, LDS image and tile table are wedm_step_packed's (two virtual chunks per lane in float2 registers; the table built for
 // 2 L chunks; one-change tiles and 1- / 2-cell tails with EXTRA).  A wave with a frozen (terminated) environment keeps the
 // tile code, its lanes do not store (wedm_step_packed's FROZEN_OK, always on here).
 // Not here (the launch plan keeps such launches on wedm_step_packed): a trace sample inside the launch, keep_stepping_terminated.
+#ifndef WEDM_SERVED_STAGE_W
+#define WEDM_SERVED_STAGE_W 2  // pairs per stage of the packed walk
+#endif
+#ifndef WEDM_SERVED_DENSE
+#define WEDM_SERVED_DENSE WEDM_PACKED_DENSE  // the quiet line also carries sparks that keep burning or end
+#endif
 #ifndef WEDM_SERVED_WAVES_PER_EU
 #define WEDM_SERVED_WAVES_PER_EU 3
 #endif
-template <int L, bool EXTRA>
-__global__ void __launch_bounds__(320, WEDM_SERVED_WAVES_PER_EU) wedm_step_served(const KArgs k) {
-    constexpr int EPB = 256 / L;
-    static_assert(EPB <= 64, "one lane of the scalar wave per environment of the block");
+template <int L, bool EXTRA, int WW = 3>
+__global__ void __launch_bounds__((WW + 1) * 64, WEDM_SERVED_WAVES_PER_EU) wedm_step_served(const KArgs k) {
+    constexpr int NT = WW * 64;   // walker threads = columns of the LDS image
+    constexpr int EPB = NT / L;   // environments per block
+    static_assert(EPB <= 64 && WW <= 4, "one lane of the scalar wave per environment of the block");
     typedef ServedBox<EPB> Box;
     const ColdRef cold = kernarg_cold();
     extern __shared__ __attribute__((aligned(16))) float lds[];
@@ -103,21 +163,25 @@ __global__ void __launch_bounds__(320, WEDM_SERVED_WAVES_PER_EU) wedm_step_serve
     const int R = 2 * Cv;  // data rows per lane; rows R and R+1 are the halo pair
     const int n = k.hot.n_seg;
     const int64_t stride = cold->s.stride;
-    volatile Box* const box = (volatile Box*)(lds + (size_t)(R + 2) * 256);
+    volatile Box* const box = (volatile Box*)(lds + (size_t)(R + 2) * NT);
     const float spool = k.hot.spool, tref = k.hot.tref, alpha = k.hot.alpha, tdiel = k.hot.tdiel;
-    const bool scalar_wave = tid >= 256;
+    const bool scalar_wave = tid >= NT;
 #ifdef WEDM_STAMPS
-    unsigned long long sv_wait_acc = 0, sv_t0 = 0, sv_t1 = 0, sv_c0 = 0, sv_c1 = 0, sv_spec = 0;
+    unsigned long long sv_wait_acc = 0, sv_t0 = 0, sv_t1 = 0, sv_c0 = 0, sv_c1 = 0, sv_spec = 0, sv_pa = 0, sv_pb = 0, sv_pc = 0, sv_q0 = 0, sv_q1 = 0;
     uint32_t sv_hwid = 0, sv_xcc = 0;
     asm volatile("s_getreg_b32 %0, hwreg(4)\n\ts_getreg_b32 %1, hwreg(20)" : "=s"(sv_hwid), "=s"(sv_xcc));
     asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(sv_t0)::"memory");
 #define WEDM_SV_STAMP_OUT() do { \
         asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(sv_t1)::"memory"); \
         if (k.dbg && (tid & 63) == 0) { \
-            unsigned long long* o = k.dbg + ((size_t)blockIdx.x * 5 + (tid >> 6)) * 8; \
-            o[0] = sv_hwid; o[1] = sv_xcc; o[2] = sv_t0; o[3] = sv_t1; o[4] = sv_wait_acc; o[5] = sv_c1 - sv_c0; o[6] = sv_spec; } } while (0)
+            unsigned long long* o = k.dbg + ((size_t)blockIdx.x * (WW + 1) + (tid >> 6)) * 12; \
+            o[0] = sv_hwid; o[1] = sv_xcc; o[2] = sv_t0; o[3] = sv_t1; o[4] = sv_wait_acc; o[5] = sv_c1 - sv_c0; o[6] = sv_spec; o[7] = sv_pa; o[8] = sv_pb; o[9] = sv_pc; } } while (0)
+#define WEDM_SV_PHASE(acc) do { __builtin_amdgcn_sched_barrier(0); WEDM_SV_CLOCK(sv_q1); acc += sv_q1 - sv_q0; sv_q0 = sv_q1; __builtin_amdgcn_sched_barrier(0); } while (0)
+#define WEDM_SV_PHASE_START() do { __builtin_amdgcn_sched_barrier(0); WEDM_SV_CLOCK(sv_q0); __builtin_amdgcn_sched_barrier(0); } while (0)
 #else
 #define WEDM_SV_STAMP_OUT() do { } while (0)
+#define WEDM_SV_PHASE(acc) do { } while (0)
+#define WEDM_SV_PHASE_START() do { } while (0)
 #endif
 
     if (tid == 0) { box->cf_seq = 0u; box->tm_seq[0] = 0u; box->tm_seq[1] = 0u; box->tm_seq[2] = 0u; box->tm_seq[3] = 0u; }
@@ -131,11 +195,11 @@ __global__ void __launch_bounds__(320, WEDM_SERVED_WAVES_PER_EU) wedm_step_serve
         __builtin_amdgcn_s_setprio(3);  // its chain is on the critical path of four walker waves
 #endif
         Hot hv = k.hot;
-#ifndef WEDM_SV_NO_PIN
+#ifdef WEDM_SV_PIN  // (no pinned constants: the scalar wave's 168 registers hold an Env and a prelude's temporaries, nothing to spare)
         pin_mechanics_in_vgprs(hv);
         pin_quiet_in_vgprs(hv);
 #endif
-        const int sl = tid - 256;
+        const int sl = tid - NT;
         const int64_t e = e0 + (sl < EPB ? sl : 0);
         const bool live = sl < EPB && e0 + sl < k.num_envs;
         Env s;
@@ -173,11 +237,34 @@ __global__ void __launch_bounds__(320, WEDM_SERVED_WAVES_PER_EU) wedm_step_serve
                 if (sl == 0) box->cf_seq = (uint32_t)it + 1u;
                 break;
             }
+            WEDM_SV_PHASE_START();
             Coef cf{0.0f, 0.0f, 0, -1};
             QuietTry qt;
-            const bool was_quiet = quiet_prelude_t<WEDM_PACKED_DENSE>(hv, cold, g, e, gid, s, qt, cf);
+#ifdef WEDM_SV_STUB_SCALAR  // (instruction-count probe: the scalar wave publishes a quiet step and computes nothing; results are garbage)
+            const bool was_quiet = true;
+            qt.have_w = false;
+#else
+            const bool was_quiet = quiet_prelude_t<WEDM_SERVED_DENSE>(hv, cold, g, e, gid, s, qt, cf);
+#endif
 #ifndef WEDM_SV_NO_GENERAL
-            if (!was_quiet && !s.done) cf = scalar_prelude(hv, cold, g, e, gid, s, ps, true, qt);
+#ifndef WEDM_SV_CALL_GENERAL
+            if (__builtin_expect(!was_quiet && !s.done, 0)) cf = scalar_prelude(hv, cold, g, e, gid, s, ps, true, qt);
+#else
+            // (measured: 32 768 x 400 9.8 ms with the call against 8.3 ms inlined -- the values that live across the call are
+            // spilled around it in the hot loop too; kept as a switch)
+            if (__builtin_expect(!was_quiet && !s.done, 0)) {
+                // through COPIES: an object whose address goes to a call lives in memory for its whole life -- handing `s` itself
+                // over put every access of the hot loop into scratch (no "spill" in the statistics, 10 000 cycles per step)
+                Env s_mem = s;
+                Persist ps_mem = ps;
+                QuietTry qt_mem = qt;
+                Coef cf_mem{0.0f, 0.0f, 0, -1};
+                sv_general_prelude((uint64_t)(const WEDM_AS4 char*)__builtin_amdgcn_kernarg_segment_ptr(), e, gid, s_mem, ps_mem, qt_mem, cf_mem);
+                s = s_mem;
+                ps = ps_mem;
+                cf = cf_mem;
+            }
+#endif
 #endif
             const float jf_eff = (cf.joule_on && !s.done) ? cf.jf : 0.0f;
             if (sl < EPB) {
@@ -187,6 +274,7 @@ __global__ void __launch_bounds__(320, WEDM_SERVED_WAVES_PER_EU) wedm_step_serve
             }
             asm volatile("" ::: "memory");
             if (sl == 0) box->cf_seq = (uint32_t)it + 1u;
+            WEDM_SV_PHASE(sv_pa);  // prelude and publication
             // ---- the previous step's temperature monitor, now that its maximum is there (the walkers had a prelude's time)
             if (pending) {
                 { WEDM_SV_WAIT_BEGIN(); sv_wait_lanes(&box->tm_seq[(sl < EPB ? sl * L : 0) >> 6], (uint32_t)it); WEDM_SV_WAIT_END(); }
@@ -200,6 +288,7 @@ __global__ void __launch_bounds__(320, WEDM_SERVED_WAVES_PER_EU) wedm_step_serve
                 pending = false;
                 have_m = true;
             }
+            WEDM_SV_PHASE(sv_pb);  // wait for and apply the previous step's monitor
             // ---- can this step break the wire?
             const float Mb = fmaxf(M, tdiel);
             const float conv_max = fmaxf(ps.conv_base, ps.conv_zone);
@@ -217,10 +306,12 @@ __global__ void __launch_bounds__(320, WEDM_SERVED_WAVES_PER_EU) wedm_step_serve
 #ifdef WEDM_STAMPS
                 ++sv_spec;
 #endif
+#ifndef WEDM_SV_STUB_SCALAR
                 if (!s.done) {
                     epilogue_voltage_sum(s);
                     epilogue_motion(hv, s);
                 }
+#endif
                 pending = true;
             } else {
                 { WEDM_SV_WAIT_BEGIN(); sv_wait_lanes(&box->tm_seq[(sl < EPB ? sl * L : 0) >> 6], (uint32_t)it + 1u); WEDM_SV_WAIT_END(); }
@@ -232,6 +323,7 @@ __global__ void __launch_bounds__(320, WEDM_SERVED_WAVES_PER_EU) wedm_step_serve
                 }
                 have_m = true;
             }
+            WEDM_SV_PHASE(sv_pc);  // the proof and the rest of the epilogue
         }
         if (pending) {  // the last step's monitor
             sv_wait_lanes(&box->tm_seq[(sl < EPB ? sl * L : 0) >> 6], (uint32_t)it);
@@ -268,8 +360,8 @@ __global__ void __launch_bounds__(320, WEDM_SERVED_WAVES_PER_EU) wedm_step_serve
     const bool live = e < k.num_envs;
     const int wave = tid >> 6;
     // ---- stage: wire cell i -> virtual chunk vc = i / Cv, cell r = i % Cv -> lane vc/2, row 2r + vc%2
-    const auto wire_slot = [Cv](int i) { const int vc = i / Cv; return (2 * (i - vc * Cv) + (vc & 1)) * 256 + (vc >> 1); };
-    copy_wire<L, true>(cold->s.T, stride, e0, k.num_envs, n, tid, lds, wire_slot);
+    const auto wire_slot = [Cv](int i) { const int vc = i / Cv; return (2 * (i - vc * Cv) + (vc & 1)) * NT + (vc >> 1); };
+    copy_wire_nt<L, NT, true>(cold->s.T, stride, e0, k.num_envs, n, tid, lds, wire_slot);
     Geom g;
     load_geom(k.hot, cold, 0, g);  // uniform geometry
     float* col = lds + tid;
@@ -277,7 +369,7 @@ __global__ void __launch_bounds__(320, WEDM_SERVED_WAVES_PER_EU) wedm_step_serve
     const bool reinit = live && WEDM_AUTORESET(cold) && cold->s.i8[(int64_t)WEDM_B_DONE * stride + e] != 0;
     __syncthreads();  // (A)
     if (reinit) {
-        for (int row = 0; row < R; ++row) col[row * 256] = spool;
+        for (int row = 0; row < R; ++row) col[row * NT] = spool;
     }
     Persist ps{box->adv[el], 0.0f, 0.0f, 0};
 
@@ -329,6 +421,7 @@ __global__ void __launch_bounds__(320, WEDM_SERVED_WAVES_PER_EU) wedm_step_serve
     for (int it = 0; it < k.n_substeps; ++it) {
         const int slot = it & 1;
         { WEDM_SV_WAIT_BEGIN(); sv_wait(&box->cf_seq, (uint32_t)it + 1u); WEDM_SV_WAIT_END(); }
+        WEDM_SV_PHASE_START();
         const int32_t fl = box->flags[slot][el];
         if (fl & SV_STOP) break;  // (block-wide: every lane reads it)
         Coef cf{box->jf[slot][el], box->q[slot][el], (fl & SV_JOULE) ? 1 : 0, box->pidx[slot][el]};
@@ -338,12 +431,12 @@ __global__ void __launch_bounds__(320, WEDM_SERVED_WAVES_PER_EU) wedm_step_serve
         const bool done = !live || (fl & SV_DONE);
 
         // ---- halos (OLD values, read before any store of this step)
-        const float halo_l = (c > 0) ? col[(R - 1) * 256 - 1] : spool;  // left neighbour lane's B[Cv-1]
+        const float halo_l = (c > 0) ? col[(R - 1) * NT - 1] : spool;  // left neighbour lane's B[Cv-1]
         const float halo_r = (c < L - 1) ? col[1] : 0.0f;               // right neighbour lane's A[0]
-        const float a_last = col[(R - 2) * 256];                        // own A[Cv-1]: left halo of B
-        const float b_first = col[256];                                 // own B[0]: right halo of A
-        col[R * 256] = b_first;
-        col[(R + 1) * 256] = halo_r;
+        const float a_last = col[(R - 2) * NT];                        // own A[Cv-1]: left halo of B
+        const float b_first = col[NT];                                  // own B[0]: right halo of A
+        col[R * NT] = b_first;
+        col[(R + 1) * NT] = halo_r;
 
         const bool frozen_wave = __any(done);
         const bool all_slow = __any(cf.q < 0.0f);  // a negative plasma heat: every cell on the predicated path (same results)
@@ -354,11 +447,11 @@ __global__ void __launch_bounds__(320, WEDM_SERVED_WAVES_PER_EU) wedm_step_serve
         // full predicated formula for one owned cell, from OLD values (patched cells)
         auto patch_value = [&](int i, int own) -> float {
             const int v = own - 1, r = i - (v ? baseB : baseA), row = 2 * r + v;
-            const float left = col[(r > 0 ? row - 2 : row) * 256];
+            const float left = col[(r > 0 ? row - 2 : row) * NT];
             float tm = r > 0 ? left : (v ? a_last : halo_l);
             if (i == 1) tm = spool;
-            const float tp = col[(row + 2) * 256];
-            return stencil_cell(i, n, tm, col[row * 256], tp, g, cf, ps, tref, alpha, tdiel);
+            const float tp = col[(row + 2) * NT];
+            return stencil_cell(i, n, tm, col[row * NT], tp, g, cf, ps, tref, alpha, tdiel);
         };
         const int own_pl = (!done && cf.pidx >= 1) ? owner(cf.pidx) : 0;
         float tpl = 0.0f, tlast = 0.0f;
@@ -379,7 +472,7 @@ __global__ void __launch_bounds__(320, WEDM_SERVED_WAVES_PER_EU) wedm_step_serve
 #pragma unroll
                     for (int v = 0; v < 2; ++v) {
                         const uint32_t b = tail_bits >> (4 * (2 * q + v));
-                        tt[2 * q + v] = interior_cell<true>(col[(2 * (r - 1) + v) * 256], col[(2 * r + v) * 256], col[(2 * (r + 1) + v) * 256],
+                        tt[2 * q + v] = interior_cell<true>(col[(2 * (r - 1) + v) * NT], col[(2 * r + v) * NT], col[(2 * (r + 1) + v) * NT],
                                                             g.k, g.tuf, (b & 1u) ? ps.conv_zone : ps.conv_base, tdiel, ps.adv,
                                                             (b & 2u) ? jfl : 0.0f, alpha, tref);
                     }
@@ -390,7 +483,8 @@ __global__ void __launch_bounds__(320, WEDM_SERVED_WAVES_PER_EU) wedm_step_serve
 
         float tmax = spool;
         f2 tm1 = {halo_l, a_last};
-        f2 tc = {col[0], col[256]};
+        f2 tc = {col[0], col[NT]};
+        WEDM_SV_PHASE(sv_pa);  // mailbox, halos, patched cells and tails from old values
         {
             const float jf_lane = (cf.joule_on && !done) ? cf.jf : 0.0f;
             const bool joule_wave = __any(jf_lane != 0.0f);
@@ -401,13 +495,29 @@ __global__ void __launch_bounds__(320, WEDM_SERVED_WAVES_PER_EU) wedm_step_serve
                 for (int u = 0; u < 8; ++u) {
                     int p = r0 + 1 + u;
                     if (decltype(clamp)::value) p = p < Cv ? p : Cv;  // pair Cv is the halo pair; later pairs are never used
-                    dst[u].x = col[(2 * p) * 256];
-                    dst[u].y = col[(2 * p + 1) * 256];
+                    dst[u].x = col[(2 * p) * NT];
+                    dst[u].y = col[(2 * p + 1) * NT];
                 }
             };
             auto store2 = [&](int r, f2 v) {
-                col[(2 * r) * 256] = v.x;
-                col[(2 * r + 1) * 256] = v.y;
+                col[(2 * r) * NT] = v.x;
+                col[(2 * r + 1) * NT] = v.y;
+            };
+            // a tile with one coefficient change at `split`: the pairs' coefficients are selected group by group, right before
+            // the stage-major group that uses them (all eight up front are 32 registers the walker does not have)
+            auto percell_tile = [&](const f2 (&old)[10], f2 (&tn)[8], int split, f2 conv_lo, f2 conv_hi, f2 jfe_lo, f2 jfe_hi) {
+                constexpr int W = WEDM_SERVED_STAGE_W;
+#pragma unroll
+                for (int o = 0; o < 8; o += W) {
+                    f2 cv[8], jv[8];  // (only entries o .. o + W - 1 are set and read)
+#pragma unroll
+                    for (int u = 0; u < W; ++u) {
+                        cv[o + u] = (o + u) < split ? conv_lo : conv_hi;
+                        jv[o + u] = (o + u) < split ? jfe_lo : jfe_hi;
+                    }
+                    if (joule_wave) tile_staged<f2, true, true, W>(old, tn, o, g.k, g.tuf, cv, tdiel, ps.adv, jv, alpha, tref);
+                    else tile_staged<f2, false, true, W>(old, tn, o, g.k, g.tuf, cv, tdiel, ps.adv, jv, alpha, tref);
+                }
             };
             auto tile = [&](auto frozen, int t, f2 (&cur)[8]) {
                 constexpr bool FROZEN = decltype(frozen)::value;  // the copy for a wave with frozen lanes: they do not store
@@ -422,10 +532,15 @@ __global__ void __launch_bounds__(320, WEDM_SERVED_WAVES_PER_EU) wedm_step_serve
 #pragma unroll
                     for (int u = 0; u < 8; ++u) old[u + 2] = cur[u];
                     cv[0] = conv_lo; jv[0] = jfe_lo;
-                    if (joule_wave && __any(jfe_lo.x != 0.0f || jfe_lo.y != 0.0f))
-                        tile8_staged<f2, true, false>(old, tn, g.k, g.tuf, cv, tdiel, ps.adv, jv, alpha, tref);
-                    else
-                        tile8_staged<f2, false, false>(old, tn, g.k, g.tuf, cv, tdiel, ps.adv, jv, alpha, tref);
+                    if (joule_wave && __any(jfe_lo.x != 0.0f || jfe_lo.y != 0.0f)) {
+#pragma unroll
+                        for (int o = 0; o < 8; o += WEDM_SERVED_STAGE_W)
+                            tile_staged<f2, true, false, WEDM_SERVED_STAGE_W>(old, tn, o, g.k, g.tuf, cv, tdiel, ps.adv, jv, alpha, tref);
+                    } else {
+#pragma unroll
+                        for (int o = 0; o < 8; o += WEDM_SERVED_STAGE_W)
+                            tile_staged<f2, false, false, WEDM_SERVED_STAGE_W>(old, tn, o, g.k, g.tuf, cv, tdiel, ps.adv, jv, alpha, tref);
+                    }
                     tn[0].x = (c == 0 && t == 0) ? spool : tn[0].x;
                     const float last_y = (own_last == 2 && t == t_last) ? spool : tn[7].y;
                     float m0 = fmax_gt(tn[0].x, tn[0].y), m1 = fmax_gt(tn[1].x, tn[1].y);
@@ -447,16 +562,11 @@ __global__ void __launch_bounds__(320, WEDM_SERVED_WAVES_PER_EU) wedm_step_serve
                     const int split = (int)((split_pack[t >> 3] >> ((t & 7) * 4)) & 15u);
                     const f2 conv_hi = {((zhA >> t) & 1u) ? cz : cb, ((zhB >> t) & 1u) ? cz : cb};
                     const f2 jfe_hi = {((jhA >> t) & 1u) ? jf_lane : 0.0f, ((jhB >> t) & 1u) ? jf_lane : 0.0f};
-                    f2 old[10], tn[8], cv[8], jv[8];
+                    f2 old[10], tn[8];
                     old[0] = tm1; old[1] = tc;
 #pragma unroll
-                    for (int u = 0; u < 8; ++u) {
-                        old[u + 2] = cur[u];
-                        cv[u] = u < split ? conv_lo : conv_hi;
-                        jv[u] = u < split ? jfe_lo : jfe_hi;
-                    }
-                    if (joule_wave) tile8_staged<f2, true, true>(old, tn, g.k, g.tuf, cv, tdiel, ps.adv, jv, alpha, tref);
-                    else tile8_staged<f2, false, true>(old, tn, g.k, g.tuf, cv, tdiel, ps.adv, jv, alpha, tref);
+                    for (int u = 0; u < 8; ++u) old[u + 2] = cur[u];
+                    percell_tile(old, tn, split, conv_lo, conv_hi, jfe_lo, jfe_hi);
                     tn[0].x = (c == 0 && t == 0) ? spool : tn[0].x;
                     const float last_y = (own_last == 2 && t == t_last) ? spool : tn[7].y;
                     if (!FROZEN || !done) {
@@ -483,16 +593,11 @@ __global__ void __launch_bounds__(320, WEDM_SERVED_WAVES_PER_EU) wedm_step_serve
                     const f2 jfe_hi = {((jhA >> t) & 1u) ? jf_lane : 0.0f, ((jhB >> t) & 1u) ? jf_lane : 0.0f};
                     const uint32_t imA = (uint32_t)(baseA + r0 - 1), imB = (uint32_t)(baseB + r0 - 1);
                     const uint32_t span = (uint32_t)(n - 3);
-                    f2 old[10], tn[8], cv[8], jv[8];
+                    f2 old[10], tn[8];
                     old[0] = tm1; old[1] = tc;
 #pragma unroll
-                    for (int u = 0; u < 8; ++u) {
-                        old[u + 2] = cur[u];
-                        cv[u] = u < split ? conv_lo : conv_hi;
-                        jv[u] = u < split ? jfe_lo : jfe_hi;
-                    }
-                    if (joule_wave) tile8_staged<f2, true, true>(old, tn, g.k, g.tuf, cv, tdiel, ps.adv, jv, alpha, tref);
-                    else tile8_staged<f2, false, true>(old, tn, g.k, g.tuf, cv, tdiel, ps.adv, jv, alpha, tref);
+                    for (int u = 0; u < 8; ++u) old[u + 2] = cur[u];
+                    percell_tile(old, tn, split, conv_lo, conv_hi, jfe_lo, jfe_hi);
 #pragma unroll
                     for (int u = 0; u < 8; ++u) {
                         if (u < cnt) {
@@ -526,7 +631,7 @@ __global__ void __launch_bounds__(320, WEDM_SERVED_WAVES_PER_EU) wedm_step_serve
                                 x = (i >= 1) ? stencil_cell(i, n, (i == 1) ? spool : m, cc, pp, g, cf, ps, tref, alpha, tdiel) : spool;
                             }
                             if (valid) {
-                                col[(2 * r + v) * 256] = x;
+                                col[(2 * r + v) * NT] = x;
                                 tmax = fmax_gt(tmax, x);
                             }
                         }
@@ -546,6 +651,7 @@ __global__ void __launch_bounds__(320, WEDM_SERVED_WAVES_PER_EU) wedm_step_serve
                 for (int t = 0; t < n_walk; ++t) tile(std::true_type{}, t, bufA);
             }
         }
+        WEDM_SV_PHASE(sv_pb);  // the tiles
         // ---- patches (after every store of the walk): tail cells, then boundary condition, last cell, plasma cell
         if (use_tail && !done) {
 #pragma unroll
@@ -554,7 +660,7 @@ __global__ void __launch_bounds__(320, WEDM_SERVED_WAVES_PER_EU) wedm_step_serve
 #pragma unroll
                     for (int v = 0; v < 2; ++v) {
                         if ((tail_bits >> (4 * (2 * q + v))) & 4u) {  // interior: exists, counts, and is not the wire's last cell
-                            col[(2 * (Cv - tail + q) + v) * 256] = tt[2 * q + v];
+                            col[(2 * (Cv - tail + q) + v) * NT] = tt[2 * q + v];
                             tmax = fmax_gt(tmax, tt[2 * q + v]);
                         }
                     }
@@ -564,12 +670,12 @@ __global__ void __launch_bounds__(320, WEDM_SERVED_WAVES_PER_EU) wedm_step_serve
         if (c == 0 && !done) col[0] = spool;
         if (own_last && !done) {
             const int v = own_last - 1;
-            col[(2 * (n - 1 - (v ? baseB : baseA)) + v) * 256] = tlast;
+            col[(2 * (n - 1 - (v ? baseB : baseA)) + v) * NT] = tlast;
             tmax = fmax_gt(tmax, tlast);
         }
         if (own_pl) {
             const int v = own_pl - 1;
-            col[(2 * (cf.pidx - (v ? baseB : baseA)) + v) * 256] = tpl;
+            col[(2 * (cf.pidx - (v ? baseB : baseA)) + v) * NT] = tpl;
             tmax = fmax_gt(tmax, tpl);
         }
 #pragma unroll
@@ -577,6 +683,7 @@ __global__ void __launch_bounds__(320, WEDM_SERVED_WAVES_PER_EU) wedm_step_serve
         if (c == 0) box->tmax[slot][el] = tmax;
         asm volatile("" ::: "memory");
         if ((tid & 63) == 0) box->tm_seq[wave] = (uint32_t)it + 1u;
+        WEDM_SV_PHASE(sv_pc);  // patches, reduction, publication
     }
 
 #ifdef WEDM_STAMPS
@@ -584,5 +691,5 @@ __global__ void __launch_bounds__(320, WEDM_SERVED_WAVES_PER_EU) wedm_step_serve
 #endif
     WEDM_SV_STAMP_OUT();
     __syncthreads();  // (B)
-    copy_wire<L, false>(cold->s.T, stride, e0, k.num_envs, n, tid, lds, wire_slot);
+    copy_wire_nt<L, NT, false>(cold->s.T, stride, e0, k.num_envs, n, tid, lds, wire_slot);
 }

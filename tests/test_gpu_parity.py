@@ -1168,7 +1168,7 @@ def test_config4_shard_of_rank_7_matches_oracle():
         act = env.make_action(0.1, 80.0, 5, 3.0, 80.0)
         env.step_many(act, 1000)
         env.step_many(act, 1000)
-    assert "wedm_step_packed<8>" in gpu._backend.last_kernel(), gpu._backend.last_kernel()
+    assert "wedm_step_served<8>" in gpu._backend.last_kernel(), gpu._backend.last_kernel()
     check(gpu, cpu, n)
     for env in (gpu, cpu):
         act = env.make_action(0.1, 80.0, 5, 3.0, 80.0)
@@ -1579,11 +1579,11 @@ def test_register_kernel_one_environment_per_lane_matches_oracle(mode, lanes):
         assert int(st.episode.max()) >= 1
     if mode == "autoreset":
         return   # (the oracle seam samples a trace after single microseconds, and every launch boundary is an episode boundary here)
-    # a launch with a trace sample has no register-kernel form: the LDS kernels take it, results unchanged
+    # a launch with a trace sample runs the register kernel's TRACE instantiation (round 4), results unchanged
     traces = [e.bind_trace(["voltage", "wire_max_temperature"], every=1, capacity=64, envs=(0, 64)) for e in (gpu, cpu)]
     for env in (gpu, cpu):
         env.step_many(env.make_action(0.1, 80.0, 17, 3.0, 20.0), 40)
-    assert "wedm_step_regs" not in gpu._backend.last_kernel()
+    assert "wedm_step_regs<" in gpu._backend.last_kernel()
     assert_rings_equal(*traces)
     check(gpu, cpu, n)
 
@@ -1766,3 +1766,26 @@ def test_negative_plasma_heat_every_kernel_matches_oracle(segment_len):
     assert ran >= 8 and int(cpu.state.spark_count.sum()) > 5 * n
     T = cpu.state.wire_temperature
     assert float(torch.as_tensor(T[:, :]).min()) < 293.0      # cells cooled below the spool temperature by the negative heat
+
+
+# ------------------------------------------------------------------ the automatic launch plan
+PLAN_POINTS = [(4096, 128), (16384, 128), (20480, 128), (32768, 128), (65536, 128), (4096, 200), (16384, 200), (8192, 256),
+               (32768, 256), (2048, 400), (4096, 400), (8192, 400), (16384, 400), (32768, 400)]
+
+
+@pytest.mark.parametrize("n,n_seg", PLAN_POINTS)
+def test_automatic_plan_is_within_reach_of_the_best_forced_kernel(n, n_seg):
+    """`wedm_step`'s automatic kernel choice against every forced variant that accepts the shape (tools/plan_sweep.py;
+    the whole grid is recorded in profiles/r4/plan_sweep.txt): the plan's thresholds were fitted on single boxes, and a
+    cliff between two of them -- 16 384 / 20 480 x 128, 4 096 / 8 192 x 400 -- would otherwise go unnoticed.  Median of
+    three fused launches per kernel; 7 % of slack (5 % asked + launch-to-launch noise of a 2-ms kernel)."""
+    import sys
+
+    from pathlib import Path
+
+    sys.path.insert(0, str(Path(__file__).resolve().parents[1] / "tools"))
+    import plan_sweep
+
+    r = plan_sweep.sweep_point(n, n_seg)
+    (ams, aname), (bms, bname, bkey) = r["auto"], r["best"]
+    assert ams <= 1.07 * bms, f"{n} x {n_seg}: auto {aname} {ams:.3f} ms, forced {bname} {bkey} {bms:.3f} ms"

@@ -20,8 +20,9 @@ if len(sys.argv) > 3:
     env.state.workpiece_position = 10.0 + float(sys.argv[3])
     env.state.target_position = 5000.0
 act = env.make_action(0.1, 80.0, 5, 3.0, 80.0)
-nblk = (n + 256 // lanes - 1) // (256 // lanes)
-buf = torch.zeros(nblk * 5 * 8, dtype=torch.int64, device="cuda")
+WW = 3  # walker waves per block (wedm_served.h)
+nblk = (n + WW * 64 // lanes - 1) // (WW * 64 // lanes)
+buf = torch.zeros(nblk * (WW + 1) * 12, dtype=torch.int64, device="cuda")
 L = env._backend._L
 L.wedm_debug_set_stamp_buffer.argtypes = [C.c_void_p, C.c_void_p]
 L.wedm_debug_set_stamp_buffer(env._backend._ctx, C.c_void_p(buf.data_ptr()))
@@ -29,7 +30,7 @@ env.step_many(act, 1000)
 buf.zero_()
 env.step_many(act, 1000)
 torch.cuda.synchronize()
-r = buf.cpu().numpy().reshape(nblk, 5, 8)
+r = buf.cpu().numpy().reshape(nblk, WW + 1, 12)
 hw, xcc = r[:, :, 0], r[:, :, 1] & 0xF
 cu = ((xcc << 16) | (((hw >> 13) & 7) << 8) | (((hw >> 12) & 1) << 4) | ((hw >> 8) & 0xF))[:, 0]
 simd = (hw >> 4) & 3
@@ -47,8 +48,11 @@ for c in set(cu.tolist()):
         best = max(best, cur)
     over.append(best)
 print("blocks resident together per CU: " + ", ".join(f"{k}: {over.count(k)} CUs" for k in sorted(set(over))))
-print("SIMD of the five waves of block 0:", simd[0].tolist(), " of block 1:", simd[1].tolist() if nblk > 1 else "-")
-for name, sel in (("walker", slice(0, 4)), ("scalar", slice(4, 5))):
+print("SIMD of the waves of block 0:", simd[0].tolist(), " of block 1:", simd[1].tolist() if nblk > 1 else "-")
+for name, sel in (("walker", slice(0, WW)), ("scalar", slice(WW, WW + 1))):
     wait, tot = r[:, sel, 4].astype(np.float64), r[:, sel, 5].astype(np.float64)
     print(f"{name} waves: loop {tot.mean() / 1000:.0f} cycles per step, of which spinning {wait.mean() / 1000:.0f} ({100 * wait.sum() / tot.sum():.0f} %)")
-print(f"steps the scalar wave ran ahead: {r[:, 4, 6].mean():.0f} of 1000")
+w, sc = r[:, :WW, 7:10].astype(np.float64).mean(axis=(0, 1)) / 1000, r[:, WW, 7:10].astype(np.float64).mean(axis=0) / 1000
+print(f"walker phases, cycles per step: mailbox + halos + patched cells from old values {w[0]:.0f}, tiles {w[1]:.0f}, patches + reduction + publication {w[2]:.0f}")
+print(f"scalar phases, cycles per step: prelude + publication {sc[0]:.0f}, previous monitor (incl. its wait) {sc[1]:.0f}, proof + rest of the epilogue {sc[2]:.0f}")
+print(f"steps the scalar wave ran ahead: {r[:, WW, 6].mean():.0f} of 1000")
