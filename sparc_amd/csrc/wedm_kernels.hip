@@ -3530,7 +3530,11 @@ static int32_t plan_launch(wedm_ctx* ctx, bool single, bool tr, bool frozen_ok, 
         const long blocks = (ctx->num_envs + (192 / L) - 1) / (192 / L);
         const long b = (blocks + 255) / 256;
         static const double f[4] = {0.0, 1.0, 1.49, 1.80};
-        const double c = 1300.0 + 950.0 * eff_tiles(ctx->walk_C[ti]);
+        // (a partial tile of 3 ... 7 cells runs the boundary-tile code for every lane: two tiles' worth -- 16 384 x 200 over 8 lanes,
+        // chunks of 13 cells: 5.3 ms against 3.4 ms over 4 lanes)
+        const int Cv = ctx->walk_C[ti], rest = Cv & 7;
+        const double tiles = eff_tiles(Cv) + ((rest >= 3 || (rest && Cv < 8)) ? 1.0 : 0.0);
+        const double c = 1300.0 + 950.0 * tiles;
         return (double)(b / rb) * c * f[rb] + ((b % rb) ? c * f[b % rb] : 0.0);
     };
     const double sv_cost4 = served_cost(4), sv_cost8 = served_cost(8);
@@ -3543,7 +3547,8 @@ static int32_t plan_launch(wedm_ctx* ctx, bool single, bool tr, bool frozen_ok, 
     // the served kernel where its model beats what the choice so far would take (measured over 2 048 ... 131 072 environments x
     // 128 ... 512 segments, profiles/r4/plan_sweep.txt: blocks of 24 / 48 environments, three to a CU, fill the chip where
     // blocks of 32 ... 128 leave a ragged second round, and a sixth fewer instructions)
-    if (!single && !tr && served_ok && ctx->lanes == 0 && (variant == 0 || (variant == 7 && ctx->variant == 0))) {
+    if (!single && !tr && served_ok && ctx->lanes == 0 && P.n_seg <= 512 /* the range the model was fitted on */ &&
+        (variant == 0 || (variant == 7 && ctx->variant == 0))) {
         const double sv = std::min(sv_cost4, sv_cost8);
         double other = best_lds_cost;
         if (variant == 7) {  // the two-lane register kernel: 128 environments per block, two blocks per CU (6 050 / 7 800 cycles)

@@ -52,14 +52,43 @@ struct ServedBox {   // lives in LDS behind the wire image
 };
 
 // diagnostic build -DWEDM_STAMPS (tools/stamps_served.py): per wave {HW_ID, XCC_ID, start, end (100 MHz clock all XCDs
-// share), shader-clock cycles spent spinning, shader-clock cycles in the loop, steps speculated}
+// share), shader-clock cycles spent spinning, shader-clock cycles in the loop, steps speculated, three phase sums}
 #ifdef WEDM_STAMPS
+struct SvStamps {
+    unsigned long long wait_acc = 0, t0 = 0, t1 = 0, c0 = 0, c1 = 0, spec = 0, pa = 0, pb = 0, pc = 0, q0 = 0, q1 = 0, w0 = 0;
+    uint32_t hwid = 0, xcc = 0;
+};
 #define WEDM_SV_CLOCK(var) asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(var)::"memory")
-#define WEDM_SV_WAIT_BEGIN() unsigned long long sv_w0_; WEDM_SV_CLOCK(sv_w0_)
-#define WEDM_SV_WAIT_END() do { unsigned long long sv_w1_; WEDM_SV_CLOCK(sv_w1_); sv_wait_acc += sv_w1_ - sv_w0_; } while (0)
+#define WEDM_SV_WAIT_BEGIN() WEDM_SV_CLOCK(svs.w0)
+#define WEDM_SV_WAIT_END() do { unsigned long long sv_w1_; WEDM_SV_CLOCK(sv_w1_); svs.wait_acc += sv_w1_ - svs.w0; } while (0)
+#define WEDM_SV_PHASE(acc) do { __builtin_amdgcn_sched_barrier(0); WEDM_SV_CLOCK(svs.q1); svs.acc += svs.q1 - svs.q0; svs.q0 = svs.q1; __builtin_amdgcn_sched_barrier(0); } while (0)
+#define WEDM_SV_PHASE_START() do { __builtin_amdgcn_sched_barrier(0); WEDM_SV_CLOCK(svs.q0); __builtin_amdgcn_sched_barrier(0); } while (0)
+#define WEDM_SV_LOOP_START() WEDM_SV_CLOCK(svs.c0)
+#define WEDM_SV_LOOP_END() WEDM_SV_CLOCK(svs.c1)
+#define WEDM_SV_COUNT_SPEC() (++svs.spec)
+__device__ __forceinline__ void sv_stamps_begin(SvStamps& svs) {
+    asm volatile("s_getreg_b32 %0, hwreg(4)\n\ts_getreg_b32 %1, hwreg(20)" : "=s"(svs.hwid), "=s"(svs.xcc));
+    asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(svs.t0)::"memory");
+}
+// `row`: this wave's 12 words of the stamp buffer (lane 0 writes), or null
+__device__ __forceinline__ void sv_stamps_out(SvStamps& svs, unsigned long long* row) {
+    asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(svs.t1)::"memory");
+    if (row && (threadIdx.x & 63) == 0) {
+        row[0] = svs.hwid; row[1] = svs.xcc; row[2] = svs.t0; row[3] = svs.t1; row[4] = svs.wait_acc; row[5] = svs.c1 - svs.c0;
+        row[6] = svs.spec; row[7] = svs.pa; row[8] = svs.pb; row[9] = svs.pc;
+    }
+}
 #else
+struct SvStamps { };
 #define WEDM_SV_WAIT_BEGIN() do { } while (0)
 #define WEDM_SV_WAIT_END() do { } while (0)
+#define WEDM_SV_PHASE(acc) do { } while (0)
+#define WEDM_SV_PHASE_START() do { } while (0)
+#define WEDM_SV_LOOP_START() do { } while (0)
+#define WEDM_SV_LOOP_END() do { } while (0)
+#define WEDM_SV_COUNT_SPEC() do { } while (0)
+__device__ __forceinline__ void sv_stamps_begin(SvStamps&) { }
+__device__ __forceinline__ void sv_stamps_out(SvStamps&, unsigned long long*) { }
 #endif
 
 __device__ __forceinline__ void sv_wait(const volatile uint32_t* p, uint32_t want) {
@@ -134,11 +163,6 @@ __device__ __forceinline__ void copy_wire_nt(float* T, int64_t stride, int64_t e
     }
 }
 
-// ============================================ served packed kernel: L lanes / env, 2 cells / op, scalar physics on a wave of its own
-// Walk, LDS image and tile table are wedm_step_packed's (two virtual chunks per lane in float2 registers; the table built for
-// 2 L chunks; one-change tiles and 1- / 2-cell tails with EXTRA).  A wave with a frozen (terminated) environment keeps the
-// tile code, its lanes do not store (wedm_step_packed's FROZEN_OK, always on here).
-// Not here (the launch plan keeps such launches on wedm_step_packed): a trace sample inside the launch, keep_stepping_terminated.
 #ifndef WEDM_SERVED_STAGE_W
 #define WEDM_SERVED_STAGE_W 2  // pairs per stage of the packed walk
 #endif
@@ -148,6 +172,174 @@ __device__ __forceinline__ void copy_wire_nt(float* T, int64_t stride, int64_t e
 #ifndef WEDM_SERVED_WAVES_PER_EU
 #define WEDM_SERVED_WAVES_PER_EU 3
 #endif
+
+// ------------------------------------------------------------------------------------------------ the scalar wave
+// Lane `sl` owns environment e0 + sl of the block (EPB of them); the walker waves hold LPE lanes per environment, so the
+// maxima of environment sl come from walker wave (sl * LPE) / 64.  Runs from the launch's first barrier to its last store.
+template <int EPB, int LPE>
+__device__ __forceinline__ void served_scalar_wave(const KArgs& k, const ColdRef cold, volatile ServedBox<EPB>* box, int64_t e0, int sl,
+                                                   SvStamps& svs, unsigned long long* stamp_row) {
+    const float spool = k.hot.spool, tref = k.hot.tref, alpha = k.hot.alpha, tdiel = k.hot.tdiel;
+#ifdef WEDM_SV_NO_SCALAR  // (register-pressure probes of the two roles: tools/kernel_resources.py -DWEDM_SV_NO_...)
+    return;
+#endif
+#ifndef WEDM_SV_NO_PRIO
+    __builtin_amdgcn_s_setprio(3);  // its chain is on the critical path of four walker waves
+#endif
+    Hot hv = k.hot;
+#ifdef WEDM_SV_PIN  // (no pinned constants: the scalar wave's 168 registers hold an Env and a prelude's temporaries, nothing to spare)
+    pin_mechanics_in_vgprs(hv);
+    pin_quiet_in_vgprs(hv);
+#endif
+    const int64_t e = e0 + (sl < EPB ? sl : 0);
+    const bool live = sl < EPB && e0 + sl < k.num_envs;
+    Env s;
+    Geom g;
+    Persist ps{0.0f, 0.0f, 0.0f, 0};
+    load_geom(k.hot, cold, live ? e : 0, g);
+    if (live) load_env(cold, e, s);
+    else { s.done = WEDM_DEAD_LANE; s.unwind = 0.0; s.h_base = 0.0f; s.h_zone = 0.0f; s.broken = 0; s.ctrl = 0; s.tmax = spool; s.tcrit = 0; }
+    const bool reinit = live && s.done && WEDM_AUTORESET(cold);  // next-step autoreset
+    if (reinit) reinit_env(cold, e, s, true);
+    const bool frozen0 = s.done;
+    if (!s.done) {
+        s.ipk = peak_current(cold, s.mode, e);
+        init_persist(k.hot, cold, e, s, ps);
+    }
+    const uint32_t gid = k.hot.env_id_offset + (uint32_t)e;
+    if (sl < EPB) box->adv[sl] = ps.adv;
+    __syncthreads();  // (A) the walkers have staged the wire; the mailbox is initialised
+
+    // the maximum principle needs non-negative coefficients and the explicit scheme inside its stability limit
+    const float kf = g.k, tuf = g.tuf;
+    bool pending = false;      // the previous step's temperature monitor is still to be applied (wave-uniform)
+    bool pend_live = false;    // ... for this lane
+    bool have_m = false;       // max(T) of the wire as it is now is known (wave-uniform): not in a launch's first step
+    float M = spool;
+    int it = 0;
+    WEDM_SV_LOOP_START();
+    for (; it < k.n_substeps; ++it) {
+        const int slot = it & 1;
+        if (__all(s.done != 0)) {  // every environment of the block is terminated: the walkers stop too
+            if (sl < EPB) box->flags[slot][sl] = SV_STOP | SV_DONE;
+            asm volatile("" ::: "memory");
+            if (sl == 0) box->cf_seq = (uint32_t)it + 1u;
+            break;
+        }
+        WEDM_SV_PHASE_START();
+        Coef cf{0.0f, 0.0f, 0, -1};
+        QuietTry qt;
+#ifdef WEDM_SV_STUB_SCALAR  // (instruction-count probe: the scalar wave publishes a quiet step and computes nothing; results are garbage)
+        const bool was_quiet = true;
+        qt.have_w = false;
+#else
+        const bool was_quiet = quiet_prelude_t<WEDM_SERVED_DENSE>(hv, cold, g, e, gid, s, qt, cf);
+#endif
+#ifndef WEDM_SV_NO_GENERAL
+#ifndef WEDM_SV_CALL_GENERAL
+        if (__builtin_expect(!was_quiet && !s.done, 0)) cf = scalar_prelude(hv, cold, g, e, gid, s, ps, true, qt);
+#else
+        // (measured: 32 768 x 400 9.8 ms with the call against 8.3 ms inlined -- the values that live across the call are
+        // spilled around it in the hot loop too; kept as a switch)
+        if (__builtin_expect(!was_quiet && !s.done, 0)) {
+            // through COPIES: an object whose address goes to a call lives in memory for its whole life -- handing `s` itself
+            // over put every access of the hot loop into scratch (no "spill" in the statistics, 10 000 cycles per step)
+            Env s_mem = s;
+            Persist ps_mem = ps;
+            QuietTry qt_mem = qt;
+            Coef cf_mem{0.0f, 0.0f, 0, -1};
+            sv_general_prelude((uint64_t)(const WEDM_AS4 char*)__builtin_amdgcn_kernarg_segment_ptr(), e, gid, s_mem, ps_mem, qt_mem, cf_mem);
+            s = s_mem;
+            ps = ps_mem;
+            cf = cf_mem;
+        }
+#endif
+#endif
+        const float jf_eff = (cf.joule_on && !s.done) ? cf.jf : 0.0f;
+        if (sl < EPB) {
+            box->jf[slot][sl] = cf.jf; box->q[slot][sl] = cf.q; box->pidx[slot][sl] = cf.pidx;
+            box->conv_base[slot][sl] = ps.conv_base; box->conv_zone[slot][sl] = ps.conv_zone;
+            box->flags[slot][sl] = (cf.joule_on ? SV_JOULE : 0) | (s.done ? SV_DONE : 0) | (ps.adv_on ? SV_ADV : 0);
+        }
+        asm volatile("" ::: "memory");
+        if (sl == 0) box->cf_seq = (uint32_t)it + 1u;
+        WEDM_SV_PHASE(pa);  // prelude and publication
+        // ---- the previous step's temperature monitor, now that its maximum is there (the walkers had a prelude's time)
+        if (pending) {
+            { WEDM_SV_WAIT_BEGIN(); sv_wait_lanes(&box->tm_seq[(sl < EPB ? sl * LPE : 0) >> 6], (uint32_t)it); WEDM_SV_WAIT_END(); }
+            const float tm = sl < EPB ? box->tmax[slot ^ 1][sl] : spool;
+            if (pend_live) {
+                s.tcrit = tm > hv.tcrit ? s.tcrit + 1 : 0;
+                s.tmax = tm;
+                if (tm > hv.tbreak) { s.err = 1; s.broken = 1; s.done = hv.done_value; }  // (proven impossible; loud if it ever is not)
+                M = tm;
+            }
+            pending = false;
+            have_m = true;
+        }
+        WEDM_SV_PHASE(pb);  // wait for and apply the previous step's monitor
+        // ---- can this step break the wire?
+        const float Mb = fmaxf(M, tdiel);
+        const float conv_max = fmaxf(ps.conv_base, ps.conv_zone);
+        const bool scheme_ok = kf >= 0.0f && tuf > 0.0f && alpha >= 0.0f && ps.conv_base >= 0.0f && ps.conv_zone >= 0.0f &&
+                               ps.adv >= 0.0f && jf_eff >= 0.0f && tuf * (2.0f * kf + conv_max + ps.adv) <= 1.0f;
+        const float rise = tuf * (jf_eff * (1.0f + alpha * (Mb - tref)) + fmaxf(cf.q, 0.0f));
+        const bool safe = s.done || (scheme_ok && !s.ctrl && Mb + rise + 1.0f < hv.tbreak);  // (a NaN anywhere: not safe)
+#ifdef WEDM_SV_NO_SPEC  // (ablation: never ahead -- every step waits for its maximum, as an unserved kernel does)
+        if (false) {
+#else
+        if (have_m && __all(safe)) {
+#endif
+            // proven: no lane's wire breaks in this step -> the rest of the epilogue now, the monitor when the maximum arrives
+            pend_live = !s.done;
+            WEDM_SV_COUNT_SPEC();
+#ifndef WEDM_SV_STUB_SCALAR
+            if (!s.done) {
+                epilogue_voltage_sum(s);
+                epilogue_motion(hv, s);
+            }
+#endif
+            pending = true;
+        } else {
+            { WEDM_SV_WAIT_BEGIN(); sv_wait_lanes(&box->tm_seq[(sl < EPB ? sl * LPE : 0) >> 6], (uint32_t)it + 1u); WEDM_SV_WAIT_END(); }
+            const float tm = sl < EPB ? box->tmax[slot][sl] : spool;
+            if (!s.done) {
+                scalar_epilogue(hv, s, tm);
+                if (s.ctrl) control_step_outputs(cold, e, s, true);
+                M = tm;
+            }
+            have_m = true;
+        }
+        WEDM_SV_PHASE(pc);  // the proof and the rest of the epilogue
+    }
+    if (pending) {  // the last step's monitor
+        sv_wait_lanes(&box->tm_seq[(sl < EPB ? sl * LPE : 0) >> 6], (uint32_t)it);
+        const float tm = sl < EPB ? box->tmax[(it - 1) & 1][sl] : spool;
+        if (pend_live) {
+            s.tcrit = tm > hv.tcrit ? s.tcrit + 1 : 0;
+            s.tmax = tm;
+            if (tm > hv.tbreak) { s.err = 1; s.broken = 1; s.done = hv.done_value; }
+        }
+    }
+    WEDM_SV_LOOP_END();
+    sv_stamps_out(svs, stamp_row);
+    __builtin_amdgcn_s_setprio(0);
+    __syncthreads();  // (B) the walkers' last step is in LDS
+    if (live) {
+        if (WEDM_REWARD_ON(cold)) {
+            if (!frozen0) write_reward(cold, e, s);
+            else cold->s.reward[e] = 0.0f;  // a frozen environment earns nothing (not the previous launch's reward)
+        }
+        store_time_hi(cold, e, s, (uint32_t)k.n_substeps * (uint32_t)k.hot.dt_us);
+        store_env(cold, e, s);
+    }
+}
+
+// ============================================ served packed kernel: L lanes / env, 2 cells / op, scalar physics on a wave of its own
+// Walk, LDS image and tile table are wedm_step_packed's (two virtual chunks per lane in float2 registers; the table built for
+// 2 L chunks; one-change tiles and 1- / 2-cell tails with EXTRA).  A wave with a frozen (terminated) environment keeps the
+// tile code, its lanes do not store (wedm_step_packed's FROZEN_OK, always on here).
+// Not here (the launch plan keeps such launches on wedm_step_packed): a trace sample inside the launch, keep_stepping_terminated.
 template <int L, bool EXTRA, int WW = 3>
 __global__ void __launch_bounds__((WW + 1) * 64, WEDM_SERVED_WAVES_PER_EU) wedm_step_served(const KArgs k) {
     constexpr int NT = WW * 64;   // walker threads = columns of the LDS image
@@ -166,188 +358,14 @@ __global__ void __launch_bounds__((WW + 1) * 64, WEDM_SERVED_WAVES_PER_EU) wedm_
     volatile Box* const box = (volatile Box*)(lds + (size_t)(R + 2) * NT);
     const float spool = k.hot.spool, tref = k.hot.tref, alpha = k.hot.alpha, tdiel = k.hot.tdiel;
     const bool scalar_wave = tid >= NT;
-#ifdef WEDM_STAMPS
-    unsigned long long sv_wait_acc = 0, sv_t0 = 0, sv_t1 = 0, sv_c0 = 0, sv_c1 = 0, sv_spec = 0, sv_pa = 0, sv_pb = 0, sv_pc = 0, sv_q0 = 0, sv_q1 = 0;
-    uint32_t sv_hwid = 0, sv_xcc = 0;
-    asm volatile("s_getreg_b32 %0, hwreg(4)\n\ts_getreg_b32 %1, hwreg(20)" : "=s"(sv_hwid), "=s"(sv_xcc));
-    asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(sv_t0)::"memory");
-#define WEDM_SV_STAMP_OUT() do { \
-        asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(sv_t1)::"memory"); \
-        if (k.dbg && (tid & 63) == 0) { \
-            unsigned long long* o = k.dbg + ((size_t)blockIdx.x * (WW + 1) + (tid >> 6)) * 12; \
-            o[0] = sv_hwid; o[1] = sv_xcc; o[2] = sv_t0; o[3] = sv_t1; o[4] = sv_wait_acc; o[5] = sv_c1 - sv_c0; o[6] = sv_spec; o[7] = sv_pa; o[8] = sv_pb; o[9] = sv_pc; } } while (0)
-#define WEDM_SV_PHASE(acc) do { __builtin_amdgcn_sched_barrier(0); WEDM_SV_CLOCK(sv_q1); acc += sv_q1 - sv_q0; sv_q0 = sv_q1; __builtin_amdgcn_sched_barrier(0); } while (0)
-#define WEDM_SV_PHASE_START() do { __builtin_amdgcn_sched_barrier(0); WEDM_SV_CLOCK(sv_q0); __builtin_amdgcn_sched_barrier(0); } while (0)
-#else
-#define WEDM_SV_STAMP_OUT() do { } while (0)
-#define WEDM_SV_PHASE(acc) do { } while (0)
-#define WEDM_SV_PHASE_START() do { } while (0)
-#endif
+    SvStamps svs;
+    sv_stamps_begin(svs);
+    unsigned long long* const stamp_row = k.dbg ? k.dbg + ((size_t)blockIdx.x * (WW + 1) + (tid >> 6)) * 12 : nullptr;
 
     if (tid == 0) { box->cf_seq = 0u; box->tm_seq[0] = 0u; box->tm_seq[1] = 0u; box->tm_seq[2] = 0u; box->tm_seq[3] = 0u; }
 
     if (scalar_wave) {
-        // ------------------------------------------------------------------------------------------------ the scalar wave
-#ifdef WEDM_SV_NO_SCALAR  // (register-pressure probes of the two roles: tools/kernel_resources.py -DWEDM_SV_NO_...)
-        return;
-#endif
-#ifndef WEDM_SV_NO_PRIO
-        __builtin_amdgcn_s_setprio(3);  // its chain is on the critical path of four walker waves
-#endif
-        Hot hv = k.hot;
-#ifdef WEDM_SV_PIN  // (no pinned constants: the scalar wave's 168 registers hold an Env and a prelude's temporaries, nothing to spare)
-        pin_mechanics_in_vgprs(hv);
-        pin_quiet_in_vgprs(hv);
-#endif
-        const int sl = tid - NT;
-        const int64_t e = e0 + (sl < EPB ? sl : 0);
-        const bool live = sl < EPB && e0 + sl < k.num_envs;
-        Env s;
-        Geom g;
-        Persist ps{0.0f, 0.0f, 0.0f, 0};
-        load_geom(k.hot, cold, live ? e : 0, g);
-        if (live) load_env(cold, e, s);
-        else { s.done = WEDM_DEAD_LANE; s.unwind = 0.0; s.h_base = 0.0f; s.h_zone = 0.0f; s.broken = 0; s.ctrl = 0; s.tmax = spool; s.tcrit = 0; }
-        const bool reinit = live && s.done && WEDM_AUTORESET(cold);  // next-step autoreset
-        if (reinit) reinit_env(cold, e, s, true);
-        const bool frozen0 = s.done;
-        if (!s.done) {
-            s.ipk = peak_current(cold, s.mode, e);
-            init_persist(k.hot, cold, e, s, ps);
-        }
-        const uint32_t gid = k.hot.env_id_offset + (uint32_t)e;
-        if (sl < EPB) box->adv[sl] = ps.adv;
-        __syncthreads();  // (A) the walkers have staged the wire; the mailbox is initialised
-
-        // the maximum principle needs non-negative coefficients and the explicit scheme inside its stability limit
-        const float kf = g.k, tuf = g.tuf;
-        bool pending = false;      // the previous step's temperature monitor is still to be applied (wave-uniform)
-        bool pend_live = false;    // ... for this lane
-        bool have_m = false;       // max(T) of the wire as it is now is known (wave-uniform): not in a launch's first step
-        float M = spool;
-        int it = 0;
-#ifdef WEDM_STAMPS
-        WEDM_SV_CLOCK(sv_c0);
-#endif
-        for (; it < k.n_substeps; ++it) {
-            const int slot = it & 1;
-            if (__all(s.done != 0)) {  // every environment of the block is terminated: the walkers stop too
-                if (sl < EPB) box->flags[slot][sl] = SV_STOP | SV_DONE;
-                asm volatile("" ::: "memory");
-                if (sl == 0) box->cf_seq = (uint32_t)it + 1u;
-                break;
-            }
-            WEDM_SV_PHASE_START();
-            Coef cf{0.0f, 0.0f, 0, -1};
-            QuietTry qt;
-#ifdef WEDM_SV_STUB_SCALAR  // (instruction-count probe: the scalar wave publishes a quiet step and computes nothing; results are garbage)
-            const bool was_quiet = true;
-            qt.have_w = false;
-#else
-            const bool was_quiet = quiet_prelude_t<WEDM_SERVED_DENSE>(hv, cold, g, e, gid, s, qt, cf);
-#endif
-#ifndef WEDM_SV_NO_GENERAL
-#ifndef WEDM_SV_CALL_GENERAL
-            if (__builtin_expect(!was_quiet && !s.done, 0)) cf = scalar_prelude(hv, cold, g, e, gid, s, ps, true, qt);
-#else
-            // (measured: 32 768 x 400 9.8 ms with the call against 8.3 ms inlined -- the values that live across the call are
-            // spilled around it in the hot loop too; kept as a switch)
-            if (__builtin_expect(!was_quiet && !s.done, 0)) {
-                // through COPIES: an object whose address goes to a call lives in memory for its whole life -- handing `s` itself
-                // over put every access of the hot loop into scratch (no "spill" in the statistics, 10 000 cycles per step)
-                Env s_mem = s;
-                Persist ps_mem = ps;
-                QuietTry qt_mem = qt;
-                Coef cf_mem{0.0f, 0.0f, 0, -1};
-                sv_general_prelude((uint64_t)(const WEDM_AS4 char*)__builtin_amdgcn_kernarg_segment_ptr(), e, gid, s_mem, ps_mem, qt_mem, cf_mem);
-                s = s_mem;
-                ps = ps_mem;
-                cf = cf_mem;
-            }
-#endif
-#endif
-            const float jf_eff = (cf.joule_on && !s.done) ? cf.jf : 0.0f;
-            if (sl < EPB) {
-                box->jf[slot][sl] = cf.jf; box->q[slot][sl] = cf.q; box->pidx[slot][sl] = cf.pidx;
-                box->conv_base[slot][sl] = ps.conv_base; box->conv_zone[slot][sl] = ps.conv_zone;
-                box->flags[slot][sl] = (cf.joule_on ? SV_JOULE : 0) | (s.done ? SV_DONE : 0) | (ps.adv_on ? SV_ADV : 0);
-            }
-            asm volatile("" ::: "memory");
-            if (sl == 0) box->cf_seq = (uint32_t)it + 1u;
-            WEDM_SV_PHASE(sv_pa);  // prelude and publication
-            // ---- the previous step's temperature monitor, now that its maximum is there (the walkers had a prelude's time)
-            if (pending) {
-                { WEDM_SV_WAIT_BEGIN(); sv_wait_lanes(&box->tm_seq[(sl < EPB ? sl * L : 0) >> 6], (uint32_t)it); WEDM_SV_WAIT_END(); }
-                const float tm = sl < EPB ? box->tmax[slot ^ 1][sl] : spool;
-                if (pend_live) {
-                    s.tcrit = tm > hv.tcrit ? s.tcrit + 1 : 0;
-                    s.tmax = tm;
-                    if (tm > hv.tbreak) { s.err = 1; s.broken = 1; s.done = hv.done_value; }  // (proven impossible; loud if it ever is not)
-                    M = tm;
-                }
-                pending = false;
-                have_m = true;
-            }
-            WEDM_SV_PHASE(sv_pb);  // wait for and apply the previous step's monitor
-            // ---- can this step break the wire?
-            const float Mb = fmaxf(M, tdiel);
-            const float conv_max = fmaxf(ps.conv_base, ps.conv_zone);
-            const bool scheme_ok = kf >= 0.0f && tuf > 0.0f && alpha >= 0.0f && ps.conv_base >= 0.0f && ps.conv_zone >= 0.0f &&
-                                   ps.adv >= 0.0f && jf_eff >= 0.0f && tuf * (2.0f * kf + conv_max + ps.adv) <= 1.0f;
-            const float rise = tuf * (jf_eff * (1.0f + alpha * (Mb - tref)) + fmaxf(cf.q, 0.0f));
-            const bool safe = s.done || (scheme_ok && !s.ctrl && Mb + rise + 1.0f < hv.tbreak);  // (a NaN anywhere: not safe)
-#ifdef WEDM_SV_NO_SPEC  // (ablation: never ahead -- every step waits for its maximum, as an unserved kernel does)
-            if (false) {
-#else
-            if (have_m && __all(safe)) {
-#endif
-                // proven: no lane's wire breaks in this step -> the rest of the epilogue now, the monitor when the maximum arrives
-                pend_live = !s.done;
-#ifdef WEDM_STAMPS
-                ++sv_spec;
-#endif
-#ifndef WEDM_SV_STUB_SCALAR
-                if (!s.done) {
-                    epilogue_voltage_sum(s);
-                    epilogue_motion(hv, s);
-                }
-#endif
-                pending = true;
-            } else {
-                { WEDM_SV_WAIT_BEGIN(); sv_wait_lanes(&box->tm_seq[(sl < EPB ? sl * L : 0) >> 6], (uint32_t)it + 1u); WEDM_SV_WAIT_END(); }
-                const float tm = sl < EPB ? box->tmax[slot][sl] : spool;
-                if (!s.done) {
-                    scalar_epilogue(hv, s, tm);
-                    if (s.ctrl) control_step_outputs(cold, e, s, true);
-                    M = tm;
-                }
-                have_m = true;
-            }
-            WEDM_SV_PHASE(sv_pc);  // the proof and the rest of the epilogue
-        }
-        if (pending) {  // the last step's monitor
-            sv_wait_lanes(&box->tm_seq[(sl < EPB ? sl * L : 0) >> 6], (uint32_t)it);
-            const float tm = sl < EPB ? box->tmax[(it - 1) & 1][sl] : spool;
-            if (pend_live) {
-                s.tcrit = tm > hv.tcrit ? s.tcrit + 1 : 0;
-                s.tmax = tm;
-                if (tm > hv.tbreak) { s.err = 1; s.broken = 1; s.done = hv.done_value; }
-            }
-        }
-#ifdef WEDM_STAMPS
-        WEDM_SV_CLOCK(sv_c1);
-#endif
-        WEDM_SV_STAMP_OUT();
-        __builtin_amdgcn_s_setprio(0);
-        __syncthreads();  // (B) the walkers' last step is in LDS
-        if (live) {
-            if (WEDM_REWARD_ON(cold)) {
-                if (!frozen0) write_reward(cold, e, s);
-                else cold->s.reward[e] = 0.0f;  // a frozen environment earns nothing (not the previous launch's reward)
-            }
-            store_time_hi(cold, e, s, (uint32_t)k.n_substeps * (uint32_t)k.hot.dt_us);
-            store_env(cold, e, s);
-        }
+        served_scalar_wave<EPB, L>(k, cold, box, e0, tid - NT, svs, stamp_row);
         return;
     }
 
@@ -415,9 +433,7 @@ __global__ void __launch_bounds__((WW + 1) * 64, WEDM_SERVED_WAVES_PER_EU) wedm_
         }
     }
 
-#ifdef WEDM_STAMPS
-    WEDM_SV_CLOCK(sv_c0);
-#endif
+    WEDM_SV_LOOP_START();
     for (int it = 0; it < k.n_substeps; ++it) {
         const int slot = it & 1;
         { WEDM_SV_WAIT_BEGIN(); sv_wait(&box->cf_seq, (uint32_t)it + 1u); WEDM_SV_WAIT_END(); }
@@ -484,7 +500,7 @@ __global__ void __launch_bounds__((WW + 1) * 64, WEDM_SERVED_WAVES_PER_EU) wedm_
         float tmax = spool;
         f2 tm1 = {halo_l, a_last};
         f2 tc = {col[0], col[NT]};
-        WEDM_SV_PHASE(sv_pa);  // mailbox, halos, patched cells and tails from old values
+        WEDM_SV_PHASE(pa);  // mailbox, halos, patched cells and tails from old values
         {
             const float jf_lane = (cf.joule_on && !done) ? cf.jf : 0.0f;
             const bool joule_wave = __any(jf_lane != 0.0f);
@@ -651,7 +667,7 @@ __global__ void __launch_bounds__((WW + 1) * 64, WEDM_SERVED_WAVES_PER_EU) wedm_
                 for (int t = 0; t < n_walk; ++t) tile(std::true_type{}, t, bufA);
             }
         }
-        WEDM_SV_PHASE(sv_pb);  // the tiles
+        WEDM_SV_PHASE(pb);  // the tiles
         // ---- patches (after every store of the walk): tail cells, then boundary condition, last cell, plasma cell
         if (use_tail && !done) {
 #pragma unroll
@@ -683,13 +699,16 @@ __global__ void __launch_bounds__((WW + 1) * 64, WEDM_SERVED_WAVES_PER_EU) wedm_
         if (c == 0) box->tmax[slot][el] = tmax;
         asm volatile("" ::: "memory");
         if ((tid & 63) == 0) box->tm_seq[wave] = (uint32_t)it + 1u;
-        WEDM_SV_PHASE(sv_pc);  // patches, reduction, publication
+        WEDM_SV_PHASE(pc);  // patches, reduction, publication
     }
 
-#ifdef WEDM_STAMPS
-    WEDM_SV_CLOCK(sv_c1);
-#endif
-    WEDM_SV_STAMP_OUT();
+    WEDM_SV_LOOP_END();
+    sv_stamps_out(svs, stamp_row);
     __syncthreads();  // (B)
     copy_wire_nt<L, NT, false>(cold->s.T, stride, e0, k.num_envs, n, tid, lds, wire_slot);
 }
+
+// (A served form of the register kernel -- wedm_step_regs<128, 2>'s walk on two walker waves, the scalar physics of their 64
+// environments on a third, four blocks of three waves per CU -- was written and not kept: the walk with 64 wire registers per
+// lane wants 239 registers and spills 52 at the 168 that three waves per SIMD leave; at 256 registers the chip holds 6 waves per
+// CU instead of today's 8 and the batch needs two rounds.)
