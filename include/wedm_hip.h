@@ -407,7 +407,9 @@ int64_t wedm_trace_samples(wedm_ctx* ctx);
  * with the float64 scalar physics of a block's environments on a FIFTH wave of the block, one lane per environment, one
  * microsecond ahead of the four walking waves where it can prove that the step does not break the wire; coefficients and
  * maxima cross through LDS; uniform geometry, float32 stencil, freeze-on-termination; launches with a trace sample take
- * kernel 4).  All variants produce bit-identical results.  With wedm_params.stencil_mode 1 only 0, 1, 2 and 3 are accepted (3: the tile walk with
+ * kernel 4), 10 = kernel 2's cell-by-cell form by name (since round 4 kernel 2 itself is the packed form -- two virtual
+ * chunks per lane advanced in float2 registers, per-cell coefficients from the lane's own indices -- wherever the stencil is
+ * float32; the cell-by-cell form remains for stencil_mode 1 and for A/B timing).  All variants produce bit-identical results.  With wedm_params.stencil_mode 1 only 0, 1, 2 (= 10) and 3 are accepted (3: the tile walk with
  * per-cell coefficients, no stage-major / packed form).                                          */
 int32_t wedm_set_kernel(wedm_ctx* ctx, int32_t variant);
 

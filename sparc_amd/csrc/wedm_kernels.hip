@@ -3044,6 +3044,7 @@ __global__ void __launch_bounds__(256, WEDM_PACKED_MIN_BLOCKS) wedm_step_packed(
 
 
 #include "wedm_served.h"
+#include "wedm_lanes2.h"
 
 // ------------------------------------------------------------ translation-unit parts (build time only)
 // The packed and fused kernels exist in 32 and 40 instantiations and take hipcc two minutes in one translation unit.
@@ -3065,6 +3066,9 @@ __global__ void __launch_bounds__(256, WEDM_PACKED_MIN_BLOCKS) wedm_step_packed(
 #define WEDM_EXT_FUSED(L, a, b, c) extern template __global__ void wedm_step_fused<L, a, b, c>(const KArgs);
 // the served kernels (wedm_served.h): <L, EXTRA>
 #define WEDM_SERVED_LIST(X) X(4, false) X(4, true) X(8, false) X(8, true)
+#define WEDM_LANES_PK_LIST(X) X(1, false) X(1, true) X(2, false) X(2, true) X(4, false) X(4, true) X(8, false) X(8, true) X(16, false) X(16, true)
+#define WEDM_INST_LANES_PK(L, tr) template __global__ void wedm_step_lanes_pk<L, tr>(const KArgs);
+#define WEDM_EXT_LANES_PK(L, tr) extern template __global__ void wedm_step_lanes_pk<L, tr>(const KArgs);
 #define WEDM_INST_SERVED(L, ex) template __global__ void wedm_step_served<L, ex>(const KArgs);
 #define WEDM_EXT_SERVED(L, ex) extern template __global__ void wedm_step_served<L, ex>(const KArgs);
 #if defined(WEDM_PART) && WEDM_PART == 1
@@ -3074,12 +3078,14 @@ WEDM_FUSED_LIST(WEDM_INST_FUSED)
 WEDM_FUSED_F64_LIST(WEDM_INST_FUSED_F64)
 #elif defined(WEDM_PART) && WEDM_PART == 3
 WEDM_SERVED_LIST(WEDM_INST_SERVED)
+WEDM_LANES_PK_LIST(WEDM_INST_LANES_PK)
 #else
 #if defined(WEDM_PART)
 WEDM_PACKED_LIST(WEDM_EXT_PACKED)
 WEDM_FUSED_LIST(WEDM_EXT_FUSED)
 WEDM_FUSED_F64_LIST(WEDM_EXT_FUSED_F64)
 WEDM_SERVED_LIST(WEDM_EXT_SERVED)
+WEDM_LANES_PK_LIST(WEDM_EXT_LANES_PK)
 #endif
 
 __global__ void __launch_bounds__(256)
@@ -3360,6 +3366,15 @@ template <bool TR, bool FZ> static const void* pick_packed(int L, bool extra) {
     return extra ? pick_packed<TR, FZ, true>(L) : pick_packed<TR, FZ, false>(L);
 }
 
+template <bool TR> static const void* pick_lanes_pk(int L) {
+    switch (L) {
+        case 1: return (const void*)wedm_step_lanes_pk<1, TR>;
+        case 2: return (const void*)wedm_step_lanes_pk<2, TR>;
+        case 4: return (const void*)wedm_step_lanes_pk<4, TR>;
+        case 8: return (const void*)wedm_step_lanes_pk<8, TR>;
+        default: return (const void*)wedm_step_lanes_pk<16, TR>;
+    }
+}
 static const void* pick_served(int L, bool extra) {
     switch (L) {
         case 4: return extra ? (const void*)wedm_step_served<4, true> : (const void*)wedm_step_served<4, false>;
@@ -3454,6 +3469,20 @@ static int32_t plan_launch(wedm_ctx* ctx, bool single, bool tr, bool frozen_ok, 
         }
     }
     const bool lanes_ok = glanes > 0;
+    // ... and its packed form (wedm_step_lanes_pk, float32 stencil): two virtual chunks of ceil(n_seg_max / 2L) cells per lane
+    int pklanes = 0;
+    {
+        const int Ls[5] = {1, 2, 4, 8, 16};
+        for (int i = 0; i < 5; ++i) {
+            const size_t b = (2 * (size_t)((ctx->n_seg_max + 2 * Ls[i] - 1) / (2 * Ls[i])) + 2) * 1024;
+            if (b > (size_t)ctx->lds_limit) continue;
+            if (ctx->lanes) { if (Ls[i] == ctx->lanes) pklanes = Ls[i]; continue; }
+            pklanes = Ls[i];
+            const long waves = (long)((ctx->num_envs + (256 / Ls[i]) - 1) / (256 / Ls[i])) * 4;
+            if (waves >= 2048) break;
+        }
+    }
+    const bool lanes_pk_ok = pklanes > 0;
     // kernel 6 (stream, single microseconds, uniform geometry): the caller's lane count, else -- among the L whose chunk
     // has at most 64 cells (the registers a lane holds its chunk in) -- the largest one whose blocks are all resident at
     // once (2 048 waves): a launch of one microsecond is one dependent chain per wave, and a shorter chunk is a shorter
@@ -3487,10 +3516,13 @@ static int32_t plan_launch(wedm_ctx* ctx, bool single, bool tr, bool frozen_ok, 
     if (f64) {
         // Numba's typing of the stencil: the fused tile walk (uniform geometry), the predicated LDS kernel (any geometry),
         // or in place in global memory; no packed form, no single-microsecond kernels
-        if (variant != 0 && variant != 1 && variant != 2 && variant != 3)
-            return fail(ctx, WEDM_ERR_UNSUPPORTED, "wedm_step: stencil_mode 1 (float64 stencil expressions) runs on kernels 1, 2 and 3 only");
+        if (variant != 0 && variant != 1 && variant != 2 && variant != 3 && variant != 10)
+            return fail(ctx, WEDM_ERR_UNSUPPORTED, "wedm_step: stencil_mode 1 (float64 stencil expressions) runs on kernels 1, 2 (10) and 3 only");
         if (variant == 0) variant = (!single && fused_ok) ? 3 : (lanes_ok ? 2 : 1);
     }
+    // kernel 2 is the packed form where it applies (float32 stencil, no injected variates); kernel 10 names the cell-by-cell
+    // form explicitly (A/B timing, tests), which also serves stencil_mode 1
+    const bool use_pk = !f64 && !ctx->replay && lanes_pk_ok;
     // kernel 8 (wide register kernel): 4, 8 or 16 lanes per environment (the fewest that hold the wire), 32 cells each in
     // registers; uniform geometry, float32 stencil, at most 512 segments.  Chosen by itself for a batch
     // that one round of blocks covers at one wave per
@@ -3564,18 +3596,18 @@ static int32_t plan_launch(wedm_ctx* ctx, bool single, bool tr, bool frozen_ok, 
         if (single) variant = (stream_ok && stream_auto) ? 6 : 5;
         else if (packed_ok && (ctx->auto_prefers_packed || !fused_ok)) variant = 4;
         else if (fused_ok) variant = 3;
-        else variant = lanes_ok ? 2 : 1;
+        else variant = (lanes_ok || use_pk) ? 2 : 1;
     }
     if (variant == 9 && !served_ok)
         return fail(ctx, WEDM_ERR_UNSUPPORTED, "wedm_step: served kernel needs uniform geometry, the float32 stencil, lanes 4 or 8, two chunks that fit in LDS and freeze_terminated");
-    if (variant == 9 && tr) variant = packed_ok ? 4 : fused_ok ? 3 : lanes_ok ? 2 : 1;
+    if (variant == 9 && tr) variant = packed_ok ? 4 : fused_ok ? 3 : (lanes_ok || use_pk) ? 2 : 1;
     if (variant == 7 && !regs_ok)
         return fail(ctx, WEDM_ERR_UNSUPPORTED, "wedm_step: register kernel needs uniform geometry, at most 128 segments and the float32 stencil");
     if (variant == 3 && !fused_ok)
         return fail(ctx, WEDM_ERR_UNSUPPORTED, "wedm_step: fused kernel needs uniform geometry and a chunk that fits in LDS");
     if (variant == 4 && !packed_ok)
         return fail(ctx, WEDM_ERR_UNSUPPORTED, "wedm_step: packed kernel needs uniform geometry, lanes in {1,2,4,8} and two chunks that fit in LDS");
-    if (variant == 2 && !lanes_ok)
+    if ((variant == 2 && !use_pk && !lanes_ok) || (variant == 10 && !lanes_ok))
         return fail(ctx, WEDM_ERR_UNSUPPORTED, "wedm_step: no lane count puts a chunk of the wire in LDS");
     if (variant == 6 && !stream_ok)
         return fail(ctx, WEDM_ERR_UNSUPPORTED, "wedm_step: stream kernel needs uniform geometry and lanes in {1,2,4,8,16} with a chunk of at most 104 cells");
@@ -3621,7 +3653,12 @@ static int32_t plan_launch(wedm_ctx* ctx, bool single, bool tr, bool frozen_ok, 
            : ctx->walk4_C[sli] <= 64 ? (tr ? pick_stream<true, 64>(slanes) : pick_stream<false, 64>(slanes))
                                      : (tr ? pick_stream<true, 104>(slanes) : pick_stream<false, 104>(slanes));
         std::snprintf(out.name, sizeof(out.name), "wedm_step_stream<%d><<<%d,256,%zuB>>>", slanes, grid, fl);
-    } else if (variant == 2) {
+    } else if (variant == 2 && use_pk) {
+        grid = (ctx->num_envs + 256 / pklanes - 1) / (256 / pklanes);
+        fl = (2 * (size_t)((ctx->n_seg_max + 2 * pklanes - 1) / (2 * pklanes)) + 2) * 1024;
+        fn = tr ? pick_lanes_pk<true>(pklanes) : pick_lanes_pk<false>(pklanes);
+        std::snprintf(out.name, sizeof(out.name), "wedm_step_lanes_pk<%d><<<%d,256,%zuB>>>", pklanes, grid, fl);
+    } else if (variant == 2 || variant == 10) {
         grid = (ctx->num_envs + 256 / glanes - 1) / (256 / glanes);
         fl = (size_t)((ctx->n_seg_max + glanes - 1) / glanes) * 1024;
         fn = f64 ? (tr ? pick_lanes<true, true>(glanes) : pick_lanes<false, true>(glanes))
@@ -3884,7 +3921,7 @@ int32_t wedm_bind_rng_replay(wedm_ctx* ctx, const double* table, int64_t n_steps
 
 int32_t wedm_set_kernel(wedm_ctx* ctx, int32_t variant) {
     if (!ctx) return WEDM_ERR_BAD_ARG;
-    if (variant < 0 || variant > 9) return fail(ctx, WEDM_ERR_BAD_ARG, "wedm_set_kernel: variant must be 0..9");
+    if (variant < 0 || variant > 10) return fail(ctx, WEDM_ERR_BAD_ARG, "wedm_set_kernel: variant must be 0..10");
     ctx->variant = variant;
     ctx->invalidate_plans();
     return WEDM_OK;

@@ -130,7 +130,8 @@ def test_device_math_primitives_match_cpu_bit_for_bit(orc, kind):
         f"kind {kind}: {np.count_nonzero(got.view(np.uint64) != want.view(np.uint64))} of {len(want)} differ"
 
 
-KERNELS = [(1, 0), (5, 0), (6, 0), (6, 4), (6, 16), (2, 0), (3, 1), (3, 2), (3, 4), (3, 8), (3, 16), (4, 1), (4, 2), (4, 4), (4, 8)]
+KERNELS = [(1, 0), (5, 0), (6, 0), (6, 4), (6, 16), (2, 0), (3, 1), (3, 2), (3, 4), (3, 8), (3, 16), (4, 1), (4, 2), (4, 4), (4, 8),
+           (10, 0), (2, 4), (2, 16)]   # (2: the packed any-geometry kernel; 10: its cell-by-cell form)
 # the served kernels (wedm_served.h: the scalar physics of a block's environments on a wave of its own, one step ahead)
 SERVED = [(9, 4), (9, 8)]
 
@@ -213,7 +214,7 @@ def test_fused_kernel_with_ragged_chunks_and_heavy_sparking(variant, lanes):
         env.step_many(a, 700)
     check(gpu, cpu, n)
     want = {3: f"wedm_step_fused<{lanes}>", 4: f"wedm_step_packed<{lanes}>", 6: f"wedm_step_stream<{lanes}>",
-            2: f"wedm_step_lanes<{lanes}>", 9: f"wedm_step_served<{lanes}>"}[variant]
+            2: f"wedm_step_lanes_pk<{lanes}>", 9: f"wedm_step_served<{lanes}>"}[variant]
     assert want in gpu._backend.last_kernel()
     assert bool(gpu.state.is_wire_broken.any()) and not bool(gpu.state.is_wire_broken.all())
 
@@ -842,7 +843,7 @@ def test_randomized_configurations_all_kernels_bit_exact(case):
         env.state.workpiece_position = torch.as_tensor(10.0 + gaps)
         env.state.target_position = torch.as_tensor(np.where(np.arange(n) % 7 == 3, 10.0 + gaps + 0.01, 5000.0)) if extreme else 5000.0
         env.state.debris_volume = torch.as_tensor(debris) if (case % 2 or extreme) else 0.0
-    variants = [(0, 0), (1, 0), (5, 0), (2, 4), (2, 8)] if per_env else KERNELS + [(0, 0), (7, 0), (8, 0)]
+    variants = [(0, 0), (1, 0), (5, 0), (2, 4), (2, 8), (10, 4), (2, 2), (2, 16)] if per_env else KERNELS + [(0, 0), (7, 0), (8, 0)]
     servo = rng.uniform(50, 300, n) if kw["mechanics_control_mode"] == "velocity" else rng.uniform(-0.05, 0.3, n)
     if extreme:
         servo = servo * rng.choice([1.0, 1.0, 20.0, -3.0], n)
@@ -1203,7 +1204,7 @@ def test_config5_shard_of_rank_5_matches_oracle():
         act = env.make_action(0.1, 80.0, mode, 3.0, 80.0)
         env.step_many(act, 1000)
         env.step_many(act, 1000)
-    assert "wedm_step_lanes<8>" in gpu._backend.last_kernel(), gpu._backend.last_kernel()
+    assert "wedm_step_lanes_pk<8>" in gpu._backend.last_kernel(), gpu._backend.last_kernel()
     check(gpu, cpu, n)
     for env in (gpu, cpu):
         act = env.make_action(0.1, 80.0, mode, 3.0, 80.0)
@@ -1278,7 +1279,7 @@ def test_config5_at_full_size_all_eight_shards_in_turn_equal_one_batch():
         n, world, make_env, lambda env, lo, hi: env.make_action(0.1, 80.0, M[lo:hi], 3.0, 80.0),
         T_rows_of=lambda env: env.n_segments)
     assert sparks > 200000, sparks
-    assert len(kernels) >= 2, kernels  # (wedm_step_lanes<4> for the whole batch, <8> for a shard)
+    assert len(kernels) >= 2, kernels  # (wedm_step_lanes_pk<4> for the whole batch, <8> for a shard)
 
 
 # ------------------------------------------------------------------ auto-reset / reward / voltage sum inside the launch
