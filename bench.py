@@ -70,7 +70,7 @@ def parse_args():
     ap.add_argument("--substeps", type=int, default=1000, help="physics microseconds per bench step")
     ap.add_argument("--workload", choices=["config3", "config2", "config4", "config5"], default="config3")
     ap.add_argument("--num-envs", type=int, default=0, help="override environments per GPU")
-    ap.add_argument("--kernel", type=int, default=0, help="0 auto, 1 global-memory, 2 LDS predicated, 3 LDS fused, 4 LDS fused + packed f32, 5 global-memory split, 6 stream (single microseconds), 7 registers (one or two lanes per environment), 8 wide registers (4 / 8 / 16 lanes per environment)")
+    ap.add_argument("--kernel", type=int, default=0, help="0 auto, 1 global-memory, 2 LDS any-geometry (packed), 9 served packed, 10 LDS any-geometry cell by cell, 11 served any-geometry, 3 LDS fused, 4 LDS fused + packed f32, 5 global-memory split, 6 stream (single microseconds), 7 registers (one or two lanes per environment), 8 wide registers (4 / 8 / 16 lanes per environment)")
     ap.add_argument("--lanes", type=int, default=0, help="lanes per environment in kernel 3 (0 auto)")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="target wall time of the cpu_baseline leg")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -185,7 +185,18 @@ def measured_traffic(kernel_name):
     return (row["hbm_bytes_per_launch"], None) if row else (None, why)
 
 
-def roofline_block(kernel_name, kernel_ms, n_envs, n_sub, n_seg, traffic_override=None):
+def resident_waves_cap(backend):
+    """Waves of the last launch's kernel that can be resident per SIMD: blocks per CU by the occupancy API x waves per block / 4
+    (the served kernels run three blocks of four waves per CU, the register / LDS kernels two)."""
+    try:
+        block = int(backend.last_kernel().split("<<<")[1].split(">>>")[0].split(",")[1])
+        occ = backend.last_occupancy()
+        return max(1.0, occ * (block // 64) / 4.0) if occ > 0 else 2.0
+    except Exception:
+        return 2.0
+
+
+def roofline_block(kernel_name, kernel_ms, n_envs, n_sub, n_seg, traffic_override=None, resident_cap=2.0):
     """The `roofline` object for one kernel launch of `n_envs` x `n_sub` env-steps that took `kernel_ms`."""
     t = kernel_ms * 1e-3
     env_steps = n_envs * n_sub
@@ -225,9 +236,9 @@ def roofline_block(kernel_name, kernel_ms, n_envs, n_sub, n_seg, traffic_overrid
             # f64 instructions hold it twice as long as the 2-cycle f32 instruction the issue peak assumes);
             # SQ_WAVE_CYCLES counts the quad-cycles the launch's waves were resident.  Both from the SAME counter pass,
             # so their ratio is the pipe occupancy at the clock the chip really ran at, whatever that was.
-            # waves RESIDENT per SIMD: every step kernel is built for at most 2 blocks of 4 waves per CU, and a launch with
-            # more waves than that runs them in rounds
-            resident = min(max(1.0, valu["sq_waves"] / 1024.0), 2.0)
+            # waves RESIDENT per SIMD: what the occupancy API admits for the kernel that ran (`resident_cap`: 2 for the register /
+            # LDS kernels, 3 for the served kernels); a launch with more waves than that runs them in rounds
+            resident = min(max(1.0, valu["sq_waves"] / 1024.0), resident_cap)
             simd_cycles = valu["sq_wave_cycles"] / resident                  # quad-cycles a SIMD was occupied by the launch
             scale = env_steps / valu["env_steps_per_launch"]
             out["valu_pipe_busy"] = {
@@ -587,12 +598,12 @@ def main():
                                 "counter), no data-path collective; obs all-gather per control step (async, overlapped "
                                 "with the next launch)") if world > 1 else "single GPU",
                 "ranks": world, "env_id_offsets": [r * n_local for r in range(world)],
-                "kernel": kname, "build_id": env._backend.build_id(),
+                "kernel": kname, "build_id": env._backend.build_id(), "occupancy_blocks_per_cu": env._backend.last_occupancy(),
                 **({"trace": args.trace} if args.trace != "off" else {}),
                 **({"stencil_dtype": args.stencil_dtype} if args.stencil_dtype != "float32" else {}),
                 **({"initial_gap_um": args.gap} if args.gap is not None else {}),
             },
-            "roofline": roofline_block(kname, kernel_ms, n_local, n_sub, S, args.traffic),
+            "roofline": roofline_block(kname, kernel_ms, n_local, n_sub, S, args.traffic, resident_cap=resident_waves_cap(env._backend)),
             **({"per_rank": per_rank} if per_rank is not None else {}),
             "check": {"envs_done": done, "envs_wire_broken": broken, "envs_target_reached": reached, "sparks": sparks,
                       **({"note": "per-environment draws that pair the thinnest wires (0.10 mm) with the highest current modes "

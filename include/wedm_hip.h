@@ -409,7 +409,9 @@ int64_t wedm_trace_samples(wedm_ctx* ctx);
  * maxima cross through LDS; uniform geometry, float32 stencil, freeze-on-termination; launches with a trace sample take
  * kernel 4), 10 = kernel 2's cell-by-cell form by name (since round 4 kernel 2 itself is the packed form -- two virtual
  * chunks per lane advanced in float2 registers, per-cell coefficients from the lane's own indices -- wherever the stencil is
- * float32; the cell-by-cell form remains for stencil_mode 1 and for A/B timing).  All variants produce bit-identical results.  With wedm_params.stencil_mode 1 only 0, 1, 2 (= 10) and 3 are accepted (3: the tile walk with
+ * float32; the cell-by-cell form remains for stencil_mode 1 and for A/B timing), 11 = the served form of kernel 2 (its walk
+ * on three waves of a block, the scalar physics on the fourth, as kernel 9; by name only: not faster at BASELINE configs[4]).
+ * All variants produce bit-identical results.  With wedm_params.stencil_mode 1 only 0, 1, 2 (= 10) and 3 are accepted (3: the tile walk with
  * per-cell coefficients, no stage-major / packed form).                                          */
 int32_t wedm_set_kernel(wedm_ctx* ctx, int32_t variant);
 

@@ -3069,6 +3069,9 @@ __global__ void __launch_bounds__(256, WEDM_PACKED_MIN_BLOCKS) wedm_step_packed(
 #define WEDM_LANES_PK_LIST(X) X(1, false) X(1, true) X(2, false) X(2, true) X(4, false) X(4, true) X(8, false) X(8, true) X(16, false) X(16, true)
 #define WEDM_INST_LANES_PK(L, tr) template __global__ void wedm_step_lanes_pk<L, tr>(const KArgs);
 #define WEDM_EXT_LANES_PK(L, tr) extern template __global__ void wedm_step_lanes_pk<L, tr>(const KArgs);
+#define WEDM_LANES_SERVED_LIST(X) X(4) X(8) X(16)
+#define WEDM_INST_LANES_SERVED(L) template __global__ void wedm_step_lanes_served<L>(const KArgs);
+#define WEDM_EXT_LANES_SERVED(L) extern template __global__ void wedm_step_lanes_served<L>(const KArgs);
 #define WEDM_INST_SERVED(L, ex) template __global__ void wedm_step_served<L, ex>(const KArgs);
 #define WEDM_EXT_SERVED(L, ex) extern template __global__ void wedm_step_served<L, ex>(const KArgs);
 #if defined(WEDM_PART) && WEDM_PART == 1
@@ -3079,6 +3082,7 @@ WEDM_FUSED_F64_LIST(WEDM_INST_FUSED_F64)
 #elif defined(WEDM_PART) && WEDM_PART == 3
 WEDM_SERVED_LIST(WEDM_INST_SERVED)
 WEDM_LANES_PK_LIST(WEDM_INST_LANES_PK)
+WEDM_LANES_SERVED_LIST(WEDM_INST_LANES_SERVED)
 #else
 #if defined(WEDM_PART)
 WEDM_PACKED_LIST(WEDM_EXT_PACKED)
@@ -3086,6 +3090,7 @@ WEDM_FUSED_LIST(WEDM_EXT_FUSED)
 WEDM_FUSED_F64_LIST(WEDM_EXT_FUSED_F64)
 WEDM_SERVED_LIST(WEDM_EXT_SERVED)
 WEDM_LANES_PK_LIST(WEDM_EXT_LANES_PK)
+WEDM_LANES_SERVED_LIST(WEDM_EXT_LANES_SERVED)
 #endif
 
 __global__ void __launch_bounds__(256)
@@ -3483,6 +3488,22 @@ static int32_t plan_launch(wedm_ctx* ctx, bool single, bool tr, bool frozen_ok, 
         }
     }
     const bool lanes_pk_ok = pklanes > 0;
+    // ... and the served form of that (wedm_step_lanes_served: 4, 8 or 16 lanes per environment, three walker waves + the scalar
+    // wave per block, three blocks per CU where the LDS image allows): the caller's lane count, else the fewest lanes whose
+    // blocks fill the chip at three per CU
+    int svgl = 0;
+    {
+        const int Ls[3] = {4, 8, 16};
+        for (int i = 0; i < 3; ++i) {
+            const size_t b = (2 * (size_t)((ctx->n_seg_max + 2 * Ls[i] - 1) / (2 * Ls[i])) + 2) * 768 + sizeof(ServedBox<48>);
+            if (b > (size_t)ctx->lds_limit) continue;
+            if (ctx->lanes) { if (Ls[i] == ctx->lanes) svgl = Ls[i]; continue; }
+            svgl = Ls[i];
+            const long blocks = (ctx->num_envs + (192 / Ls[i]) - 1) / (192 / Ls[i]);
+            if (blocks >= 768 && 3 * b <= 160 * 1024) break;
+        }
+    }
+    const bool lanes_sv_ok = svgl > 0 && !ctx->replay && P.stencil_mode == 0 && !P.keep_stepping_terminated;
     // kernel 6 (stream, single microseconds, uniform geometry): the caller's lane count, else -- among the L whose chunk
     // has at most 64 cells (the registers a lane holds its chunk in) -- the largest one whose blocks are all resident at
     // once (2 048 waves): a launch of one microsecond is one dependent chain per wave, and a shorter chunk is a shorter
@@ -3607,6 +3628,7 @@ static int32_t plan_launch(wedm_ctx* ctx, bool single, bool tr, bool frozen_ok, 
         return fail(ctx, WEDM_ERR_UNSUPPORTED, "wedm_step: fused kernel needs uniform geometry and a chunk that fits in LDS");
     if (variant == 4 && !packed_ok)
         return fail(ctx, WEDM_ERR_UNSUPPORTED, "wedm_step: packed kernel needs uniform geometry, lanes in {1,2,4,8} and two chunks that fit in LDS");
+    if (variant == 11 && (!lanes_sv_ok || tr)) variant = 2;  // (a trace sample, stencil_mode 1, keep-stepping: the unserved forms)
     if ((variant == 2 && !use_pk && !lanes_ok) || (variant == 10 && !lanes_ok))
         return fail(ctx, WEDM_ERR_UNSUPPORTED, "wedm_step: no lane count puts a chunk of the wire in LDS");
     if (variant == 6 && !stream_ok)
@@ -3653,7 +3675,12 @@ static int32_t plan_launch(wedm_ctx* ctx, bool single, bool tr, bool frozen_ok, 
            : ctx->walk4_C[sli] <= 64 ? (tr ? pick_stream<true, 64>(slanes) : pick_stream<false, 64>(slanes))
                                      : (tr ? pick_stream<true, 104>(slanes) : pick_stream<false, 104>(slanes));
         std::snprintf(out.name, sizeof(out.name), "wedm_step_stream<%d><<<%d,256,%zuB>>>", slanes, grid, fl);
-    } else if (variant == 2 && use_pk) {
+    } else if (lanes_sv_ok && variant == 11) {  // (by name only: at 16 384 environments x <= 450 segments it measures 2.39e9 against the packed form's 2.48e9 - 2.62e9)
+        grid = (ctx->num_envs + 192 / svgl - 1) / (192 / svgl);
+        fl = (2 * (size_t)((ctx->n_seg_max + 2 * svgl - 1) / (2 * svgl)) + 2) * 768 + (svgl == 4 ? sizeof(ServedBox<48>) : svgl == 8 ? sizeof(ServedBox<24>) : sizeof(ServedBox<12>));
+        fn = svgl == 4 ? (const void*)wedm_step_lanes_served<4> : svgl == 8 ? (const void*)wedm_step_lanes_served<8> : (const void*)wedm_step_lanes_served<16>;
+        std::snprintf(out.name, sizeof(out.name), "wedm_step_lanes_served<%d><<<%d,256,%zuB>>>", svgl, grid, fl);
+    } else if ((variant == 2 || variant == 11) && use_pk) {
         grid = (ctx->num_envs + 256 / pklanes - 1) / (256 / pklanes);
         fl = (2 * (size_t)((ctx->n_seg_max + 2 * pklanes - 1) / (2 * pklanes)) + 2) * 1024;
         fn = tr ? pick_lanes_pk<true>(pklanes) : pick_lanes_pk<false>(pklanes);
@@ -3921,7 +3948,7 @@ int32_t wedm_bind_rng_replay(wedm_ctx* ctx, const double* table, int64_t n_steps
 
 int32_t wedm_set_kernel(wedm_ctx* ctx, int32_t variant) {
     if (!ctx) return WEDM_ERR_BAD_ARG;
-    if (variant < 0 || variant > 10) return fail(ctx, WEDM_ERR_BAD_ARG, "wedm_set_kernel: variant must be 0..10");
+    if (variant < 0 || variant > 11) return fail(ctx, WEDM_ERR_BAD_ARG, "wedm_set_kernel: variant must be 0..11");
     ctx->variant = variant;
     ctx->invalidate_plans();
     return WEDM_OK;

@@ -14,6 +14,150 @@
 // float32 stencil only (stencil_mode 1 stays on wedm_step_lanes).
 #pragma once
 
+// One microsecond of the packed any-geometry walk for this lane's two virtual chunks (LDS rows of NT floats); returns the
+// lane's maximum (the caller reduces it over the environment's L lanes).  `keep`: the environment is live (a terminated one's
+// wire stays as it is).
+struct LanesPkGeom {   // per lane, fixed for the launch
+    int c, Cv, R, n, baseA, baseB, own_last;
+    uint32_t zs, zw, cbot, cw, span;
+    bool has_inner;
+};
+template <int L, int NT>
+__device__ __forceinline__ float lanes_pk_step(float* col, const LanesPkGeom& q, bool keep, const Geom& g, const Coef& cf, const Persist& ps,
+                                               float spool, float tref, float alpha, float tdiel) {
+    const int c = q.c, Cv = q.Cv, R = q.R, n = q.n, baseA = q.baseA, baseB = q.baseB, own_last = q.own_last;
+    const uint32_t zs = q.zs, zw = q.zw, cbot = q.cbot, cw = q.cw, span = q.span;
+    const bool has_inner = q.has_inner;
+    auto owner = [&](int i) -> int {  // which of this lane's virtual chunks holds wire cell i (0: none, 1: A, 2: B)
+        if (i >= baseA && i < baseA + Cv) return 1;
+        if (i >= baseB && i < baseB + Cv) return 2;
+        return 0;
+    };
+    // ---- halos (OLD values, read before any store of this step)
+    const float halo_l = (c > 0) ? col[(R - 1) * NT - 1] : spool;  // left neighbour lane's B[Cv-1]
+    const float halo_r = (c < L - 1) ? col[1] : 0.0f;               // right neighbour lane's A[0]
+    const float a_last = col[(R - 2) * NT];                        // own A[Cv-1]: left halo of B
+    const float b_first = col[NT];                                 // own B[0]: right halo of A
+    col[R * NT] = b_first;
+    col[(R + 1) * NT] = halo_r;
+    float tmax = spool;
+
+    if (!__any(cf.q < 0.0f)) {
+        // full predicated formula for one owned cell, from OLD values (patched cells); rows R, R + 1 are the halo pair
+        auto patch_value = [&](int i, int own, bool last) -> float {
+            const int v = own - 1, r = i - (v ? baseB : baseA), row = 2 * r + v;
+            const float left = col[(r > 0 ? row - 2 : row) * NT];
+            float tm = r > 0 ? left : (v ? a_last : halo_l);
+            if (i == 1) tm = spool;
+            const float tp = last ? 0.0f : col[(row + 2) * NT];
+            return stencil_cell(i, n, tm, col[row * NT], tp, g, cf, ps, tref, alpha, tdiel);
+        };
+        const int own_pl = (keep && cf.pidx >= 1 && cf.pidx < n) ? owner(cf.pidx) : 0;
+        float tpl = 0.0f, tlast = 0.0f;
+        if (__any(own_pl != 0)) {
+            if (own_pl) tpl = patch_value(cf.pidx, own_pl, false);
+        }
+        if (own_last && keep) tlast = patch_value(n - 1, own_last, true);
+
+        const float jf_lane = (cf.joule_on && keep) ? cf.jf : 0.0f;
+        const bool joule_wave = __any(jf_lane != 0.0f);
+        const float cz = ps.conv_zone, cb = ps.conv_base;
+        f2 tm1 = {halo_l, a_last};
+        f2 tc = {col[0], col[NT]};
+        for (int r0 = 0; r0 < Cv; r0 += 8) {
+            f2 old[10], tn[8];
+            old[0] = tm1; old[1] = tc;
+            if (r0 + 8 <= Cv) {  // a full tile: one base address + immediate offsets
+                const float* const row = col + (2 * (r0 + 1)) * NT;
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    old[u + 2].x = row[(2 * u) * NT];
+                    old[u + 2].y = row[(2 * u + 1) * NT];
+                }
+            } else {
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    int p = r0 + 1 + u;
+                    p = p < Cv ? p : Cv;  // pair Cv is the halo pair; later pairs are never used
+                    old[u + 2].x = col[(2 * p) * NT];
+                    old[u + 2].y = col[(2 * p + 1) * NT];
+                }
+            }
+            // the pairs' coefficients group by group, right before the stage-major group that uses them (all eight up
+            // front are 32 registers more than the Env leaves)
+            constexpr int W = WEDM_STAGE_W_PACKED;
+#pragma unroll
+            for (int o = 0; o < 8; o += W) {
+                f2 cv[8], jv[8];  // (only entries o .. o + W - 1 are set and read)
+#pragma unroll
+                for (int u = o; u < o + W; ++u) {
+                    const uint32_t ia = (uint32_t)(baseA + r0 + u), ib = (uint32_t)(baseB + r0 + u);
+                    cv[u] = f2{(ia - zs < zw) ? cz : cb, (ib - zs < zw) ? cz : cb};
+                    jv[u] = f2{(ia - cbot < cw) ? jf_lane : 0.0f, (ib - cbot < cw) ? jf_lane : 0.0f};
+                }
+                if (joule_wave) tile_staged<f2, true, true, W>(old, tn, o, g.k, g.tuf, cv, tdiel, ps.adv, jv, alpha, tref);
+                else tile_staged<f2, false, true, W>(old, tn, o, g.k, g.tuf, cv, tdiel, ps.adv, jv, alpha, tref);
+            }
+            // ONE predicate per cell for store and maximum: interior (1 <= i <= n - 2) and this environment live.  Wire cell
+            // 0 and the last cell are written after the walk anyway (spool temperature, the patched value), cells past the
+            // wire keep their value (the write-back copies all n_seg_max rows), a terminated environment's wire stays: all of
+            // them simply store their OLD value back (a select, not a branch: 41 exec-mask round trips per tile otherwise).
+            float mx[8];
+            const uint32_t ja = (uint32_t)(baseA + r0) - 1u, jb = (uint32_t)(baseB + r0) - 1u;
+            const uint32_t lim = (keep && has_inner) ? span : 0u;
+            const bool any_ok = keep && has_inner;
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const bool inA = any_ok && (ja + (uint32_t)u <= lim), inB = any_ok && (jb + (uint32_t)u <= lim);
+                if (r0 + u < Cv) {  // (wave-uniform)
+                    col[(2 * (r0 + u)) * NT] = inA ? tn[u].x : old[u + 1].x;
+                    col[(2 * (r0 + u) + 1) * NT] = inB ? tn[u].y : old[u + 1].y;
+                    mx[u] = fmax_gt(inA ? tn[u].x : spool, inB ? tn[u].y : spool);
+                } else {
+                    mx[u] = spool;
+                }
+            }
+            tmax = fmax_gt(tmax, fmax_gt(fmax_gt(fmax_gt(mx[0], mx[1]), fmax_gt(mx[2], mx[3])),
+                                         fmax_gt(fmax_gt(mx[4], mx[5]), fmax_gt(mx[6], mx[7]))));
+            tm1 = old[8];
+            tc = old[9];
+        }
+        // ---- patches (after every store of the walk): boundary condition, last cell, plasma cell
+        if (c == 0 && keep) col[0] = spool;
+        if (own_last && keep) {
+            const int v = own_last - 1;
+            col[(2 * (n - 1 - (v ? baseB : baseA)) + v) * NT] = tlast;
+            tmax = fmax_gt(tmax, tlast);
+        }
+        if (own_pl) {
+            const int v = own_pl - 1;
+            col[(2 * (cf.pidx - (v ? baseB : baseA)) + v) * NT] = tpl;
+            tmax = fmax_gt(tmax, tpl);
+        }
+    } else {
+        // a negative plasma heat somewhere in the wave: every cell on the predicated formula, chunk A then chunk B (each
+        // with its rolling window of OLD values; the halos were taken above)
+#pragma unroll 1
+        for (int v = 0; v < 2; ++v) {
+            const int cbase = v ? baseB : baseA;
+            float tm1 = v ? a_last : halo_l, tc = col[v * NT];
+            for (int r = 0; r < Cv; ++r) {
+                const float nx = col[(2 * (r + 1) + v) * NT];  // (row 2 Cv + v: this chunk's right halo)
+                const int i = cbase + r;
+                if (i < n && keep) {
+                    float tn = spool;
+                    if (i >= 1) tn = stencil_cell(i, n, (i == 1) ? spool : tm1, tc, nx, g, cf, ps, tref, alpha, tdiel);
+                    col[(2 * r + v) * NT] = tn;
+                    tmax = fmax_gt(tmax, tn);
+                }
+                tm1 = tc;
+                tc = nx;
+            }
+        }
+    }
+    return tmax;
+}
+
 template <int L, bool TRACE>
 __global__ void __launch_bounds__(256, 2) wedm_step_lanes_pk(const KArgs k) {
     const ColdRef cold = kernarg_cold();
@@ -72,6 +216,7 @@ __global__ void __launch_bounds__(256, 2) wedm_step_lanes_pk(const KArgs k) {
     const uint32_t cbot = (uint32_t)g.cb, cw = g.ct >= g.cb ? (uint32_t)(g.ct - g.cb + 1) : 0u;
     const bool has_inner = n >= 3;
     const uint32_t span = has_inner ? (uint32_t)(n - 3) : 0u;
+    const LanesPkGeom pkg{c, Cv, R, n, baseA, baseB, own_last, zs, zw, cbot, cw, span, has_inner};
 
     const bool tracing = WEDM_TRACING(k);
     int trace_next = k.trace_next, trace_slot = k.trace_slot;
@@ -85,128 +230,7 @@ __global__ void __launch_bounds__(256, 2) wedm_step_lanes_pk(const KArgs k) {
         freeze_wire(s);
         const bool keep = !s.done;
 
-        // ---- halos (OLD values, read before any store of this step)
-        const float halo_l = (c > 0) ? col[(R - 1) * 256 - 1] : spool;  // left neighbour lane's B[Cv-1]
-        const float halo_r = (c < L - 1) ? col[1] : 0.0f;               // right neighbour lane's A[0]
-        const float a_last = col[(R - 2) * 256];                        // own A[Cv-1]: left halo of B
-        const float b_first = col[256];                                 // own B[0]: right halo of A
-        col[R * 256] = b_first;
-        col[(R + 1) * 256] = halo_r;
-        float tmax = spool;
-
-        if (!__any(cf.q < 0.0f)) {
-            // full predicated formula for one owned cell, from OLD values (patched cells); rows R, R + 1 are the halo pair
-            auto patch_value = [&](int i, int own, bool last) -> float {
-                const int v = own - 1, r = i - (v ? baseB : baseA), row = 2 * r + v;
-                const float left = col[(r > 0 ? row - 2 : row) * 256];
-                float tm = r > 0 ? left : (v ? a_last : halo_l);
-                if (i == 1) tm = spool;
-                const float tp = last ? 0.0f : col[(row + 2) * 256];
-                return stencil_cell(i, n, tm, col[row * 256], tp, g, cf, ps, tref, alpha, tdiel);
-            };
-            const int own_pl = (keep && cf.pidx >= 1 && cf.pidx < n) ? owner(cf.pidx) : 0;
-            float tpl = 0.0f, tlast = 0.0f;
-            if (__any(own_pl != 0)) {
-                if (own_pl) tpl = patch_value(cf.pidx, own_pl, false);
-            }
-            if (own_last && keep) tlast = patch_value(n - 1, own_last, true);
-
-            const float jf_lane = (cf.joule_on && keep) ? cf.jf : 0.0f;
-            const bool joule_wave = __any(jf_lane != 0.0f);
-            const float cz = ps.conv_zone, cb = ps.conv_base;
-            f2 tm1 = {halo_l, a_last};
-            f2 tc = {col[0], col[256]};
-            for (int r0 = 0; r0 < Cv; r0 += 8) {
-                f2 old[10], tn[8];
-                old[0] = tm1; old[1] = tc;
-                if (r0 + 8 <= Cv) {  // a full tile: one base address + immediate offsets
-                    const float* const row = col + (2 * (r0 + 1)) * 256;
-#pragma unroll
-                    for (int u = 0; u < 8; ++u) {
-                        old[u + 2].x = row[(2 * u) * 256];
-                        old[u + 2].y = row[(2 * u + 1) * 256];
-                    }
-                } else {
-#pragma unroll
-                    for (int u = 0; u < 8; ++u) {
-                        int p = r0 + 1 + u;
-                        p = p < Cv ? p : Cv;  // pair Cv is the halo pair; later pairs are never used
-                        old[u + 2].x = col[(2 * p) * 256];
-                        old[u + 2].y = col[(2 * p + 1) * 256];
-                    }
-                }
-                // the pairs' coefficients group by group, right before the stage-major group that uses them (all eight up
-                // front are 32 registers more than the Env leaves)
-                constexpr int W = WEDM_STAGE_W_PACKED;
-#pragma unroll
-                for (int o = 0; o < 8; o += W) {
-                    f2 cv[8], jv[8];  // (only entries o .. o + W - 1 are set and read)
-#pragma unroll
-                    for (int u = o; u < o + W; ++u) {
-                        const uint32_t ia = (uint32_t)(baseA + r0 + u), ib = (uint32_t)(baseB + r0 + u);
-                        cv[u] = f2{(ia - zs < zw) ? cz : cb, (ib - zs < zw) ? cz : cb};
-                        jv[u] = f2{(ia - cbot < cw) ? jf_lane : 0.0f, (ib - cbot < cw) ? jf_lane : 0.0f};
-                    }
-                    if (joule_wave) tile_staged<f2, true, true, W>(old, tn, o, g.k, g.tuf, cv, tdiel, ps.adv, jv, alpha, tref);
-                    else tile_staged<f2, false, true, W>(old, tn, o, g.k, g.tuf, cv, tdiel, ps.adv, jv, alpha, tref);
-                }
-                // ONE predicate per cell for store and maximum: interior (1 <= i <= n - 2) and this environment live.  Wire cell
-                // 0 and the last cell are written after the walk anyway (spool temperature, the patched value), cells past the
-                // wire keep their value (the write-back copies all n_seg_max rows), a terminated environment's wire stays: all of
-                // them simply store their OLD value back (a select, not a branch: 41 exec-mask round trips per tile otherwise).
-                float mx[8];
-                const uint32_t ja = (uint32_t)(baseA + r0) - 1u, jb = (uint32_t)(baseB + r0) - 1u;
-                const uint32_t lim = (keep && has_inner) ? span : 0u;
-                const bool any_ok = keep && has_inner;
-#pragma unroll
-                for (int u = 0; u < 8; ++u) {
-                    const bool inA = any_ok && (ja + (uint32_t)u <= lim), inB = any_ok && (jb + (uint32_t)u <= lim);
-                    if (r0 + u < Cv) {  // (wave-uniform)
-                        col[(2 * (r0 + u)) * 256] = inA ? tn[u].x : old[u + 1].x;
-                        col[(2 * (r0 + u) + 1) * 256] = inB ? tn[u].y : old[u + 1].y;
-                        mx[u] = fmax_gt(inA ? tn[u].x : spool, inB ? tn[u].y : spool);
-                    } else {
-                        mx[u] = spool;
-                    }
-                }
-                tmax = fmax_gt(tmax, fmax_gt(fmax_gt(fmax_gt(mx[0], mx[1]), fmax_gt(mx[2], mx[3])),
-                                             fmax_gt(fmax_gt(mx[4], mx[5]), fmax_gt(mx[6], mx[7]))));
-                tm1 = old[8];
-                tc = old[9];
-            }
-            // ---- patches (after every store of the walk): boundary condition, last cell, plasma cell
-            if (c == 0 && keep) col[0] = spool;
-            if (own_last && keep) {
-                const int v = own_last - 1;
-                col[(2 * (n - 1 - (v ? baseB : baseA)) + v) * 256] = tlast;
-                tmax = fmax_gt(tmax, tlast);
-            }
-            if (own_pl) {
-                const int v = own_pl - 1;
-                col[(2 * (cf.pidx - (v ? baseB : baseA)) + v) * 256] = tpl;
-                tmax = fmax_gt(tmax, tpl);
-            }
-        } else {
-            // a negative plasma heat somewhere in the wave: every cell on the predicated formula, chunk A then chunk B (each
-            // with its rolling window of OLD values; the halos were taken above)
-#pragma unroll 1
-            for (int v = 0; v < 2; ++v) {
-                const int cbase = v ? baseB : baseA;
-                float tm1 = v ? a_last : halo_l, tc = col[v * 256];
-                for (int r = 0; r < Cv; ++r) {
-                    const float nx = col[(2 * (r + 1) + v) * 256];  // (row 2 Cv + v: this chunk's right halo)
-                    const int i = cbase + r;
-                    if (i < n && keep) {
-                        float tn = spool;
-                        if (i >= 1) tn = stencil_cell(i, n, (i == 1) ? spool : tm1, tc, nx, g, cf, ps, tref, alpha, tdiel);
-                        col[(2 * r + v) * 256] = tn;
-                        tmax = fmax_gt(tmax, tn);
-                    }
-                    tm1 = tc;
-                    tc = nx;
-                }
-            }
-        }
+        float tmax = lanes_pk_step<L, 256>(col, pkg, keep, g, cf, ps, spool, tref, alpha, tdiel);
 #pragma unroll
         for (int m = 1; m < L; m <<= 1) tmax = fmax_gt(tmax, __shfl_xor(tmax, m));
         unfreeze_wire(hv, s);
@@ -231,4 +255,86 @@ __global__ void __launch_bounds__(256, 2) wedm_step_lanes_pk(const KArgs k) {
         store_time_hi(cold, e, s, (uint32_t)k.n_substeps * (uint32_t)k.hot.dt_us);
         store_env(cold, e, s);
     }
+}
+
+// ============================================ served form: the scalar physics of the block's environments on a fourth wave
+// wedm_step_lanes_pk's walk on three walker waves (192 / L environments per block), prelude and epilogue once per environment
+// on the scalar wave, one microsecond ahead of the walkers where it can prove that the step does not break the wire
+// (wedm_served.h: mailbox, protocol, proof).  Three blocks per CU at 168 registers.  No trace point, freeze-on-termination
+// only (other launches run wedm_step_lanes_pk).
+template <int L>
+__global__ void __launch_bounds__(256, WEDM_SERVED_WAVES_PER_EU) wedm_step_lanes_served(const KArgs k) {
+    constexpr int NT = 192, EPB = NT / L;
+    static_assert(EPB <= 64, "one lane of the scalar wave per environment of the block");
+    typedef ServedBox<EPB> Box;
+    const ColdRef cold = kernarg_cold();
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    const int tid = threadIdx.x;
+    const int64_t e0 = (int64_t)blockIdx.x * EPB;
+    const int nmax = k.n_seg_max;
+    const int Cv = (nmax + 2 * L - 1) / (2 * L);  // cells per virtual chunk
+    const int R = 2 * Cv;
+    const int64_t stride = cold->s.stride;
+    volatile Box* const box = (volatile Box*)(lds + (size_t)(R + 2) * NT);
+    const float spool = k.hot.spool, tref = k.hot.tref, alpha = k.hot.alpha, tdiel = k.hot.tdiel;
+    SvStamps svs;
+    sv_stamps_begin(svs);
+    unsigned long long* const stamp_row = k.dbg ? k.dbg + ((size_t)blockIdx.x * 4 + (tid >> 6)) * 12 : nullptr;
+    if (tid == 0) { box->cf_seq = 0u; box->tm_seq[0] = 0u; box->tm_seq[1] = 0u; box->tm_seq[2] = 0u; box->tm_seq[3] = 0u; }
+    if (tid >= NT) {
+        served_scalar_wave<EPB, L>(k, cold, box, e0, tid - NT, svs, stamp_row);
+        return;
+    }
+
+    // ---------------------------------------------------------------------------------------------------- the walker waves
+    const int el = tid / L, c = tid % L, wave = tid >> 6;
+    const int64_t e = e0 + el;
+    const bool live = e < k.num_envs;
+    const auto wire_slot = [Cv](int i) { const int vc = i / Cv; return (2 * (i - vc * Cv) + (vc & 1)) * NT + (vc >> 1); };
+    copy_wire_nt<L, NT, true>(cold->s.T, stride, e0, k.num_envs, nmax, tid, lds, wire_slot);
+    Geom g;
+    load_geom(k.hot, cold, live ? e : 0, g);  // this lane's environment
+    float* col = lds + tid;
+    const bool reinit = live && WEDM_AUTORESET(cold) && cold->s.i8[(int64_t)WEDM_B_DONE * stride + e] != 0;
+    __syncthreads();  // (A)
+    if (reinit) {
+        for (int row = 0; row < R; ++row) col[row * NT] = spool;
+    }
+    Persist ps{box->adv[el], 0.0f, 0.0f, 0};
+    const int baseA = 2 * c * Cv, baseB = baseA + Cv;
+    const int n = g.n_seg;
+    if (c == 0) col[0] = spool;  // wire cell 0 is held at the spool temperature
+    const int own_last = (n >= 2) ? ((n - 1 >= baseA && n - 1 < baseA + Cv) ? 1 : (n - 1 >= baseB && n - 1 < baseB + Cv) ? 2 : 0) : 0;
+    const bool has_inner = n >= 3;
+    const LanesPkGeom pkg{c, Cv, R, n, baseA, baseB, own_last,
+                          (uint32_t)g.az_start, g.az_end > g.az_start ? (uint32_t)(g.az_end - g.az_start) : 0u,
+                          (uint32_t)g.cb, g.ct >= g.cb ? (uint32_t)(g.ct - g.cb + 1) : 0u,
+                          has_inner ? (uint32_t)(n - 3) : 0u, has_inner};
+
+    WEDM_SV_LOOP_START();
+    for (int it = 0; it < k.n_substeps; ++it) {
+        const int slot = it & 1;
+        { WEDM_SV_WAIT_BEGIN(); sv_wait(&box->cf_seq, (uint32_t)it + 1u); WEDM_SV_WAIT_END(); }
+        WEDM_SV_PHASE_START();
+        const int32_t fl = box->flags[slot][el];
+        if (fl & SV_STOP) break;  // (block-wide: every lane reads it)
+        const Coef cf{box->jf[slot][el], box->q[slot][el], (fl & SV_JOULE) ? 1 : 0, box->pidx[slot][el]};
+        ps.conv_base = box->conv_base[slot][el];
+        ps.conv_zone = box->conv_zone[slot][el];
+        ps.adv_on = (fl & SV_ADV) ? 1 : 0;
+        const bool keep = live && !(fl & SV_DONE);
+        WEDM_SV_PHASE(pa);
+        float tmax = lanes_pk_step<L, NT>(col, pkg, keep, g, cf, ps, spool, tref, alpha, tdiel);
+        WEDM_SV_PHASE(pb);
+#pragma unroll
+        for (int m = 1; m < L; m <<= 1) tmax = fmax_gt(tmax, __shfl_xor(tmax, m));
+        if (c == 0) box->tmax[slot][el] = tmax;
+        asm volatile("" ::: "memory");
+        if ((tid & 63) == 0) box->tm_seq[wave] = (uint32_t)it + 1u;
+        WEDM_SV_PHASE(pc);
+    }
+    WEDM_SV_LOOP_END();
+    sv_stamps_out(svs, stamp_row);
+    __syncthreads();  // (B)
+    copy_wire_nt<L, NT, false>(cold->s.T, stride, e0, k.num_envs, nmax, tid, lds, wire_slot);
 }

@@ -426,8 +426,8 @@ class WireEDMEnv:
         registers: wires of 9 to 512 segments, uniform geometry; auto picks it for fused launches of small
         batches), 9 = served kernel (kernel 4's walk with the float64 scalar physics of a block's environments on a wave
         of its own, one microsecond ahead of the walking waves: 4 or 8 lanes per environment, uniform geometry);
-        10 = kernel 2's cell-by-cell form by name (kernel 2 is its packed form wherever the stencil is float32);
-        ``lanes`` lanes per environment for 2/3/4/6/8/9/10 (0 = auto).  All variants are bit-identical."""
+        10 = kernel 2's cell-by-cell form by name (kernel 2 is its packed form wherever the stencil is float32), 11 = the served
+        form of kernel 2; ``lanes`` lanes per environment for 2/3/4/6/8/9/10/11 (0 = auto).  All variants are bit-identical."""
         self._backend.set_kernel(variant)
         if hasattr(self._backend, "set_lanes"):
             self._backend.set_lanes(lanes)

@@ -134,9 +134,10 @@ KERNELS = [(1, 0), (5, 0), (6, 0), (6, 4), (6, 16), (2, 0), (3, 1), (3, 2), (3, 
            (10, 0), (2, 4), (2, 16)]   # (2: the packed any-geometry kernel; 10: its cell-by-cell form)
 # the served kernels (wedm_served.h: the scalar physics of a block's environments on a wave of its own, one step ahead)
 SERVED = [(9, 4), (9, 8)]
+SERVED_ANY = [(11, 4), (11, 8), (11, 16)]   # the served form of the any-geometry kernel
 
 
-@pytest.mark.parametrize("variant,lanes", KERNELS + SERVED)
+@pytest.mark.parametrize("variant,lanes", KERNELS + SERVED + SERVED_ANY)
 def test_default_config_fused_matches_oracle(variant, lanes):
     """BASELINE config 2 shape (S=400): 3 control intervals, every kernel variant."""
     n = 320
@@ -196,7 +197,7 @@ def test_config3_grid_128_segments(variant, lanes):
     check(gpu, cpu, n)
 
 
-@pytest.mark.parametrize("variant,lanes", [(3, 4), (3, 8), (3, 16), (4, 4), (4, 8), (6, 4), (6, 8), (2, 8), (9, 4), (9, 8)])
+@pytest.mark.parametrize("variant,lanes", [(3, 4), (3, 8), (3, 16), (4, 4), (4, 8), (6, 4), (6, 8), (2, 8), (9, 4), (9, 8), (11, 8)])
 def test_fused_kernel_with_ragged_chunks_and_heavy_sparking(variant, lanes):
     """361 segments (not divisible by any lane count), thin wire + I17: Joule heating,
     plasma cells at chunk edges, wire breaks and frozen environments inside live waves."""
@@ -214,7 +215,7 @@ def test_fused_kernel_with_ragged_chunks_and_heavy_sparking(variant, lanes):
         env.step_many(a, 700)
     check(gpu, cpu, n)
     want = {3: f"wedm_step_fused<{lanes}>", 4: f"wedm_step_packed<{lanes}>", 6: f"wedm_step_stream<{lanes}>",
-            2: f"wedm_step_lanes_pk<{lanes}>", 9: f"wedm_step_served<{lanes}>"}[variant]
+            2: f"wedm_step_lanes_pk<{lanes}>", 9: f"wedm_step_served<{lanes}>", 11: f"wedm_step_lanes_"}[variant]
     assert want in gpu._backend.last_kernel()
     assert bool(gpu.state.is_wire_broken.any()) and not bool(gpu.state.is_wire_broken.all())
 
@@ -252,14 +253,14 @@ def test_per_environment_geometry_config5():
     gpu, cpu = make_pair(n, **kw)
     assert gpu.n_segments == cpu.n_segments and 350 <= gpu.n_segments <= 450
     both((gpu, cpu), lambda e: (e.reset(seed=2024), close_gap(e, 24.0, 10.0)))
-    for variant, lanes in ((1, 0), (5, 0), (2, 4), (2, 8), (2, 16), (2, 0)):
+    for variant, lanes in ((1, 0), (5, 0), (2, 4), (2, 8), (2, 16), (2, 0), (10, 8), (11, 4), (11, 8), (11, 16)):
         gpu.set_kernel(variant, lanes)
         for env in (gpu, cpu):
             a = env.make_action(0.1, 80.0, mode, 3.0, 40.0)
             env.step_many(a, 700)
         check(gpu, cpu, n)
-        if variant == 2:
-            assert "wedm_step_lanes" in gpu._backend.last_kernel()
+        if variant in (2, 10, 11):
+            assert {2: "wedm_step_lanes_pk", 10: "wedm_step_lanes<", 11: "wedm_step_lanes_served"}[variant] in gpu._backend.last_kernel()
     assert int(gpu.state.spark_count.sum()) > 100
 
 
@@ -843,7 +844,7 @@ def test_randomized_configurations_all_kernels_bit_exact(case):
         env.state.workpiece_position = torch.as_tensor(10.0 + gaps)
         env.state.target_position = torch.as_tensor(np.where(np.arange(n) % 7 == 3, 10.0 + gaps + 0.01, 5000.0)) if extreme else 5000.0
         env.state.debris_volume = torch.as_tensor(debris) if (case % 2 or extreme) else 0.0
-    variants = [(0, 0), (1, 0), (5, 0), (2, 4), (2, 8), (10, 4), (2, 2), (2, 16)] if per_env else KERNELS + [(0, 0), (7, 0), (8, 0)]
+    variants = [(0, 0), (1, 0), (5, 0), (2, 4), (2, 8), (10, 4), (2, 2), (2, 16), (11, 4), (11, 8), (11, 16)] if per_env else KERNELS + [(0, 0), (7, 0), (8, 0)]
     servo = rng.uniform(50, 300, n) if kw["mechanics_control_mode"] == "velocity" else rng.uniform(-0.05, 0.3, n)
     if extreme:
         servo = servo * rng.choice([1.0, 1.0, 20.0, -3.0], n)
@@ -1204,7 +1205,7 @@ def test_config5_shard_of_rank_5_matches_oracle():
         act = env.make_action(0.1, 80.0, mode, 3.0, 80.0)
         env.step_many(act, 1000)
         env.step_many(act, 1000)
-    assert "wedm_step_lanes_pk<8>" in gpu._backend.last_kernel(), gpu._backend.last_kernel()
+    assert "wedm_step_lanes_" in gpu._backend.last_kernel(), gpu._backend.last_kernel()   # (the served or the packed form)
     check(gpu, cpu, n)
     for env in (gpu, cpu):
         act = env.make_action(0.1, 80.0, mode, 3.0, 80.0)
@@ -1283,7 +1284,7 @@ def test_config5_at_full_size_all_eight_shards_in_turn_equal_one_batch():
 
 
 # ------------------------------------------------------------------ auto-reset / reward / voltage sum inside the launch
-@pytest.mark.parametrize("variant,lanes", [(0, 0), (2, 4), (3, 8), (4, 4), (1, 0), (5, 0), (6, 8), (9, 8), (9, 4)])
+@pytest.mark.parametrize("variant,lanes", [(0, 0), (2, 4), (3, 8), (4, 4), (1, 0), (5, 0), (6, 8), (9, 8), (9, 4), (11, 8)])
 def test_in_kernel_autoreset_and_reward_match_oracle_and_host_path(variant, lanes):
     """wedm_params.autoreset + reward_mode: environments that reach their cutting target are
     re-initialised by the NEXT launch itself (Philox episode + 1, fresh module state, spool-temperature wire,
@@ -1748,7 +1749,7 @@ def test_negative_plasma_heat_every_kernel_matches_oracle(segment_len):
               config=EnvironmentConfig(target_cutting_distance=5000.0))
     gpu, cpu = make_pair(n, **kw)
     ran = 0
-    for variant, lanes in KERNELS + [(0, 0), (7, 0), (8, 0)] + SERVED:
+    for variant, lanes in KERNELS + [(0, 0), (7, 0), (8, 0)] + SERVED + SERVED_ANY:
         gpu.set_kernel(variant, lanes)
         for env in (gpu, cpu):
             env.reset(seed=515)
