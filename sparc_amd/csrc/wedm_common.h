@@ -236,6 +236,23 @@ __device__ __forceinline__ void run_substeps(const KArgs& k, const ColdRef cold,
 // np.max over finite temperatures; maps to v_max_f32 / v_max3_f32
 __device__ __forceinline__ float fmax_gt(float a, float b) { return __builtin_fmaxf(a, b); }
 
+// max over the L lanes of an environment (L a power of two <= 16, the lanes adjacent and aligned inside one DPP row): quad
+// permutes, half-row mirror, row mirror -- one v_max_f32 with a DPP operand per doubling.  (__shfl_xor is a ds_bpermute with
+// its address arithmetic: ~4 instructions and an LDS round trip per doubling.)
+template <int CTRL>
+__device__ __forceinline__ float dpp_lane_perm(float x) {
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), CTRL, 0xF, 0xF, false));
+}
+template <int L>
+__device__ __forceinline__ float max_over_env_lanes(float v) {
+    static_assert(L == 1 || L == 2 || L == 4 || L == 8 || L == 16, "lanes per environment");
+    if (L >= 2) v = fmax_gt(v, dpp_lane_perm<0xB1>(v));    // quad_perm [1,0,3,2]
+    if (L >= 4) v = fmax_gt(v, dpp_lane_perm<0x4E>(v));    // quad_perm [2,3,0,1]
+    if (L >= 8) v = fmax_gt(v, dpp_lane_perm<0x141>(v));   // row_half_mirror
+    if (L >= 16) v = fmax_gt(v, dpp_lane_perm<0x140>(v));  // row_mirror
+    return v;
+}
+
 #ifdef WEDM_STAMPS
 // -DWEDM_STAMPS_REAL: the 100 MHz clock all XCDs share (10 ns per tick: start / end skew across the chip) instead of the
 // per-XCD shader clock (phase lengths inside a wave)

@@ -231,8 +231,7 @@ __global__ void __launch_bounds__(256, 2) wedm_step_lanes_pk(const KArgs k) {
         const bool keep = !s.done;
 
         float tmax = lanes_pk_step<L, 256>(col, pkg, keep, g, cf, ps, spool, tref, alpha, tdiel);
-#pragma unroll
-        for (int m = 1; m < L; m <<= 1) tmax = fmax_gt(tmax, __shfl_xor(tmax, m));
+        tmax = max_over_env_lanes<L>(tmax);
         unfreeze_wire(hv, s);
         if (!s.done) {
             scalar_epilogue(hv, s, tmax);
@@ -326,8 +325,7 @@ __global__ void __launch_bounds__(256, WEDM_SERVED_WAVES_PER_EU) wedm_step_lanes
         WEDM_SV_PHASE(pa);
         float tmax = lanes_pk_step<L, NT>(col, pkg, keep, g, cf, ps, spool, tref, alpha, tdiel);
         WEDM_SV_PHASE(pb);
-#pragma unroll
-        for (int m = 1; m < L; m <<= 1) tmax = fmax_gt(tmax, __shfl_xor(tmax, m));
+        tmax = max_over_env_lanes<L>(tmax);
         if (c == 0) box->tmax[slot][el] = tmax;
         asm volatile("" ::: "memory");
         if ((tid & 63) == 0) box->tm_seq[wave] = (uint32_t)it + 1u;

@@ -694,8 +694,7 @@ __global__ void __launch_bounds__((WW + 1) * 64, WEDM_SERVED_WAVES_PER_EU) wedm_
             col[(2 * (cf.pidx - (v ? baseB : baseA)) + v) * NT] = tpl;
             tmax = fmax_gt(tmax, tpl);
         }
-#pragma unroll
-        for (int m = 1; m < L; m <<= 1) tmax = fmax_gt(tmax, __shfl_xor(tmax, m));
+        tmax = max_over_env_lanes<L>(tmax);
         if (c == 0) box->tmax[slot][el] = tmax;
         asm volatile("" ::: "memory");
         if ((tid & 63) == 0) box->tm_seq[wave] = (uint32_t)it + 1u;
