@@ -411,7 +411,8 @@ def other_config_lines(device):
         sec, kname = time_launches(env, act, 1000, steps, 2)
         line = {"name": f"{label}: num_envs={n_local}, n_segments={env.n_segments}, fresh reset(seed=1234), fused 1000-us launches",
                 "workload": name, "value": n_local * 1000 / sec, "unit": "env-steps/s", "kernel": kname, "kernel_ms": sec * 1e3,
-                "steps": steps, "roofline": roofline_block(kname, sec * 1e3, n_local, 1000, env.n_segments),
+                "steps": steps, "occupancy_blocks_per_cu": env._backend.last_occupancy(),
+                "roofline": roofline_block(kname, sec * 1e3, n_local, 1000, env.n_segments, resident_cap=resident_waves_cap(env._backend)),
                 "check": {"envs_done": int(env.state.done.sum().item()), "sparks": int(env.state.spark_count.sum().item())}}
         out.append(line)
         env.close()

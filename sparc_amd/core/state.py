@@ -78,7 +78,8 @@ class WireTemperature:
       ``wt[e]`` / ``wt[2:5, 10:20]`` (integers and slices) is again a write-through proxy, so ``wt[1][10] = 999``
       and ``state.wire_temperature[2].fill_(500)`` change the block.  Indexing with a tensor or a list returns a plain
       gathered tensor (a copy, as advanced indexing does on a NumPy array too).
-    * ``wt.quads`` is the zero-copy ``[num_envs, n_seg / 4, 4]`` view of the block itself."""
+    * ``wt.quads`` is the zero-copy ``[num_envs, n_seg / 4, 4]`` view of the block itself; ``wt.tensor()`` is the way to get a
+      plain tensor (``torch.as_tensor(wt)`` walks the sequence protocol element by element: correct, seconds for 200 x 400)."""
 
     def __init__(self, T: torch.Tensor, num_envs: int, n_seg: int, _chain=()):
         self._T, self._n, self._s, self._chain = T, num_envs, n_seg, tuple(_chain)
@@ -121,6 +122,11 @@ class WireTemperature:
 
     def __len__(self):
         return self.shape[0]
+
+    def __iter__(self):
+        # rows of ONE gathered copy (plain tensors): `torch.as_tensor(wt)`, `list(wt)`, `for row in wt` walk the sequence
+        # protocol, and row proxies that each gather the whole block again made that quadratic (minutes for 200 x 400)
+        return iter(self.tensor())
 
     def __getitem__(self, idx):
         if _is_basic_index(idx):

@@ -478,20 +478,24 @@ __global__ void __launch_bounds__((WW + 1) * 64, WEDM_SERVED_WAVES_PER_EU) wedm_
 
         // ---- tail cells: new values from OLD ones, now (not on the predicated path, whose last tile covers them)
         const bool use_tail = EXTRA && tail != 0 && !all_slow;
-        float tt[4] = {0.0f, 0.0f, 0.0f, 0.0f};  // [2 q + v]
+        // (as ONE packed pair per tail position -- both virtual chunks together, the Joule term only where some lane of the
+        // wave carries current, exactly as the tiles do it -- instead of two scalar cells with the Joule term always)
+        f2 ttp[2] = {f2{0.0f, 0.0f}, f2{0.0f, 0.0f}};  // [q] = (chunk A, chunk B)
         if (use_tail) {
             const float jfl = (cf.joule_on && !done) ? cf.jf : 0.0f;
+            const bool joule_tail = __any(jfl != 0.0f);
 #pragma unroll
             for (int q = 0; q < 2; ++q) {
                 if (q < tail) {
                     const int r = Cv - tail + q;
-#pragma unroll
-                    for (int v = 0; v < 2; ++v) {
-                        const uint32_t b = tail_bits >> (4 * (2 * q + v));
-                        tt[2 * q + v] = interior_cell<true>(col[(2 * (r - 1) + v) * NT], col[(2 * r + v) * NT], col[(2 * (r + 1) + v) * NT],
-                                                            g.k, g.tuf, (b & 1u) ? ps.conv_zone : ps.conv_base, tdiel, ps.adv,
-                                                            (b & 2u) ? jfl : 0.0f, alpha, tref);
-                    }
+                    const uint32_t ba = tail_bits >> (4 * (2 * q)), bb = tail_bits >> (4 * (2 * q + 1));
+                    const f2 tm = {col[(2 * (r - 1)) * NT], col[(2 * (r - 1) + 1) * NT]};
+                    const f2 tcc = {col[(2 * r) * NT], col[(2 * r + 1) * NT]};
+                    const f2 tp = {col[(2 * (r + 1)) * NT], col[(2 * (r + 1) + 1) * NT]};
+                    const f2 conv = {(ba & 1u) ? ps.conv_zone : ps.conv_base, (bb & 1u) ? ps.conv_zone : ps.conv_base};
+                    const f2 jfe = {(ba & 2u) ? jfl : 0.0f, (bb & 2u) ? jfl : 0.0f};
+                    ttp[q] = joule_tail ? interior2<true>(tm, tcc, tp, g.k, g.tuf, conv, tdiel, ps.adv, jfe, alpha, tref)
+                                        : interior2<false>(tm, tcc, tp, g.k, g.tuf, conv, tdiel, ps.adv, jfe, alpha, tref);
                 }
             }
         }
@@ -676,8 +680,9 @@ __global__ void __launch_bounds__((WW + 1) * 64, WEDM_SERVED_WAVES_PER_EU) wedm_
 #pragma unroll
                     for (int v = 0; v < 2; ++v) {
                         if ((tail_bits >> (4 * (2 * q + v))) & 4u) {  // interior: exists, counts, and is not the wire's last cell
-                            col[(2 * (Cv - tail + q) + v) * NT] = tt[2 * q + v];
-                            tmax = fmax_gt(tmax, tt[2 * q + v]);
+                            const float x = v ? ttp[q].y : ttp[q].x;
+                            col[(2 * (Cv - tail + q) + v) * NT] = x;
+                            tmax = fmax_gt(tmax, x);
                         }
                     }
                 }

@@ -1767,7 +1767,7 @@ def test_negative_plasma_heat_every_kernel_matches_oracle(segment_len):
         ran += 1
     assert ran >= 8 and int(cpu.state.spark_count.sum()) > 5 * n
     T = cpu.state.wire_temperature
-    assert float(torch.as_tensor(T[:, :]).min()) < 293.0      # cells cooled below the spool temperature by the negative heat
+    assert float(T.tensor().min()) < 293.0                      # cells cooled below the spool temperature by the negative heat
 
 
 # ------------------------------------------------------------------ the automatic launch plan

@@ -356,6 +356,10 @@ def test_wire_temperature_proxy_reads_gather_and_assignments_write_through():
     picked = wt[torch.tensor([0, 4])]                                   # advanced indexing: a plain copy, as on a NumPy array
     assert isinstance(picked, torch.Tensor) and picked.shape == (2, n)
     assert torch.stack([wt[0], wt[1]]).shape == (2, n)
+    import time
+    t0 = time.perf_counter()
+    assert torch.as_tensor(wt[:, :]).shape == (5, n) and len(list(wt)) == 5 and isinstance(next(iter(wt)), torch.Tensor)
+    assert time.perf_counter() - t0 < 1.0                              # (the sequence protocol walks one gathered copy)
     assert bool((env.state.T[32, :5, 1:] == np.float32(293.15)).all())  # padding still untouched
     env.state.wire_temperature = np.full(n, 300.0, dtype=np.float32)
     env.step_many(env.make_action(), 3)                                 # and the kernels' view is the same memory
