@@ -10,7 +10,7 @@ from pathlib import Path
 import pytest
 
 ROOT = Path(__file__).resolve().parents[1]
-R = ROOT / "profiles" / "r3"
+R = ROOT / "profiles" / "r4"
 
 
 def bench(name):
@@ -62,14 +62,15 @@ def test_headline_roofline_recomputes_from_profiles():
     assert b["value"] == pytest.approx(65536 * 1000 / (b["ms_per_step"] * 1e-3), rel=1e-9)
     assert rf["kernel_ms"] <= b["ms_per_step"] * 1.001
     assert "wedm_step_regs<2>" in kernel                                # the wire in the lanes' registers, two lanes per environment
-    avg_ms, calls = rocprof_avg_ms("rocprofv3_kernel_stats_config3.csv", "wedm_step_regs<128, 2>")
+    avg_ms, calls = rocprof_avg_ms("rocprofv3_kernel_stats_config3.csv", "wedm_step_regs<128, 2")
     assert calls >= 20 and avg_ms == pytest.approx(rf["kernel_ms"], rel=0.03)
     # traffic well above the algorithmic minimum would mean wasted re-reads: T + state in and out + obs = ~102 MB per
     # launch of 1000 us; the register kernel adds what its 8 scratch accesses per wave and microsecond (spilled state
     # registers around the scalar phases) leak past the L2: ~25 MB, 0.1 % of HBM time
     assert traffic["hbm_bytes_per_launch"] < 1.3 * 102e6
     assert b["cpu_baseline"]["kind"] == "port" and b["cpu_baseline"]["cores"] >= 1
-    assert len(b["side"]) == 5 and b["side"][3]["resets_per_env_per_launch"] > 0.05
+    # five side lines of the headline batch + the policy in the loop + the three other single-GPU BASELINE workloads (round 4)
+    assert len(b["side"]) == 9 and b["side"][3]["resets_per_env_per_launch"] > 0.05
     # a handle WITHOUT autoreset whose batch holds terminated (frozen) environments: its launches take no longer than the
     # quiet headline's (the register kernel walks under the mask of the live lanes; a wave of frozen lanes only skips work)
     frozen = b["side"][4]
@@ -145,3 +146,70 @@ def test_every_committed_bench_record_is_one_line_of_json():
     for f in files:
         b = json.loads(f.read_text())
         assert b["unit"] == "env-steps/s" and b["value"] > 0 and "roofline" in b, f.name
+
+
+def pmc(name):
+    return {l.split("\t")[2]: float(l.split("\t")[3]) for l in (R / name).read_text().splitlines()}
+
+
+def test_driver_line_times_the_other_baseline_workloads_and_a_policy_in_the_loop():
+    """Round 4: configs[1], the configs[3] shard and the configs[4] shard are side lines of the DRIVER's run, each with a
+    roofline block priced from this build's counter rows; the policy-in-the-loop line (a fresh dict of device tensors per
+    control step through WireEDMVectorEnv.step, under torch's sync-debug mode) stays within 3 % of the autoreset line."""
+    b = bench("bench_config3.json")
+    side = {s.get("workload", s["name"][:20]): s for s in b["side"]}
+    for w, kernel, floor in (("config2", "wedm_step_regs_wide<16>", 2.1e9), ("config4", "wedm_step_served<8>", 3.9e9),
+                             ("config5", "wedm_step_lanes_pk<8>", 2.4e9)):
+        line = side[w]
+        assert kernel in line["kernel"] and line["value"] >= floor, (w, line["kernel"], line["value"])
+        rf = line["roofline"]
+        assert rf["bound"] == "valu-issue" and rf["frac"] is not None and 0.0 < rf["frac"] <= 1.0
+        assert rf["achieved"] == pytest.approx(rf["valu_insts_per_env_step"] * line["value"], rel=0.02)
+        assert recorded("valu.json", line["kernel"])["build_id"] == b["config"]["build_id"]
+    policy = next(s for s in b["side"] if s["name"].startswith("policy in the loop"))
+    autoreset = b["side"][3]
+    assert policy["value"] >= 0.97 * autoreset["value"] and "sync-debug" in policy["timing"]
+
+
+def test_served_kernel_counters_against_the_kernel_it_replaced():
+    """32 768 x 400: the served kernel's wave-level VALU instructions per env-step against wedm_step_packed<8>'s, same batch,
+    same counters: fewer instructions, three blocks of four waves per CU, and the line is its kernel's."""
+    b = bench("bench_config4_shard.json")
+    assert "wedm_step_served<8>" in b["config"]["kernel"] and b["config"]["occupancy_blocks_per_cu"] == 3
+    served, packed = pmc("rocprofv3_pmc_sq_config4.txt"), pmc("rocprofv3_pmc_sq_config4_packed.txt")
+    per = lambda t: t["SQ_INSTS_VALU"] / (32768 * 1000)
+    assert per(served) == pytest.approx(b["roofline"]["valu_insts_per_env_step"], rel=1e-9)
+    assert per(served) < 92.0 < 100.0 < per(packed) < 105.0
+    assert served["SQ_WAVES"] == 1366 * 4 and packed["SQ_WAVES"] == 1024 * 4
+    assert b["value"] >= 4.0e9
+    avg_ms, calls = rocprof_avg_ms("rocprofv3_kernel_stats_config4.csv", "wedm_step_served<8")
+    assert calls >= 20 and avg_ms == pytest.approx(b["roofline"]["kernel_ms"], rel=0.03)
+    assert 0.6 < b["roofline"]["valu_pipe_busy"]["frac"] < 0.9
+
+
+def test_packed_any_geometry_kernel_counters_against_the_cell_by_cell_form():
+    b = bench("bench_config5_shard.json")
+    assert "wedm_step_lanes_pk<8>" in b["config"]["kernel"] and b["value"] >= 2.4e9
+    pk, cell = pmc("rocprofv3_pmc_sq_config5.txt"), pmc("rocprofv3_pmc_sq_config5_cellwise.txt")
+    assert pk["SQ_INSTS_VALU"] < 0.82 * cell["SQ_INSTS_VALU"] and cell["SQ_INSTS_VALU"] / (16384 * 1000) == pytest.approx(213.8, rel=0.01)
+    avg_ms, calls = rocprof_avg_ms("rocprofv3_kernel_stats_config5.csv", "wedm_step_lanes_pk<8")
+    assert calls >= 20 and avg_ms == pytest.approx(b["roofline"]["kernel_ms"], rel=0.03)
+
+
+def test_plan_sweep_record_has_no_cliff():
+    """profiles/r4/plan_sweep.txt: the automatic plan against every forced kernel over 40 shapes, on this build."""
+    txt = (R / "plan_sweep.txt").read_text()
+    assert bench("bench_config3.json")["config"]["build_id"] in txt.splitlines()[0]
+    rows = [l.split() for l in txt.splitlines() if l.startswith("  ") and not l.startswith("      ")]
+    assert len(rows) == 40
+    ratios = [float(r[-1] if r[-1] != "cliff" else r[-3]) for r in rows]
+    assert max(ratios) <= 1.07 and "cliff" not in txt
+    shapes = {(int(r[0]), int(r[1])) for r in rows}
+    assert {(16384, 128), (20480, 128), (4096, 400), (8192, 400), (32768, 400)} <= shapes
+
+
+def test_trace_launches_of_the_headline_batch_stay_on_the_register_kernel():
+    for name in ("bench_config3_trace_voltage.json", "bench_config3_trace_signals.json"):
+        b = bench(name)
+        assert "wedm_step_regs<2>" in b["config"]["kernel"]
+    assert bench("bench_config3_trace_voltage.json")["value"] >= 1.3e10
