@@ -70,7 +70,7 @@ def parse_args():
     ap.add_argument("--substeps", type=int, default=1000, help="physics microseconds per bench step")
     ap.add_argument("--workload", choices=["config3", "config2", "config4", "config5"], default="config3")
     ap.add_argument("--num-envs", type=int, default=0, help="override environments per GPU")
-    ap.add_argument("--kernel", type=int, default=0, help="0 auto, 1 global-memory, 2 LDS any-geometry (packed), 9 served packed, 10 LDS any-geometry cell by cell, 11 served any-geometry, 3 LDS fused, 4 LDS fused + packed f32, 5 global-memory split, 6 stream (single microseconds), 7 registers (one or two lanes per environment), 8 wide registers (4 / 8 / 16 lanes per environment)")
+    ap.add_argument("--kernel", type=int, default=0, help="0 auto, 1 global-memory, 2 LDS any-geometry (packed), 9 served packed, 10 LDS any-geometry cell by cell, 11 served any-geometry, 12 served registers, 3 LDS fused, 4 LDS fused + packed f32, 5 global-memory split, 6 stream (single microseconds), 7 registers (one or two lanes per environment), 8 wide registers (4 / 8 / 16 lanes per environment)")
     ap.add_argument("--lanes", type=int, default=0, help="lanes per environment in kernel 3 (0 auto)")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="target wall time of the cpu_baseline leg")
     ap.add_argument("--no-cpu-baseline", action="store_true")

@@ -410,7 +410,9 @@ int64_t wedm_trace_samples(wedm_ctx* ctx);
  * kernel 4), 10 = kernel 2's cell-by-cell form by name (since round 4 kernel 2 itself is the packed form -- two virtual
  * chunks per lane advanced in float2 registers, per-cell coefficients from the lane's own indices -- wherever the stencil is
  * float32; the cell-by-cell form remains for stencil_mode 1 and for A/B timing), 11 = the served form of kernel 2 (its walk
- * on three waves of a block, the scalar physics on the fourth, as kernel 9; by name only: not faster at BASELINE configs[4]).
+ * on three waves of a block, the scalar physics on the fourth, as kernel 9; by name only: not faster at BASELINE configs[4]),
+ * 12 = the served form of kernel 7 (two walker waves with the wire in registers + a scalar wave with all 64 lanes busy; by name
+ * only: 1.666e10 against kernel 7's 1.674e10 at the headline batch, spills; at most 128 segments, no trace sample).
  * All variants produce bit-identical results.  With wedm_params.stencil_mode 1 only 0, 1, 2 (= 10) and 3 are accepted (3: the tile walk with
  * per-cell coefficients, no stage-major / packed form).                                          */
 int32_t wedm_set_kernel(wedm_ctx* ctx, int32_t variant);

@@ -180,132 +180,7 @@ __global__ void __launch_bounds__(256, L) wedm_step_regs(const KArgs k) {
             halo_l = c == 0 ? spool : got;
             halo_r = c == 0 ? got : 0.0f;
         }
-        if (act) {  // (the lanes of terminated environments sit the walk out: their registers stay)
-            // a wave with a negative plasma heat walks every cell on the predicated formula (identical results, slower)
-            const bool all_slow = __any(cf.q < 0.0f);
-            // regular tiles of THIS microsecond: a contact-flag change inside a tile only matters while current flows
-            const float jf_lane = cf.joule_on ? cf.jf : 0.0f;
-            const bool joule_wave = __any(jf_lane != 0.0f);
-            const uint32_t n_now = all_slow ? 0u : (kind_n | kind_ne | (joule_wave ? 0u : kind_nj));
-            // the tiles that hold some lane's plasma cell (a lane's own cells only)
-            const int pcell = (cf.pidx >= 1 && cf.pidx >= base && cf.pidx < base + 2 * H) ? cf.pidx - base : -1;  // lane-local
-            uint32_t ptiles = 0u;
-            if (__any(pcell >= 0)) {
-                const int pt = pcell >= 0 ? ((pcell & (H - 1)) >> 3) : -1;
-#pragma unroll
-                for (int t = 0; t < H / 8; ++t) ptiles |= __any(pt == t) ? (1u << t) : 0u;
-            }
-            // tiles that need more than the regular code without a Joule term
-            const uint32_t general = ~n_now | (joule_wave ? joule_any : 0u) | ptiles | last_tile;
-            f2 leftp = f2{halo_l, a_last};  // OLD pair before the tile
-#pragma unroll
-            for (int t = 0; t < H / 8; ++t) {
-                if (t < n_tiles) {
-                    const int j = 8 * t;
-                    f2 tm[8], tc[8], tp[8], pn[8];
-#pragma unroll
-                    for (int u = 0; u < 8; ++u) {
-                        tc[u] = P[j + u];
-                        tm[u] = u == 0 ? leftp : P[j + u - 1];
-                        tp[u] = (j + u + 1 < H) ? P[j + u + 1 < H ? j + u + 1 : 0] : f2{b_first, halo_r};
-                    }
-                    leftp = tc[7];
-                    f2 cv[4], jv[4];
-                    cv[0] = convp[t];
-                    f2 tmA[4], tcA[4], tpA[4], pnA[4], tmB[4], tcB[4], tpB[4], pnB[4];
-#pragma unroll
-                    for (int u = 0; u < 4; ++u) { tmA[u] = tm[u]; tcA[u] = tc[u]; tpA[u] = tp[u]; tmB[u] = tm[4 + u]; tcB[u] = tc[4 + u]; tpB[u] = tp[4 + u]; }
-                    if (!((general >> t) & 1u)) {
-                        jv[0] = f2{0.0f, 0.0f};
-                        quad_staged<false, false, SW>(tmA, tcA, tpA, pnA, g.k, g.tuf, cv, tdiel, ps.adv, jv, alpha, tref);
-                        quad_staged<false, false, SW>(tmB, tcB, tpB, pnB, g.k, g.tuf, cv, tdiel, ps.adv, jv, alpha, tref);
-#pragma unroll
-                        for (int u = 0; u < 4; ++u) { pn[u] = pnA[u]; pn[4 + u] = pnB[u]; }
-                        if (t == 0) pn[0].x = (c == 0) ? spool : pn[0].x;  // wire cell 0
-                        float m0 = max3_raw(tmax, pn[0].x, pn[0].y), m1 = max3_raw(pn[1].x, pn[1].y, pn[2].x);
-                        m0 = max3_raw(m0, pn[2].y, pn[3].x); m1 = max3_raw(m1, pn[3].y, pn[4].x);
-                        m0 = max3_raw(m0, pn[4].y, pn[5].x); m1 = max3_raw(m1, pn[5].y, pn[6].x);
-                        m0 = max3_raw(m0, pn[6].y, pn[7].x);
-                        tmax = max3_raw(m0, m1, pn[7].y);
-                    } else if (((n_now | (all_slow ? 0u : kind_nj)) >> t) & 1u) {
-                        // regular, with odd cells: a Joule term, the wire's last cell, plasma cells
-                        jv[0] = f2{((jouleA >> t) & 1u) ? jf_lane : 0.0f, ((jouleB >> t) & 1u) ? jf_lane : 0.0f};
-                        if (!((n_now >> t) & 1u)) {
-                            // a contact index inside the tile while current flows (kind_nj; the zone flag is uniform): the Joule
-                            // coefficient cell by cell from the table
-                            f2 jq[8];
-#pragma unroll
-                            for (int u = 0; u < 8; ++u) {
-                                const uint32_t zj = wt->zj[j + u];
-                                jq[u] = f2{((zj >> (16 + 2 * c)) & 1u) ? jf_lane : 0.0f, ((zj >> (17 + 2 * c)) & 1u) ? jf_lane : 0.0f};
-                            }
-                            f2 jvA[4], jvB[4];
-#pragma unroll
-                            for (int u = 0; u < 4; ++u) { jvA[u] = jq[u]; jvB[u] = jq[4 + u]; }
-                            quad_staged<true, true, SW>(tmA, tcA, tpA, pnA, g.k, g.tuf, cv4(cv[0]).v, tdiel, ps.adv, jvA, alpha, tref);
-                            quad_staged<true, true, SW>(tmB, tcB, tpB, pnB, g.k, g.tuf, cv4(cv[0]).v, tdiel, ps.adv, jvB, alpha, tref);
-                        } else if (joule_wave && ((joule_any >> t) & 1u)) {
-                            quad_staged<true, false, SW>(tmA, tcA, tpA, pnA, g.k, g.tuf, cv, tdiel, ps.adv, jv, alpha, tref);
-                            quad_staged<true, false, SW>(tmB, tcB, tpB, pnB, g.k, g.tuf, cv, tdiel, ps.adv, jv, alpha, tref);
-                        } else {
-                            quad_staged<false, false, SW>(tmA, tcA, tpA, pnA, g.k, g.tuf, cv, tdiel, ps.adv, jv, alpha, tref);
-                            quad_staged<false, false, SW>(tmB, tcB, tpB, pnB, g.k, g.tuf, cv, tdiel, ps.adv, jv, alpha, tref);
-                        }
-#pragma unroll
-                        for (int u = 0; u < 4; ++u) { pn[u] = pnA[u]; pn[4 + u] = pnB[u]; }
-                        if (t == 0) pn[0].x = (c == 0) ? spool : pn[0].x;  // wire cell 0
-                        // the last cell (last position of the last chunk's tile): out of the regular maximum, predicated formula
-                        const bool has_last = ((last_tile >> t) & 1u) && owns_last;
-                        float m0 = max3_raw(tmax, pn[0].x, pn[0].y), m1 = max3_raw(pn[1].x, pn[1].y, pn[2].x);
-                        m0 = max3_raw(m0, pn[2].y, pn[3].x); m1 = max3_raw(m1, pn[3].y, pn[4].x);
-                        m0 = max3_raw(m0, pn[4].y, pn[5].x); m1 = max3_raw(m1, pn[5].y, pn[6].x);
-                        m0 = max3_raw(m0, pn[6].y, pn[7].x);
-                        tmax = max3_raw(m0, m1, has_last ? spool : pn[7].y);
-                        if ((last_tile >> t) & 1u) {
-                            const float x = stencil_cell(base + H + j + 7, nw, tm[7].y, tc[7].y, 0.0f, gw, cf, ps, tref, alpha, tdiel);
-                            pn[7].y = has_last ? x : pn[7].y;
-                            tmax = has_last ? fmax_gt(tmax, x) : tmax;
-                        }
-                        // plasma cells of the lanes that have one in this tile: the predicated formula from the same OLD values
-                        // (the regular value stays in the maximum, as where the LDS kernels patch the cell after the walk)
-                        if ((ptiles >> t) & 1u) {
-#pragma unroll
-                            for (int u = 0; u < 8; ++u) {
-                                if (__any(pcell == j + u)) {
-                                    const float x = stencil_cell(base + j + u, nw, (base + j + u == 1) ? spool : tm[u].x, tc[u].x, tp[u].x, gw, cf, ps, tref, alpha, tdiel);
-                                    pn[u].x = (pcell == j + u) ? x : pn[u].x;
-                                    tmax = (pcell == j + u) ? fmax_gt(tmax, x) : tmax;
-                                }
-                                if (__any(pcell == H + j + u)) {
-                                    const float x = stencil_cell(base + H + j + u, nw, tm[u].y, tc[u].y, tp[u].y, gw, cf, ps, tref, alpha, tdiel);
-                                    pn[u].y = (pcell == H + j + u) ? x : pn[u].y;
-                                    tmax = (pcell == H + j + u) ? fmax_gt(tmax, x) : tmax;
-                                }
-                            }
-                        }
-                    } else {
-                        // not regular in this microsecond: every cell that exists on the predicated formula
-#pragma unroll
-                        for (int u = 0; u < 8; ++u) {
-                            pn[u] = tc[u];
-                            const int ia = base + j + u, ib = base + H + j + u;
-                            {
-                                const float x = (ia >= 1) ? stencil_cell(ia, nw, (ia == 1) ? spool : tm[u].x, tc[u].x, tp[u].x, gw, cf, ps, tref, alpha, tdiel) : spool;
-                                pn[u].x = ia < nw ? x : pn[u].x;
-                                tmax = ia < nw ? fmax_gt(tmax, x) : tmax;
-                            }
-                            {
-                                const float x = stencil_cell(ib, nw, tm[u].y, tc[u].y, tp[u].y, gw, cf, ps, tref, alpha, tdiel);
-                                pn[u].y = ib < nw ? x : pn[u].y;
-                                tmax = ib < nw ? fmax_gt(tmax, x) : tmax;
-                            }
-                        }
-                    }
-#pragma unroll
-                    for (int u = 0; u < 8; ++u) P[j + u] = pn[u];
-                }
-            }
-        }
+#include "wedm_regs_walk.inc"
         if (L == 2) tmax = fmax_gt(tmax, __int_as_float(swap_with_neighbour(__float_as_int(tmax))));
         unfreeze_wire(hv, s);
         if (!s.done) {

@@ -77,6 +77,8 @@ using namespace wedm;
 #define WEDM_LANES_SERVED_LIST(X) X(4) X(8) X(16)
 #define WEDM_INST_LANES_SERVED(L) template __global__ void wedm_step_lanes_served<L>(const KArgs);
 #define WEDM_EXT_LANES_SERVED(L) extern template __global__ void wedm_step_lanes_served<L>(const KArgs);
+#define WEDM_INST_REGS_SERVED template __global__ void wedm_step_regs_served<128>(const KArgs);
+#define WEDM_EXT_REGS_SERVED extern template __global__ void wedm_step_regs_served<128>(const KArgs);
 #define WEDM_INST_SERVED(L, ex) template __global__ void wedm_step_served<L, ex>(const KArgs);
 #define WEDM_EXT_SERVED(L, ex) extern template __global__ void wedm_step_served<L, ex>(const KArgs);
 #if defined(WEDM_PART) && WEDM_PART == 1
@@ -86,6 +88,7 @@ WEDM_FUSED_LIST(WEDM_INST_FUSED)
 WEDM_FUSED_F64_LIST(WEDM_INST_FUSED_F64)
 #elif defined(WEDM_PART) && WEDM_PART == 3
 WEDM_SERVED_LIST(WEDM_INST_SERVED)
+WEDM_INST_REGS_SERVED
 WEDM_LANES_PK_LIST(WEDM_INST_LANES_PK)
 WEDM_LANES_SERVED_LIST(WEDM_INST_LANES_SERVED)
 #else
@@ -94,6 +97,7 @@ WEDM_PACKED_LIST(WEDM_EXT_PACKED)
 WEDM_FUSED_LIST(WEDM_EXT_FUSED)
 WEDM_FUSED_F64_LIST(WEDM_EXT_FUSED_F64)
 WEDM_SERVED_LIST(WEDM_EXT_SERVED)
+WEDM_EXT_REGS_SERVED
 WEDM_LANES_PK_LIST(WEDM_EXT_LANES_PK)
 WEDM_LANES_SERVED_LIST(WEDM_EXT_LANES_SERVED)
 #endif
@@ -627,6 +631,9 @@ static int32_t plan_launch(wedm_ctx* ctx, bool single, bool tr, bool frozen_ok, 
     if (variant == 9 && !served_ok)
         return fail(ctx, WEDM_ERR_UNSUPPORTED, "wedm_step: served kernel needs uniform geometry, the float32 stencil, lanes 4 or 8, two chunks that fit in LDS and freeze_terminated");
     if (variant == 9 && tr) variant = packed_ok ? 4 : fused_ok ? 3 : (lanes_ok || use_pk) ? 2 : 1;
+    // kernel 12 (served register kernel): the register kernel's conditions + what the served scalar wave does not do
+    if (variant == 12 && (!regs_ok || tr || P.keep_stepping_terminated))
+        return fail(ctx, WEDM_ERR_UNSUPPORTED, "wedm_step: served register kernel needs uniform geometry, at most 128 segments, the float32 stencil, no trace sample in the launch and freeze_terminated");
     if (variant == 7 && !regs_ok)
         return fail(ctx, WEDM_ERR_UNSUPPORTED, "wedm_step: register kernel needs uniform geometry, at most 128 segments and the float32 stencil");
     if (variant == 3 && !fused_ok)
@@ -696,6 +703,13 @@ static int32_t plan_launch(wedm_ctx* ctx, bool single, bool tr, bool frozen_ok, 
         fn = f64 ? (tr ? pick_lanes<true, true>(glanes) : pick_lanes<false, true>(glanes))
                  : (tr ? pick_lanes<true, false>(glanes) : pick_lanes<false, false>(glanes));
         std::snprintf(out.name, sizeof(out.name), "wedm_step_lanes<%d>%s<<<%d,256,%zuB>>>", glanes, f64 ? "[f64 stencil]" : "", grid, fl);
+    } else if (variant == 12) {
+        grid = (ctx->num_envs + 63) / 64;
+        fl = sizeof(ServedBox<64>);
+        out.walk = ctx->walk_dev + 11;  // four chunks of 32 cells
+        out.block = 192;                // two walker waves + the scalar wave
+        fn = (const void*)wedm_step_regs_served<128>;
+        std::snprintf(out.name, sizeof(out.name), "wedm_step_regs_served<<<%d,192,%zuB>>>", grid, fl);
     } else if (variant == 9) {
         grid = (ctx->num_envs + 192 / svl - 1) / (192 / svl);
         fl = (2 * (size_t)ctx->walk_C[svi] + 2) * 768 + sv_box;
@@ -735,7 +749,7 @@ static int32_t plan_launch(wedm_ctx* ctx, bool single, bool tr, bool frozen_ok, 
     }
     out.fn = fn;
     out.grid = grid;
-    if (variant != 9) out.block = 256;
+    if (variant != 9 && variant != 12) out.block = 256;
     out.lds = fl;
     out.valid = true;
     return WEDM_OK;
@@ -953,7 +967,7 @@ int32_t wedm_bind_rng_replay(wedm_ctx* ctx, const double* table, int64_t n_steps
 
 int32_t wedm_set_kernel(wedm_ctx* ctx, int32_t variant) {
     if (!ctx) return WEDM_ERR_BAD_ARG;
-    if (variant < 0 || variant > 11) return fail(ctx, WEDM_ERR_BAD_ARG, "wedm_set_kernel: variant must be 0..11");
+    if (variant < 0 || variant > 12) return fail(ctx, WEDM_ERR_BAD_ARG, "wedm_set_kernel: variant must be 0..12");
     ctx->variant = variant;
     ctx->invalidate_plans();
     return WEDM_OK;

@@ -712,7 +712,141 @@ __global__ void __launch_bounds__((WW + 1) * 64, WEDM_SERVED_WAVES_PER_EU) wedm_
     copy_wire_nt<L, NT, false>(cold->s.T, stride, e0, k.num_envs, n, tid, lds, wire_slot);
 }
 
-// (A served form of the register kernel -- wedm_step_regs<128, 2>'s walk on two walker waves, the scalar physics of their 64
-// environments on a third, four blocks of three waves per CU -- was written and not kept: the walk with 64 wire registers per
-// lane wants 239 registers and spills 52 at the 168 that three waves per SIMD leave; at 256 registers the chip holds 6 waves per
-// CU instead of today's 8 and the batch needs two rounds.)
+// ============================================ served register kernel: the wire in the walkers' registers, no LDS image
+// wedm_step_regs<128, 2>'s walk (wedm_regs_walk.inc) on TWO walker waves of a block -- two lanes per environment, 32 packed
+// pairs each --, the scalar physics of the block's 64 environments on a third wave, all 64 of its lanes busy.  Blocks of three
+// waves, four to a CU at 168 registers: 256 environments per CU, 65 536 in ONE round.  LDS holds the mailbox only.
+// By name only (kernel 12), measured at 65 536 x 128 (round 4): fused launches 1.666e10 env-steps/s against wedm_step_regs<128, 2>'s
+// 1.674e10 -- a sixth fewer instructions, given back by spills: the walk with 64 wire registers per lane wants 239 registers
+// and spills 53 at the 168 that three waves per SIMD leave, the scalar wave 113 -- and launches of ONE microsecond 41.7 us
+// against wedm_step_stream's 20.4 us (every state row loaded and stored, scratch traffic cold at every launch).
+template <int CELLS>
+__global__ void __launch_bounds__(192, WEDM_SERVED_WAVES_PER_EU) wedm_step_regs_served(const KArgs k) {
+    constexpr int L = 2, H = CELLS / (2 * L), EPB = 64, NT = 128;
+    static_assert(H % 8 == 0 && H / 8 <= 16, "whole tiles");
+    constexpr int SW = WEDM_REGS_SW2;
+    typedef ServedBox<EPB> Box;
+    const ColdRef cold = kernarg_cold();
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    volatile Box* const box = (volatile Box*)lds;
+    const int tid = threadIdx.x;
+    const int64_t e0 = (int64_t)blockIdx.x * EPB;
+    SvStamps svs;
+    sv_stamps_begin(svs);
+    unsigned long long* const stamp_row = k.dbg ? k.dbg + ((size_t)blockIdx.x * 3 + (tid >> 6)) * 12 : nullptr;
+    if (tid == 0) { box->cf_seq = 0u; box->tm_seq[0] = 0u; box->tm_seq[1] = 0u; box->tm_seq[2] = 0u; box->tm_seq[3] = 0u; }
+    if (tid >= NT) {
+        served_scalar_wave<EPB, L>(k, cold, box, e0, tid - NT, svs, stamp_row);
+        return;
+    }
+
+    // ---------------------------------------------------------------------------------------------------- the walker waves
+    const int c = tid % L, el = tid / L, wave = tid >> 6;
+    const int64_t e = e0 + el;
+    const bool live = e < k.num_envs;
+    const WalkTable* __restrict__ wt = k.walk;  // 2 L chunks of H cells
+    const int n = k.hot.n_seg;
+    const int64_t stride = cold->s.stride;
+    const int base = c * 2 * H;  // this lane's first cell
+    const float spool = k.hot.spool, tref = k.hot.tref, alpha = k.hot.alpha, tdiel = k.hot.tdiel;
+    // the wire first: word q = cells 4 q .. 4 q + 3 of this environment, 16 bytes per lane
+    const int nq = (n + 3) >> 2;
+    float* const Te = cold->s.T + (live ? e : 0) * 4;
+    const int q0 = base / 4;  // this lane's first word
+    f2 P[H];
+#pragma unroll
+    for (int q = 0; q < H / 4; ++q) {
+        const f4v a = (q0 + q < nq) ? *(const f4v*)(Te + (int64_t)(q0 + q) * stride * 4) : f4v{0.0f, 0.0f, 0.0f, 0.0f};
+        const f4v b = (q0 + H / 4 + q < nq) ? *(const f4v*)(Te + (int64_t)(q0 + H / 4 + q) * stride * 4) : f4v{0.0f, 0.0f, 0.0f, 0.0f};
+#pragma unroll
+        for (int u = 0; u < 4; ++u) P[4 * q + u] = f2{a[u], b[u]};
+    }
+    Geom g;
+    load_geom(k.hot, cold, 0, g);  // uniform geometry
+    // next-step autoreset: the environment's wire starts at the spool temperature (the scalar wave re-initialises the state)
+    const bool reinit = live && WEDM_AUTORESET(cold) && cold->s.i8[(int64_t)WEDM_B_DONE * stride + e] != 0;
+    if (__any(reinit)) {
+#pragma unroll
+        for (int m = 0; m < H; ++m) P[m] = reinit ? f2{spool, spool} : P[m];
+    }
+    if (c == 0) P[0].x = spool;  // wire cell 0 is held at the spool temperature (wire.py:83)
+    // tile flags of this lane's two chunks (bit t: the tile's first cell lies in the workpiece zone / between the contacts)
+    const int n_tiles = wt->n_tiles;
+    uint32_t zoneA = 0u, zoneB = 0u, jouleA = 0u, jouleB = 0u, joule_any = 0u;
+    for (int t = 0; t < n_tiles; ++t) {
+        const uint32_t lo = wt->zj[8 * t];
+        zoneA |= ((lo >> (2 * c)) & 1u) << t;       zoneB |= ((lo >> (2 * c + 1)) & 1u) << t;
+        jouleA |= ((lo >> (16 + 2 * c)) & 1u) << t; jouleB |= ((lo >> (17 + 2 * c)) & 1u) << t;
+        joule_any |= ((lo >> 16) != 0u ? 1u : 0u) << t;
+    }
+    joule_any = __builtin_amdgcn_readfirstlane(joule_any);
+    const uint32_t kind_n = __builtin_amdgcn_readfirstlane(wt->kind_n_mask);
+    const uint32_t kind_ne = __builtin_amdgcn_readfirstlane(wt->kind_ne_mask), kind_nj = __builtin_amdgcn_readfirstlane(wt->kind_nj_mask);
+    const int last_base = (2 * L - 1) * H;
+    const uint32_t last_tile = (n > last_base) ? (1u << ((n - 1 - last_base) >> 3)) : 0u;
+    const bool owns_last = c == L - 1;
+    __syncthreads();  // (A) the mailbox is initialised, the scalar wave has published the advection coefficients
+    Persist ps{box->adv[el], 0.0f, 0.0f, 0};
+    f2 convp[H / 8];  // the convection coefficient pair (chunk A, chunk B) of every tile, from the published coefficients
+
+    WEDM_SV_LOOP_START();
+    for (int it = 0; it < k.n_substeps; ++it) {
+        const int slot = it & 1;
+        { WEDM_SV_WAIT_BEGIN(); sv_wait(&box->cf_seq, (uint32_t)it + 1u); WEDM_SV_WAIT_END(); }
+        WEDM_SV_PHASE_START();
+        const int32_t fl = box->flags[slot][el];
+        if (fl & SV_STOP) break;  // (block-wide: every lane reads it)
+        Coef cf{box->jf[slot][el], box->q[slot][el], (fl & SV_JOULE) ? 1 : 0, box->pidx[slot][el]};
+        ps.conv_base = box->conv_base[slot][el];
+        ps.conv_zone = box->conv_zone[slot][el];
+        ps.adv_on = (fl & SV_ADV) ? 1 : 0;
+        const bool act = live && !(fl & SV_DONE);
+#pragma unroll
+        for (int t = 0; t < H / 8; ++t)
+            convp[t] = f2{((zoneA >> t) & 1u) ? ps.conv_zone : ps.conv_base, ((zoneB >> t) & 1u) ? ps.conv_zone : ps.conv_base};
+        float tmax = spool;
+        asm volatile("" : "+v"(zoneA), "+v"(zoneB), "+v"(jouleA), "+v"(jouleB));  // (see wedm_step_regs: the rare code's predicates stay where they are used)
+        Geom gw = g;
+        gw.n_seg = __builtin_amdgcn_readfirstlane(g.n_seg); gw.az_start = __builtin_amdgcn_readfirstlane(g.az_start);
+        gw.az_end = __builtin_amdgcn_readfirstlane(g.az_end); gw.cb = __builtin_amdgcn_readfirstlane(g.cb);
+        gw.ct = __builtin_amdgcn_readfirstlane(g.ct);
+        asm volatile("" : "+s"(gw.n_seg), "+s"(gw.az_start), "+s"(gw.az_end), "+s"(gw.cb), "+s"(gw.ct));
+        int nw = __builtin_amdgcn_readfirstlane(n);
+        asm volatile("" : "+s"(nw));
+        // halos, OLD values (every lane takes part in the exchange, frozen environments included)
+        const float a_last = P[H - 1].x, b_first = P[0].y;
+        const float give = c == 0 ? P[H - 1].y : P[0].x;
+        const float got = __int_as_float(swap_with_neighbour(__float_as_int(give)));
+        const float halo_l = c == 0 ? spool : got, halo_r = c == 0 ? got : 0.0f;
+        WEDM_SV_PHASE(pa);
+#define WEDM_REGS_WALK_TILE_FENCE 1
+#include "wedm_regs_walk.inc"
+#undef WEDM_REGS_WALK_TILE_FENCE
+        WEDM_SV_PHASE(pb);
+        tmax = fmax_gt(tmax, __int_as_float(swap_with_neighbour(__float_as_int(tmax))));
+        if (c == 0) box->tmax[slot][el] = tmax;
+        asm volatile("" ::: "memory");
+        if ((tid & 63) == 0) box->tm_seq[wave] = (uint32_t)it + 1u;
+        WEDM_SV_PHASE(pc);
+    }
+    WEDM_SV_LOOP_END();
+    sv_stamps_out(svs, stamp_row);
+
+    if (live) {
+#pragma unroll
+        for (int q = 0; q < 2 * H / 4; ++q) {
+            const int m = (q % (H / 4)) * 4;
+            const bool hi = q >= H / 4;
+            const f4v w = hi ? f4v{P[m].y, P[m + 1].y, P[m + 2].y, P[m + 3].y} : f4v{P[m].x, P[m + 1].x, P[m + 2].x, P[m + 3].x};
+            const int cell = base + 4 * q;
+            if (cell + 3 < n) {
+                *(f4v*)(Te + (int64_t)(q0 + q) * stride * 4) = w;
+            } else {  // the wire's last, partial word: the cells past the end are padding and keep their value
+#pragma unroll
+                for (int u = 0; u < 4; ++u)
+                    if (cell + u < n) Te[(int64_t)(q0 + q) * stride * 4 + u] = w[u];
+            }
+        }
+    }
+    __syncthreads();  // (B)
+}

@@ -427,7 +427,8 @@ class WireEDMEnv:
         batches), 9 = served kernel (kernel 4's walk with the float64 scalar physics of a block's environments on a wave
         of its own, one microsecond ahead of the walking waves: 4 or 8 lanes per environment, uniform geometry);
         10 = kernel 2's cell-by-cell form by name (kernel 2 is its packed form wherever the stencil is float32), 11 = the served
-        form of kernel 2; ``lanes`` lanes per environment for 2/3/4/6/8/9/10/11 (0 = auto).  All variants are bit-identical."""
+        form of kernel 2, 12 = the served form of kernel 7; ``lanes`` lanes per environment for 2/3/4/6/8/9/10/11 (0 = auto).
+        All variants are bit-identical."""
         self._backend.set_kernel(variant)
         if hasattr(self._backend, "set_lanes"):
             self._backend.set_lanes(lanes)

@@ -181,7 +181,7 @@ def test_single_microsecond_steps_with_changing_actions():
     assert torch.equal(tg.cpu(), tc)
 
 
-@pytest.mark.parametrize("variant,lanes", KERNELS + [(7, 0)] + SERVED)
+@pytest.mark.parametrize("variant,lanes", KERNELS + [(7, 0), (12, 0)] + SERVED)
 def test_config3_grid_128_segments(variant, lanes):
     """BASELINE config 3: segment_len 0.625 -> 128 segments."""
     n = 1024
