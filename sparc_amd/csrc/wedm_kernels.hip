@@ -79,6 +79,10 @@ using namespace wedm;
 #define WEDM_EXT_LANES_SERVED(L) extern template __global__ void wedm_step_lanes_served<L>(const KArgs);
 #define WEDM_INST_REGS_SERVED template __global__ void wedm_step_regs_served<128>(const KArgs);
 #define WEDM_EXT_REGS_SERVED extern template __global__ void wedm_step_regs_served<128>(const KArgs);
+// stencil_mode 1 on the register kernel: <128, L, TRACE, F64 = true>
+#define WEDM_REGS_F64_LIST(X) X(1, false) X(1, true) X(2, false) X(2, true)
+#define WEDM_INST_REGS_F64(L, tr) template __global__ void wedm_step_regs<128, L, tr, true>(const KArgs);
+#define WEDM_EXT_REGS_F64(L, tr) extern template __global__ void wedm_step_regs<128, L, tr, true>(const KArgs);
 #define WEDM_INST_SERVED(L, ex) template __global__ void wedm_step_served<L, ex>(const KArgs);
 #define WEDM_EXT_SERVED(L, ex) extern template __global__ void wedm_step_served<L, ex>(const KArgs);
 #if defined(WEDM_PART) && WEDM_PART == 1
@@ -89,6 +93,7 @@ WEDM_FUSED_F64_LIST(WEDM_INST_FUSED_F64)
 #elif defined(WEDM_PART) && WEDM_PART == 3
 WEDM_SERVED_LIST(WEDM_INST_SERVED)
 WEDM_INST_REGS_SERVED
+WEDM_REGS_F64_LIST(WEDM_INST_REGS_F64)
 WEDM_LANES_PK_LIST(WEDM_INST_LANES_PK)
 WEDM_LANES_SERVED_LIST(WEDM_INST_LANES_SERVED)
 #else
@@ -98,6 +103,7 @@ WEDM_FUSED_LIST(WEDM_EXT_FUSED)
 WEDM_FUSED_F64_LIST(WEDM_EXT_FUSED_F64)
 WEDM_SERVED_LIST(WEDM_EXT_SERVED)
 WEDM_EXT_REGS_SERVED
+WEDM_REGS_F64_LIST(WEDM_EXT_REGS_F64)
 WEDM_LANES_PK_LIST(WEDM_EXT_LANES_PK)
 WEDM_LANES_SERVED_LIST(WEDM_EXT_LANES_SERVED)
 #endif
@@ -544,10 +550,13 @@ static int32_t plan_launch(wedm_ctx* ctx, bool single, bool tr, bool frozen_ok, 
     }
     const bool f64 = P.stencil_mode != 0;
     if (f64) {
-        // Numba's typing of the stencil: the fused tile walk (uniform geometry), the predicated LDS kernel (any geometry),
-        // or in place in global memory; no packed form, no single-microsecond kernels
-        if (variant != 0 && variant != 1 && variant != 2 && variant != 3 && variant != 10)
-            return fail(ctx, WEDM_ERR_UNSUPPORTED, "wedm_step: stencil_mode 1 (float64 stencil expressions) runs on kernels 1, 2 (10) and 3 only");
+        // Numba's typing of the stencil: the register kernel (uniform geometry, at most 128 segments), the fused tile walk
+        // (uniform geometry), the predicated LDS kernel (any geometry), or in place in global memory; no packed form, no
+        // single-microsecond kernels
+        if (variant != 0 && variant != 1 && variant != 2 && variant != 3 && variant != 7 && variant != 10)
+            return fail(ctx, WEDM_ERR_UNSUPPORTED, "wedm_step: stencil_mode 1 (float64 stencil expressions) runs on kernels 1, 2 (10), 3 and 7 only");
+        // (the register kernel from the batch size at which it also takes the float32 launch)
+        if (variant == 0 && !single && uniform && ctx->walk_regs_ok && ctx->n_seg_max <= 128 && ctx->lanes == 0 && ctx->num_envs >= 20480) variant = 7;
         if (variant == 0) variant = (!single && fused_ok) ? 3 : (lanes_ok ? 2 : 1);
     }
     // kernel 2 is the packed form where it applies (float32 stencil, no injected variates); kernel 10 names the cell-by-cell
@@ -569,7 +578,7 @@ static int32_t plan_launch(wedm_ctx* ctx, bool single, bool tr, bool frozen_ok, 
         return fail(ctx, WEDM_ERR_UNSUPPORTED, "wedm_step: wide register kernel needs uniform geometry, 9 to 512 segments, the float32 stencil and lanes 0, 4, 8 or 16 with 32 cells per lane covering the wire");
     // kernel 7 (register kernel): one or two lanes per environment with the wire in their registers; wires of at most 128
     // segments, uniform geometry, float32 stencil; a launch with a trace sample runs its TRACE instantiation
-    const bool regs_ok = uniform && ctx->walk_regs_ok && ctx->n_seg_max <= 128 && !f64 && !ctx->replay;
+    const bool regs_ok = uniform && ctx->walk_regs_ok && ctx->n_seg_max <= 128 && !ctx->replay;
     if (variant == 0) {
         // fused launches of a batch that gives most CUs a block of the register kernel (measured, 128 segments, two lanes
         // per environment against the best LDS kernel: 8 192 environments 2.8e9 vs 3.5e9, 16 384: 5.5e9 vs 6.1e9,
@@ -632,10 +641,10 @@ static int32_t plan_launch(wedm_ctx* ctx, bool single, bool tr, bool frozen_ok, 
         return fail(ctx, WEDM_ERR_UNSUPPORTED, "wedm_step: served kernel needs uniform geometry, the float32 stencil, lanes 4 or 8, two chunks that fit in LDS and freeze_terminated");
     if (variant == 9 && tr) variant = packed_ok ? 4 : fused_ok ? 3 : (lanes_ok || use_pk) ? 2 : 1;
     // kernel 12 (served register kernel): the register kernel's conditions + what the served scalar wave does not do
-    if (variant == 12 && (!regs_ok || tr || P.keep_stepping_terminated))
+    if (variant == 12 && (!regs_ok || f64 || tr || P.keep_stepping_terminated))
         return fail(ctx, WEDM_ERR_UNSUPPORTED, "wedm_step: served register kernel needs uniform geometry, at most 128 segments, the float32 stencil, no trace sample in the launch and freeze_terminated");
     if (variant == 7 && !regs_ok)
-        return fail(ctx, WEDM_ERR_UNSUPPORTED, "wedm_step: register kernel needs uniform geometry, at most 128 segments and the float32 stencil");
+        return fail(ctx, WEDM_ERR_UNSUPPORTED, "wedm_step: register kernel needs uniform geometry and at most 128 segments");
     if (variant == 3 && !fused_ok)
         return fail(ctx, WEDM_ERR_UNSUPPORTED, "wedm_step: fused kernel needs uniform geometry and a chunk that fits in LDS");
     if (variant == 4 && !packed_ok)
@@ -660,9 +669,11 @@ static int32_t plan_launch(wedm_ctx* ctx, bool single, bool tr, bool frozen_ok, 
         const int rl = ctx->lanes == 1 ? 1 : 2;  // lanes per environment (default 2: two waves per SIMD)
         grid = (ctx->num_envs + 256 / rl - 1) / (256 / rl);
         out.walk = ctx->walk_dev + (rl == 1 ? 10 : 11);  // two chunks of 64 cells / four of 32
-        fn = tr ? (rl == 1 ? (const void*)wedm_step_regs<128, 1, true> : (const void*)wedm_step_regs<128, 2, true>)
+        fn = f64 ? (tr ? (rl == 1 ? (const void*)wedm_step_regs<128, 1, true, true> : (const void*)wedm_step_regs<128, 2, true, true>)
+                       : (rl == 1 ? (const void*)wedm_step_regs<128, 1, false, true> : (const void*)wedm_step_regs<128, 2, false, true>))
+           : tr ? (rl == 1 ? (const void*)wedm_step_regs<128, 1, true> : (const void*)wedm_step_regs<128, 2, true>)
                 : (rl == 1 ? (const void*)wedm_step_regs<128, 1> : (const void*)wedm_step_regs<128, 2>);
-        std::snprintf(out.name, sizeof(out.name), "wedm_step_regs<%d><<<%d,256>>>", rl, grid);
+        std::snprintf(out.name, sizeof(out.name), "wedm_step_regs<%d>%s<<<%d,256>>>", rl, f64 ? "[f64 stencil]" : "", grid);
     } else if (variant == 8) {
         grid = (ctx->num_envs + 256 / wl - 1) / (256 / wl);
         fn = tr ? (wl == 4 ? (const void*)wedm_step_regs_wide<16, 4, true, true> : wl == 8 ? (const void*)wedm_step_regs_wide<16, 8, true, true>

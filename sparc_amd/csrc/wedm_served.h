@@ -819,6 +819,9 @@ __global__ void __launch_bounds__(192, WEDM_SERVED_WAVES_PER_EU) wedm_step_regs_
         const float got = __int_as_float(swap_with_neighbour(__float_as_int(give)));
         const float halo_l = c == 0 ? spool : got, halo_r = c == 0 ? got : 0.0f;
         WEDM_SV_PHASE(pa);
+        constexpr bool kF64 = false;  // (float32 stencil only)
+        const StencilF64 f64c{0.0, 0.0, 0.0};
+        const float rw_h_base = 0.0f, rw_h_zone = 0.0f;
 #define WEDM_REGS_WALK_TILE_FENCE 1
 #include "wedm_regs_walk.inc"
 #undef WEDM_REGS_WALK_TILE_FENCE

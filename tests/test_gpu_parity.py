@@ -953,6 +953,55 @@ def test_float64_stencil_on_the_tile_walk_over_wire_lengths_and_lane_counts():
     assert ran >= 60
 
 
+def test_float64_stencil_on_the_register_kernel_over_wire_lengths_and_lane_counts():
+    """`stencil_dtype="float64"` on kernel 7 (the register walk, interior cells by `cell_f64`, odd cells by the predicated
+    float64-typed formula): wire lengths across the tile residues x one and two lanes per environment, sparks, current and a
+    frozen (broken) environment in the batch, fused launches and single microseconds, with and without a trace sample in the
+    launch == the oracle's STENCIL_F64, every byte."""
+    n_envs, ran = 96, 0
+    for n_seg in (9, 16, 17, 31, 33, 57, 64, 65, 100, 127, 128):
+        gpu, cpu = make_pair(n_envs, stencil_dtype="float64", wire_params=WireModuleParameters(segment_len=80.0 / (n_seg + 0.5)),
+                             config=EnvironmentConfig(target_cutting_distance=5000.0))
+
+        def scenario(env):
+            env.reset(seed=500 + n_seg)
+            close_gap(env, 21.0, 10.0)
+            hot = env.state.wire_temperature
+            hot[5, n_seg // 2] = 1600.0
+            hot[70, n_seg - 1] = 900.0
+            hot[71, 1] = 900.0
+            return env.make_action(0.1, 80.0, 17, 3.0, 20.0)
+
+        def run(env, act):
+            env.step_many(act, 300)
+            for _ in range(3):
+                env.step(act)
+            env.step_many(act, 200)
+
+        run(cpu, scenario(cpu))
+        want = cpu.state.clone_blocks()
+        for lanes in (1, 2):
+            for traced in (False, True):
+                act = scenario(gpu)
+                gpu.set_kernel(7, lanes)
+                trace = gpu.bind_trace(["voltage"], every=7, capacity=128) if traced else None
+                gpu.step_many(act, 300)
+                assert f"wedm_step_regs<{lanes}>[f64 stencil]" in gpu._backend.last_kernel()
+                gpu.set_kernel(0, 0)   # (single microseconds: whatever the plan takes for this typing)
+                for _ in range(3):
+                    gpu.step(act)
+                gpu.set_kernel(7, lanes)
+                gpu.step_many(act, 200)
+                torch.cuda.synchronize()
+                diffs = block_diffs(gpu.state.clone_blocks(), want, n_envs)
+                assert not diffs, f"n_seg {n_seg}, lanes {lanes}, traced {traced}:\n" + "\n".join(diffs[:10])
+                if trace is not None:
+                    gpu.unbind_trace()
+                ran += 1
+        gpu.close()
+    assert ran == 44
+
+
 @pytest.mark.parametrize("variant", [3, 4])
 def test_handle_without_autoreset_moves_to_the_frozen_lane_tile_code_by_itself(variant):
     """A handle without autoreset runs the kernel instantiation without the frozen-lane tile code until one of its launches
@@ -1451,9 +1500,12 @@ def test_float64_stencil_mode_matches_oracle_bit_for_bit(shape):
                   config=EnvironmentConfig(target_cutting_distance=5000.0))
     gpu, cpu = make_pair(n, **kw)
     both((gpu, cpu), lambda e: (e.reset(seed=77), close_gap(e, 24.0, 10.0)))
-    variants = (0, 2, 1) if shape == "per_env" else (0, 3, 2, 1)   # (kernel 3, the tile walk: uniform geometry)
-    for variant in variants:
-        gpu.set_kernel(variant, 0)
+    # (kernel 3, the tile walk: uniform geometry; kernel 7, the register walk: at most 128 segments)
+    variants = ((0, 0), (2, 0), (1, 0)) if shape == "per_env" else ((0, 0), (3, 0), (2, 0), (1, 0))
+    if shape == "config3":
+        variants += ((7, 1), (7, 2))
+    for variant, lanes in variants:
+        gpu.set_kernel(variant, lanes)
         for env in (gpu, cpu):
             a = env.make_action(0.1, 80.0, 17, 3.0, 40.0)
             env.step_many(a, 900)

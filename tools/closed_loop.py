@@ -1,7 +1,7 @@
 #!/usr/bin/env python
 """Closed-loop side measurement: the reference's driver scenario (experiments/run_simulation.py:
 gap or voltage controller recomputed on the device at every control step) at the bench batch size.
-usage: python tools/closed_loop.py [gap|voltage] [intervals] [config3|config4] [approach_ms]"""
+usage: python tools/closed_loop.py [gap|voltage] [intervals] [config3|config4] [approach_ms] [kernel variant] [lanes]"""
 import sys
 import time
 
@@ -15,6 +15,8 @@ intervals = int(sys.argv[2]) if len(sys.argv) > 2 else 20
 wl = sys.argv[3] if len(sys.argv) > 3 else "config3"
 n, wire = (65536, WireModuleParameters(segment_len=0.625)) if wl == "config3" else (32768, WireModuleParameters())
 env = WireEDMEnv(num_envs=n, device="cuda:0", wire_params=wire)
+if len(sys.argv) > 5:
+    env.set_kernel(int(sys.argv[5]), int(sys.argv[6]) if len(sys.argv) > 6 else 0)
 env.reset(seed=1)
 env.state.workpiece_position = 70.0      # run_simulation.py:199-201
 env.state.wire_position = 10.0
