@@ -337,6 +337,7 @@ __device__ __forceinline__ float dpp_perm(float x) {
 #ifndef WEDM_WIDE_MIN_BLOCKS
 #define WEDM_WIDE_MIN_BLOCKS 1
 #endif
+
 #ifndef WEDM_WIDE_SW
 #define WEDM_WIDE_SW 2  // pairs per stage (4 096 x 400: 1.883e9 with 2, 1.862e9 with 4)
 #endif
@@ -349,15 +350,20 @@ __device__ __forceinline__ float dpp_perm(float x) {
 // CUT: the instantiation for wires whose end cuts a tile (n_seg not a multiple of 8); the code for that tile costs the
 // regular path 2 - 3 % by its presence (registers), so the other wires run the instantiation without it.
 // TRACE: the instantiation with the signal-trace point (a launch into which a sample falls); built on the CUT form.
-template <int H, int L, bool CUT, bool TRACE = false>
-__global__ void __launch_bounds__(256, WEDM_WIDE_MIN_BLOCKS) wedm_step_regs_wide(const KArgs k) {
+// F64: stencil_mode 1 (the walk in Numba's typing of wire.py:58-123, as in wedm_step_regs)
+// MINB: blocks per CU the register budget admits (2: the float64 typing's instantiation for batches of more than one wave per
+// SIMD -- a lone wave issues a float64 operation every ~7 cycles, two share the pipe; 256 registers, nothing pinned)
+template <int H, int L, bool CUT, bool TRACE = false, bool F64 = false, int MINB = WEDM_WIDE_MIN_BLOCKS>
+__global__ void __launch_bounds__(256, MINB) wedm_step_regs_wide(const KArgs k) {
     static_assert(H % 8 == 0 && H <= 32, "whole tiles");
     static_assert(L == 4 || L == 8 || L == 16, "the lanes of an environment lie in one DPP row");
     constexpr int EPB = 256 / L;
     constexpr int SW = WEDM_WIDE_SW;
     const ColdRef cold = kernarg_cold();
     Hot hv = k.hot;
-    pin_hot_in_vgprs(hv);
+    // (at 256 registers pinned constants are spilled wire cells: 32 768 x 400 in the float64 typing 1.42e9 with every hot constant
+    // pinned, 1.62e9 with the epilogue's and the quiet prelude's, 1.93e9 with none)
+    if (MINB == 1) pin_hot_in_vgprs(hv);
     const int tid = threadIdx.x;
     const int c = tid % L;  // this lane's part of the wire
     const int64_t e = (int64_t)blockIdx.x * EPB + tid / L;
@@ -371,6 +377,12 @@ __global__ void __launch_bounds__(256, WEDM_WIDE_MIN_BLOCKS) wedm_step_regs_wide
     Geom g;
     Persist ps{0.0f, 0.0f, 0.0f, 0};
     load_geom(k.hot, cold, live ? e : 0, g);
+    StencilF64 f64c{0.0, 0.0, 0.0};
+    if (F64) {  // (uniform geometry: the float64 constants of the typing straight from the parameter block)
+        const wedm_params* pp = cold->p;
+        f64c = StencilF64{pp->temp_ref, pp->alpha_rho, pp->dielectric_temperature};
+        g.k64 = pp->k_cond; g.tuf64 = pp->tuf; g.a64 = pp->a_surf;
+    }
     if (live) load_env(cold, e, s);
     else { s.done = WEDM_DEAD_LANE; s.unwind = 0.0; s.h_base = 0.0f; s.h_zone = 0.0f; }
     // the wire: word q = cells 4 q .. 4 q + 3 of this environment, 16 bytes per lane; words past the end: zeros (padding)
@@ -431,10 +443,11 @@ __global__ void __launch_bounds__(256, WEDM_WIDE_MIN_BLOCKS) wedm_step_regs_wide
     f2 jm[H], convc[H];
 #pragma unroll
     for (int m = 0; m < H; ++m) jm[m] = f2{((jouleA >> m) & 1u) ? 1.0f : 0.0f, ((jouleB >> m) & 1u) ? 1.0f : 0.0f};
-    auto build_conv = [&]() {
+    auto build_conv = [&]() {  // (F64: the float32 h_eff entries themselves, quad_f64 forms (double)h * A)
+        const float cz = F64 ? s.h_zone : ps.conv_zone, cb = F64 ? s.h_base : ps.conv_base;
 #pragma unroll
         for (int m = 0; m < H; ++m)
-            convc[m] = f2{((zoneA >> m) & 1u) ? ps.conv_zone : ps.conv_base, ((zoneB >> m) & 1u) ? ps.conv_zone : ps.conv_base};
+            convc[m] = f2{((zoneA >> m) & 1u) ? cz : cb, ((zoneB >> m) & 1u) ? cz : cb};
     };
     build_conv();
     WEDM_STAMP_DECL;
@@ -482,7 +495,7 @@ __global__ void __launch_bounds__(256, WEDM_WIDE_MIN_BLOCKS) wedm_step_regs_wide
                 asm volatile("" : "+s"(nw));
             };
             if (!PLAIN) prep_gw();
-            const float jf_lane = (!PLAIN && cf.joule_on) ? cf.jf : 0.0f;
+            const float jf_lane = (!PLAIN && cf.joule_on) ? (F64 ? 1.0f : cf.jf) : 0.0f;  // (float64 typing: a flag, the factor is cf.jf64)
             const bool joule_wave = !PLAIN && __any(jf_lane != 0.0f);
             // the tiles that hold some lane's plasma cell (a lane's own cells only)
             const int pcell = (!PLAIN && cf.pidx >= 1 && cf.pidx >= base && cf.pidx < base + 2 * H) ? cf.pidx - base : -1;  // lane-local
@@ -517,11 +530,11 @@ __global__ void __launch_bounds__(256, WEDM_WIDE_MIN_BLOCKS) wedm_step_regs_wide
                         f2 jvA[4], jvB[4];
 #pragma unroll
                         for (int u = 0; u < 4; ++u) { jvA[u] = jm[j + u] * jfp; jvB[u] = jm[j + 4 + u] * jfp; }
-                        quad_staged<true, true, SW>(tmA, tcA, tpA, pnA, g.k, g.tuf, cvA, tdiel, ps.adv, jvA, alpha, tref);
-                        quad_staged<true, true, SW>(tmB, tcB, tpB, pnB, g.k, g.tuf, cvB, tdiel, ps.adv, jvB, alpha, tref);
+                        rw_quad<F64, true, true, SW>(tmA, tcA, tpA, pnA, g, cvA, tdiel, ps, jvA, alpha, tref, f64c, cf);
+                        rw_quad<F64, true, true, SW>(tmB, tcB, tpB, pnB, g, cvB, tdiel, ps, jvB, alpha, tref, f64c, cf);
                     } else {
-                        quad_staged<false, true, SW>(tmA, tcA, tpA, pnA, g.k, g.tuf, cvA, tdiel, ps.adv, cvA, alpha, tref);
-                        quad_staged<false, true, SW>(tmB, tcB, tpB, pnB, g.k, g.tuf, cvB, tdiel, ps.adv, cvB, alpha, tref);
+                        rw_quad<F64, false, true, SW>(tmA, tcA, tpA, pnA, g, cvA, tdiel, ps, cvA, alpha, tref, f64c, cw);
+                        rw_quad<F64, false, true, SW>(tmB, tcB, tpB, pnB, g, cvB, tdiel, ps, cvB, alpha, tref, f64c, cw);
                     }
 #pragma unroll
                     for (int u = 0; u < 4; ++u) { pn[u] = pnA[u]; pn[4 + u] = pnB[u]; }
@@ -533,8 +546,8 @@ __global__ void __launch_bounds__(256, WEDM_WIDE_MIN_BLOCKS) wedm_step_regs_wide
                         if (PLAIN) prep_gw();
                         // the wire's last cell (last position of its tile)
                         if ((last_tile >> t) & 1u) {
-                            const float x = stencil_cell(base + (last_in_b ? H : 0) + j + 7, nw, last_in_b ? tm[7].y : tm[7].x,
-                                                         last_in_b ? tc[7].y : tc[7].x, 0.0f, gw, cw, ps, tref, alpha, tdiel);
+                            const float x = rw_cell<F64>(base + (last_in_b ? H : 0) + j + 7, nw, last_in_b ? tm[7].y : tm[7].x,
+                                                         last_in_b ? tc[7].y : tc[7].x, 0.0f, gw, cw, ps, tref, alpha, tdiel, f64c, s.h_base, s.h_zone);
                             const bool hx = owns_last && !last_in_b, hy = owns_last && last_in_b;
                             pn[7].x = hx ? x : pn[7].x; pn[7].y = hy ? x : pn[7].y;
                         }
@@ -545,11 +558,11 @@ __global__ void __launch_bounds__(256, WEDM_WIDE_MIN_BLOCKS) wedm_step_regs_wide
 #pragma unroll
                             for (int u = 0; u < 8; ++u) {
                                 if (lw == j + u) {
-                                    const float x = stencil_cell(base + j + u, nw, tm[u].x, tc[u].x, 0.0f, gw, cw, ps, tref, alpha, tdiel);
+                                    const float x = rw_cell<F64>(base + j + u, nw, tm[u].x, tc[u].x, 0.0f, gw, cw, ps, tref, alpha, tdiel, f64c, s.h_base, s.h_zone);
                                     pn[u].x = owns_last ? x : pn[u].x;
                                 }
                                 if (lw == H + j + u) {
-                                    const float x = stencil_cell(base + H + j + u, nw, tm[u].y, tc[u].y, 0.0f, gw, cw, ps, tref, alpha, tdiel);
+                                    const float x = rw_cell<F64>(base + H + j + u, nw, tm[u].y, tc[u].y, 0.0f, gw, cw, ps, tref, alpha, tdiel, f64c, s.h_base, s.h_zone);
                                     pn[u].y = owns_last ? x : pn[u].y;
                                 }
                             }
@@ -559,11 +572,11 @@ __global__ void __launch_bounds__(256, WEDM_WIDE_MIN_BLOCKS) wedm_step_regs_wide
 #pragma unroll
                             for (int u = 0; u < 8; ++u) {
                                 if (__any(pcell == j + u)) {
-                                    const float x = stencil_cell(base + j + u, nw, (base + j + u == 1) ? spool : tm[u].x, tc[u].x, tp[u].x, gw, cf, ps, tref, alpha, tdiel);
+                                    const float x = rw_cell<F64>(base + j + u, nw, (base + j + u == 1) ? spool : tm[u].x, tc[u].x, tp[u].x, gw, cf, ps, tref, alpha, tdiel, f64c, s.h_base, s.h_zone);
                                     pn[u].x = (pcell == j + u) ? x : pn[u].x;
                                 }
                                 if (__any(pcell == H + j + u)) {
-                                    const float x = stencil_cell(base + H + j + u, nw, tm[u].y, tc[u].y, tp[u].y, gw, cf, ps, tref, alpha, tdiel);
+                                    const float x = rw_cell<F64>(base + H + j + u, nw, tm[u].y, tc[u].y, tp[u].y, gw, cf, ps, tref, alpha, tdiel, f64c, s.h_base, s.h_zone);
                                     pn[u].y = (pcell == H + j + u) ? x : pn[u].y;
                                 }
                             }

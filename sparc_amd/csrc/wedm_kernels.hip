@@ -83,6 +83,13 @@ using namespace wedm;
 #define WEDM_REGS_F64_LIST(X) X(1, false) X(1, true) X(2, false) X(2, true)
 #define WEDM_INST_REGS_F64(L, tr) template __global__ void wedm_step_regs<128, L, tr, true>(const KArgs);
 #define WEDM_EXT_REGS_F64(L, tr) extern template __global__ void wedm_step_regs<128, L, tr, true>(const KArgs);
+// stencil_mode 1 on the wide register kernel: <16, L, CUT, TRACE, F64 = true, MINB> (a traced launch runs the CUT form, as in
+// float32; MINB = 1 for a batch of one wave per SIMD, 2 beyond)
+#define WEDM_WIDE_F64_LIST1(X, mb) X(4, false, false, mb) X(4, true, false, mb) X(4, true, true, mb) X(8, false, false, mb) X(8, true, false, mb) \
+                                   X(8, true, true, mb) X(16, false, false, mb) X(16, true, false, mb) X(16, true, true, mb)
+#define WEDM_WIDE_F64_LIST(X) WEDM_WIDE_F64_LIST1(X, 1) WEDM_WIDE_F64_LIST1(X, 2)
+#define WEDM_INST_WIDE_F64(L, cut, tr, mb) template __global__ void wedm_step_regs_wide<16, L, cut, tr, true, mb>(const KArgs);
+#define WEDM_EXT_WIDE_F64(L, cut, tr, mb) extern template __global__ void wedm_step_regs_wide<16, L, cut, tr, true, mb>(const KArgs);
 #define WEDM_INST_SERVED(L, ex) template __global__ void wedm_step_served<L, ex>(const KArgs);
 #define WEDM_EXT_SERVED(L, ex) extern template __global__ void wedm_step_served<L, ex>(const KArgs);
 #if defined(WEDM_PART) && WEDM_PART == 1
@@ -93,9 +100,11 @@ WEDM_FUSED_F64_LIST(WEDM_INST_FUSED_F64)
 #elif defined(WEDM_PART) && WEDM_PART == 3
 WEDM_SERVED_LIST(WEDM_INST_SERVED)
 WEDM_INST_REGS_SERVED
-WEDM_REGS_F64_LIST(WEDM_INST_REGS_F64)
 WEDM_LANES_PK_LIST(WEDM_INST_LANES_PK)
 WEDM_LANES_SERVED_LIST(WEDM_INST_LANES_SERVED)
+#elif defined(WEDM_PART) && WEDM_PART == 4
+WEDM_REGS_F64_LIST(WEDM_INST_REGS_F64)
+WEDM_WIDE_F64_LIST(WEDM_INST_WIDE_F64)
 #else
 #if defined(WEDM_PART)
 WEDM_PACKED_LIST(WEDM_EXT_PACKED)
@@ -104,6 +113,7 @@ WEDM_FUSED_F64_LIST(WEDM_EXT_FUSED_F64)
 WEDM_SERVED_LIST(WEDM_EXT_SERVED)
 WEDM_EXT_REGS_SERVED
 WEDM_REGS_F64_LIST(WEDM_EXT_REGS_F64)
+WEDM_WIDE_F64_LIST(WEDM_EXT_WIDE_F64)
 WEDM_LANES_PK_LIST(WEDM_EXT_LANES_PK)
 WEDM_LANES_SERVED_LIST(WEDM_EXT_LANES_SERVED)
 #endif
@@ -549,16 +559,11 @@ static int32_t plan_launch(wedm_ctx* ctx, bool single, bool tr, bool frozen_ok, 
         variant = 1;
     }
     const bool f64 = P.stencil_mode != 0;
-    if (f64) {
-        // Numba's typing of the stencil: the register kernel (uniform geometry, at most 128 segments), the fused tile walk
-        // (uniform geometry), the predicated LDS kernel (any geometry), or in place in global memory; no packed form, no
-        // single-microsecond kernels
-        if (variant != 0 && variant != 1 && variant != 2 && variant != 3 && variant != 7 && variant != 10)
-            return fail(ctx, WEDM_ERR_UNSUPPORTED, "wedm_step: stencil_mode 1 (float64 stencil expressions) runs on kernels 1, 2 (10), 3 and 7 only");
-        // (the register kernel from the batch size at which it also takes the float32 launch)
-        if (variant == 0 && !single && uniform && ctx->walk_regs_ok && ctx->n_seg_max <= 128 && ctx->lanes == 0 && ctx->num_envs >= 20480) variant = 7;
-        if (variant == 0) variant = (!single && fused_ok) ? 3 : (lanes_ok ? 2 : 1);
-    }
+    // Numba's typing of the stencil: the register kernels (uniform geometry; at most 128 / 512 segments), the fused tile walk
+    // (uniform geometry), the predicated LDS kernel (any geometry), or in place in global memory; no packed LDS form, no served
+    // form, no stream / split kernel
+    if (f64 && variant != 0 && variant != 1 && variant != 2 && variant != 3 && variant != 7 && variant != 8 && variant != 10)
+        return fail(ctx, WEDM_ERR_UNSUPPORTED, "wedm_step: stencil_mode 1 (float64 stencil expressions) runs on kernels 1, 2 (10), 3, 7 and 8 only");
     // kernel 2 is the packed form where it applies (float32 stencil, no injected variates); kernel 10 names the cell-by-cell
     // form explicitly (A/B timing, tests), which also serves stencil_mode 1
     const bool use_pk = !f64 && !ctx->replay && lanes_pk_ok;
@@ -569,13 +574,13 @@ static int32_t plan_launch(wedm_ctx* ctx, bool single, bool tr, bool frozen_ok, 
     // shortest (measured, 4 096 x 400 and 16 384 x 128: DESIGN.md 4.1b)
     const int wl_min = P.n_seg <= 128 ? 4 : P.n_seg <= 256 ? 8 : 16;
     const int wl = (ctx->lanes == 4 || ctx->lanes == 8 || ctx->lanes == 16) ? ctx->lanes : wl_min;
-    const bool wide_ok = uniform && P.n_seg >= 9 && P.n_seg <= 512 && !f64 && !ctx->replay &&
+    const bool wide_ok = uniform && P.n_seg >= 9 && P.n_seg <= 512 && !ctx->replay &&
                          (ctx->lanes == 0 || (wl == ctx->lanes && wl >= wl_min));
     if (variant == 0 && !single && wide_ok && ctx->lanes == 0 &&
         (int64_t)ctx->num_envs * wl <= (int64_t)WEDM_WIDE_AUTO_MAX_LANES)
         variant = 8;
     if (variant == 8 && !wide_ok)
-        return fail(ctx, WEDM_ERR_UNSUPPORTED, "wedm_step: wide register kernel needs uniform geometry, 9 to 512 segments, the float32 stencil and lanes 0, 4, 8 or 16 with 32 cells per lane covering the wire");
+        return fail(ctx, WEDM_ERR_UNSUPPORTED, "wedm_step: wide register kernel needs uniform geometry, 9 to 512 segments and lanes 0, 4, 8 or 16 with 32 cells per lane covering the wire");
     // kernel 7 (register kernel): one or two lanes per environment with the wire in their registers; wires of at most 128
     // segments, uniform geometry, float32 stencil; a launch with a trace sample runs its TRACE instantiation
     const bool regs_ok = uniform && ctx->walk_regs_ok && ctx->n_seg_max <= 128 && !ctx->replay;
@@ -584,7 +589,12 @@ static int32_t plan_launch(wedm_ctx* ctx, bool single, bool tr, bool frozen_ok, 
         // per environment against the best LDS kernel: 8 192 environments 2.8e9 vs 3.5e9, 16 384: 5.5e9 vs 6.1e9,
         // 24 576: 8.3e9 vs 7.4e9, 32 768: 1.10e10 vs 9.9e9, 65 536: 1.67e10 vs 1.44e10, 131 072: 1.76e10 vs 1.50e10;
         // up to 16 384 environments the wide register kernel above has taken the launch: 8.1e9 there)
-        if (!single && regs_ok && ctx->lanes == 0 && ctx->num_envs >= 20480) variant = 7;
+        // (stencil_mode 1: single microseconds too -- 34 us against the cell-by-cell LDS kernel's 44 at 65 536 x 128)
+        if ((!single || f64) && regs_ok && ctx->lanes == 0 && ctx->num_envs >= 20480) variant = 7;
+        // stencil_mode 1, longer wires, any batch: the wide register kernel (two blocks per CU beyond one wave per SIMD) -- 18 - 20
+        // float64 operations per cell leave the LDS round trips of the tile walk nothing to hide behind (32 768 x 400: 1.93e9
+        // against the fused kernel's 1.49e9; 8 192 x 400: 1.5e9 against 1.2e9 already at one block per CU)
+        if (variant == 0 && f64 && !single && wide_ok && ctx->lanes == 0) variant = 8;
     }
     // kernel 9 (served packed kernel, wedm_served.h): the packed walk on three waves of a block, the scalar physics on the fourth;
     // 4 or 8 lanes per environment; no trace point and no keep_stepping_terminated (such launches stay on kernel 4).
@@ -632,7 +642,8 @@ static int32_t plan_launch(wedm_ctx* ctx, bool single, bool tr, bool frozen_ok, 
         // single-microsecond launches: the stream kernel where one round of blocks covers the batch with chunks of
         // at most 64 cells (measured: 27.5 vs 30.3 us at 65 536 x 128, 20.5 vs 24.9 us at 4 096 x 400), else the
         // split global-memory kernel (32.7 vs 48.9 us at 32 768 x 400, where the stream kernel needs two rounds)
-        if (single) variant = (stream_ok && stream_auto) ? 6 : 5;
+        if (f64) variant = (!single && fused_ok) ? 3 : (lanes_ok ? 2 : 1);
+        else if (single) variant = (stream_ok && stream_auto) ? 6 : 5;
         else if (packed_ok && (ctx->auto_prefers_packed || !fused_ok)) variant = 4;
         else if (fused_ok) variant = 3;
         else variant = (lanes_ok || use_pk) ? 2 : 1;
@@ -676,13 +687,17 @@ static int32_t plan_launch(wedm_ctx* ctx, bool single, bool tr, bool frozen_ok, 
         std::snprintf(out.name, sizeof(out.name), "wedm_step_regs<%d>%s<<<%d,256>>>", rl, f64 ? "[f64 stencil]" : "", grid);
     } else if (variant == 8) {
         grid = (ctx->num_envs + 256 / wl - 1) / (256 / wl);
-        fn = tr ? (wl == 4 ? (const void*)wedm_step_regs_wide<16, 4, true, true> : wl == 8 ? (const void*)wedm_step_regs_wide<16, 8, true, true>
-                                                                                       : (const void*)wedm_step_regs_wide<16, 16, true, true>)
-           : (P.n_seg & 7) ? (wl == 4 ? (const void*)wedm_step_regs_wide<16, 4, true> : wl == 8 ? (const void*)wedm_step_regs_wide<16, 8, true>
-                                                                                             : (const void*)wedm_step_regs_wide<16, 16, true>)
-                           : (wl == 4 ? (const void*)wedm_step_regs_wide<16, 4, false> : wl == 8 ? (const void*)wedm_step_regs_wide<16, 8, false>
-                                                                                              : (const void*)wedm_step_regs_wide<16, 16, false>);
-        std::snprintf(out.name, sizeof(out.name), "wedm_step_regs_wide<%d><<<%d,256>>>", wl, grid);
+#define WEDM_PICK_WIDE(...) (wl == 4 ? (const void*)wedm_step_regs_wide<16, 4, __VA_ARGS__> : wl == 8 ? (const void*)wedm_step_regs_wide<16, 8, __VA_ARGS__> \
+                                                                                                  : (const void*)wedm_step_regs_wide<16, 16, __VA_ARGS__>)
+        const bool cutw = (P.n_seg & 7) != 0;
+        // (stencil_mode 1: a batch of more than one wave per SIMD runs the two-blocks-per-CU instantiation -- 32 768 x 400: 1.93e9
+        // against 1.52e9; 4 096 x 400: 1.33e9 against 1.45e9)
+        const bool two = (int64_t)ctx->num_envs * wl > (int64_t)WEDM_WIDE_AUTO_MAX_LANES;
+        fn = f64 ? (two ? (tr ? WEDM_PICK_WIDE(true, true, true, 2) : cutw ? WEDM_PICK_WIDE(true, false, true, 2) : WEDM_PICK_WIDE(false, false, true, 2))
+                        : (tr ? WEDM_PICK_WIDE(true, true, true, 1) : cutw ? WEDM_PICK_WIDE(true, false, true, 1) : WEDM_PICK_WIDE(false, false, true, 1)))
+                 : (tr ? WEDM_PICK_WIDE(true, true) : cutw ? WEDM_PICK_WIDE(true) : WEDM_PICK_WIDE(false));
+#undef WEDM_PICK_WIDE
+        std::snprintf(out.name, sizeof(out.name), "wedm_step_regs_wide<%d>%s<<<%d,256>>>", wl, f64 ? "[f64 stencil]" : "", grid);
     } else if (variant == 5) {
         grid = (ctx->num_envs + 63) / 64;
         fn = tr ? (const void*)wedm_step_split<true> : (const void*)wedm_step_split<false>;

@@ -953,13 +953,18 @@ def test_float64_stencil_on_the_tile_walk_over_wire_lengths_and_lane_counts():
     assert ran >= 60
 
 
-def test_float64_stencil_on_the_register_kernel_over_wire_lengths_and_lane_counts():
-    """`stencil_dtype="float64"` on kernel 7 (the register walk, interior cells by `cell_f64`, odd cells by the predicated
-    float64-typed formula): wire lengths across the tile residues x one and two lanes per environment, sparks, current and a
-    frozen (broken) environment in the batch, fused launches and single microseconds, with and without a trace sample in the
-    launch == the oracle's STENCIL_F64, every byte."""
+@pytest.mark.parametrize("variant", [7, 8])
+def test_float64_stencil_on_the_register_kernels_over_wire_lengths_and_lane_counts(variant):
+    """`stencil_dtype="float64"` on kernels 7 and 8 (the register walks, interior cells by `cell_f64`, odd cells by the
+    predicated float64-typed formula): wire lengths across the tile residues x the lane counts, sparks, current and a frozen
+    (broken) environment in the batch, fused launches and single microseconds, with and without a trace sample in the launch
+    == the oracle's STENCIL_F64, every byte."""
+    from sparc_amd._lib import WedmError
+
     n_envs, ran = 96, 0
-    for n_seg in (9, 16, 17, 31, 33, 57, 64, 65, 100, 127, 128):
+    sizes = (9, 16, 17, 31, 33, 57, 64, 65, 100, 127, 128) if variant == 7 else (9, 17, 33, 64, 100, 128, 129, 200, 256, 257, 400, 450, 512)
+    name = "wedm_step_regs<{}>[f64 stencil]" if variant == 7 else "wedm_step_regs_wide<{}>[f64 stencil]"
+    for n_seg in sizes:
         gpu, cpu = make_pair(n_envs, stencil_dtype="float64", wire_params=WireModuleParameters(segment_len=80.0 / (n_seg + 0.5)),
                              config=EnvironmentConfig(target_cutting_distance=5000.0))
 
@@ -972,34 +977,77 @@ def test_float64_stencil_on_the_register_kernel_over_wire_lengths_and_lane_count
             hot[71, 1] = 900.0
             return env.make_action(0.1, 80.0, 17, 3.0, 20.0)
 
-        def run(env, act):
-            env.step_many(act, 300)
-            for _ in range(3):
-                env.step(act)
-            env.step_many(act, 200)
-
-        run(cpu, scenario(cpu))
+        act = scenario(cpu)
+        cpu.step_many(act, 300)
+        for _ in range(3):
+            cpu.step(act)
+        cpu.step_many(act, 200)
         want = cpu.state.clone_blocks()
-        for lanes in (1, 2):
+        for lanes in ((1, 2) if variant == 7 else (4, 8, 16)):
             for traced in (False, True):
                 act = scenario(gpu)
-                gpu.set_kernel(7, lanes)
-                trace = gpu.bind_trace(["voltage"], every=7, capacity=128) if traced else None
-                gpu.step_many(act, 300)
-                assert f"wedm_step_regs<{lanes}>[f64 stencil]" in gpu._backend.last_kernel()
+                gpu.set_kernel(variant, lanes)
+                if traced:
+                    gpu.bind_trace(["voltage"], every=7, capacity=128)
+                try:
+                    gpu.step_many(act, 300)
+                except WedmError as exc:   # (32 cells per lane do not cover this wire)
+                    assert variant == 8 and "UNSUPPORTED" in str(exc) and 32 * lanes < n_seg
+                    if traced:
+                        gpu.unbind_trace()
+                    continue
+                assert name.format(lanes) in gpu._backend.last_kernel(), gpu._backend.last_kernel()
                 gpu.set_kernel(0, 0)   # (single microseconds: whatever the plan takes for this typing)
                 for _ in range(3):
                     gpu.step(act)
-                gpu.set_kernel(7, lanes)
+                gpu.set_kernel(variant, lanes)
                 gpu.step_many(act, 200)
                 torch.cuda.synchronize()
                 diffs = block_diffs(gpu.state.clone_blocks(), want, n_envs)
                 assert not diffs, f"n_seg {n_seg}, lanes {lanes}, traced {traced}:\n" + "\n".join(diffs[:10])
-                if trace is not None:
+                if traced:
                     gpu.unbind_trace()
                 ran += 1
         gpu.close()
-    assert ran == 44
+    assert ran >= (44 if variant == 7 else 50)
+
+
+@pytest.mark.parametrize("n_seg", [400, 450, 129])
+def test_float64_stencil_on_the_wide_register_kernel_at_two_blocks_per_cu(n_seg):
+    """A batch of more than one wave per SIMD in the float64 typing runs the wide register kernel's 256-register instantiation
+    (two blocks per CU; chosen by the plan for wires of more than 128 segments): a ragged batch, sparks, hot cells, a traced
+    launch == the oracle's STENCIL_F64, every byte."""
+    n = 4128 + 5
+    gpu, cpu = make_pair(n, stencil_dtype="float64", wire_params=WireModuleParameters(segment_len=80.0 / (n_seg + 0.5)),
+                         config=EnvironmentConfig(target_cutting_distance=5000.0))
+
+    def scenario(env):
+        env.reset(seed=900 + n_seg)
+        close_gap(env, 21.0, 10.0)
+        hot = env.state.wire_temperature
+        hot[5, n_seg // 2] = 1600.0
+        hot[4100, n_seg - 1] = 900.0
+        hot[71, 1] = 900.0
+        return env.make_action(0.1, 80.0, 17, 3.0, 20.0)
+
+    act = scenario(cpu)
+    cpu.step_many(act, 150)
+    cpu.step_many(act, 50)
+    want = cpu.state.clone_blocks()
+    for traced in (False, True):
+        act = scenario(gpu)
+        if traced:
+            gpu.bind_trace(["voltage"], every=7, capacity=64, envs=(0, 64))
+        gpu.step_many(act, 150)   # the automatic plan
+        assert "wedm_step_regs_wide<" in gpu._backend.last_kernel() and "[f64 stencil]" in gpu._backend.last_kernel(), gpu._backend.last_kernel()
+        gpu.step_many(act, 50)
+        torch.cuda.synchronize()
+        diffs = block_diffs(gpu.state.clone_blocks(), want, n)
+        assert not diffs, f"n_seg {n_seg}, traced {traced}:\n" + "\n".join(diffs[:10])
+        if traced:
+            gpu.unbind_trace()
+    assert int(gpu.state.spark_count.sum()) > 100
+    gpu.close()
 
 
 @pytest.mark.parametrize("variant", [3, 4])
@@ -1503,7 +1551,9 @@ def test_float64_stencil_mode_matches_oracle_bit_for_bit(shape):
     # (kernel 3, the tile walk: uniform geometry; kernel 7, the register walk: at most 128 segments)
     variants = ((0, 0), (2, 0), (1, 0)) if shape == "per_env" else ((0, 0), (3, 0), (2, 0), (1, 0))
     if shape == "config3":
-        variants += ((7, 1), (7, 2))
+        variants += ((7, 1), (7, 2), (8, 4))
+    if shape == "default400":
+        variants += ((8, 16),)
     for variant, lanes in variants:
         gpu.set_kernel(variant, lanes)
         for env in (gpu, cpu):

@@ -27,7 +27,7 @@ obj_dir.mkdir(parents=True, exist_ok=True)
 out.parent.mkdir(parents=True, exist_ok=True)
 flags = [f for f in g.HIPCC_FLAGS if f != "-shared"] + ["-w", f'-DWEDM_BUILD_ID="{g.kernel_build_id()}+{tag}"'] + extra
 procs, objs = [], []
-for part in (1, 2, 0, 3):
+for part in (1, 2, 0, 3, 4):
     if only is not None and part != only:
         objs.append(ROOT / "build" / "obj" / f"wedm_kernels.part{part}.o")
         continue
