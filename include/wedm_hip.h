@@ -413,8 +413,11 @@ int64_t wedm_trace_samples(wedm_ctx* ctx);
  * on three waves of a block, the scalar physics on the fourth, as kernel 9; by name only: not faster at BASELINE configs[4]),
  * 12 = the served form of kernel 7 (two walker waves with the wire in registers + a scalar wave with all 64 lanes busy; by name
  * only: 1.666e10 against kernel 7's 1.674e10 at the headline batch, spills; at most 128 segments, no trace sample).
- * All variants produce bit-identical results.  With wedm_params.stencil_mode 1 only 0, 1, 2 (= 10) and 3 are accepted (3: the tile walk with
- * per-cell coefficients, no stage-major / packed form).                                          */
+ * All variants produce bit-identical results.  With wedm_params.stencil_mode 1 only 0, 1, 2 (= 10), 3, 7 and 8 are accepted (7 / 8: the
+ * register walks with every interior cell in Numba's typing -- 18 float64 operations per cell -- and, for kernel 8, a
+ * 256-register instantiation at two blocks per CU for batches beyond one wave per SIMD; 3: the tile walk with per-cell
+ * coefficients; no packed, served or single-microsecond form -- 0 takes kernel 7 from 20 480 environments of at most 128
+ * segments, kernel 8 for other wires of 9 to 512 segments, else 3 / 2 / 1).                       */
 int32_t wedm_set_kernel(wedm_ctx* ctx, int32_t variant);
 
 /* lanes that share one environment in kernels 2, 3, 4 and 6: 0 = auto, or 1, 2, 4, 8 (16: not kernel 4); kernel 7: 1, anything

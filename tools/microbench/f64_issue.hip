@@ -1,6 +1,6 @@
 // f64_issue.hip — issue cost (cycles per wave64 instruction, one wave per SIMD and two) of the float64 operations the
 // Numba-typed stencil is made of, on gfx950: v_add_f64, v_mul_f64, v_fma_f64, v_cvt_f32_f64, v_cvt_f64_f32, against v_add_f32
-// and v_pk_fma_f32.  Independent instructions (8 accumulators), s_memtime around 8 x 64 of them (64 per loop trip).
+// and v_pk_fma_f32.  Independent instructions (8 accumulators), s_memtime around 512 x 64 of them (64 per loop trip: ~100 us, so that the blocks of a launch overlap).
 //   hipcc --offload-arch=gfx950 -O2 -o build/microbench/f64_issue tools/microbench/f64_issue.hip && build/microbench/f64_issue
 #include <hip/hip_runtime.h>
 #include <cstdio>
@@ -18,7 +18,7 @@ __global__ void __launch_bounds__(256) issue(unsigned long long* out, double see
     for (int i = 0; i < 8; ++i) { a[i] = seed + i; f[i] = (float)(seed + i); p[i] = f2{f[i], f[i] + 1.0f}; }
     unsigned long long t0, t1;
     asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t0)::"memory");
-    for (int r = 0; r < 8; ++r) {
+    for (int r = 0; r < 512; ++r) {
 #define OP(i)                                                                                                      \
     if (KIND == 0) asm volatile("v_add_f64 %0, %0, %1" : "+v"(a[i]) : "v"(b));                                      \
     if (KIND == 1) asm volatile("v_mul_f64 %0, %0, %1" : "+v"(a[i]) : "v"(c));                                      \
@@ -61,7 +61,7 @@ int main() {
             }
             unsigned long long h[4];
             hipMemcpy(h, d, sizeof(h), hipMemcpyDeviceToHost);
-            const double n = 64.0 * 8.0 * (k == 7 ? 2 : 1);
+            const double n = 512.0 * 64.0 * (k == 7 ? 2 : 1);
             printf("%d wave(s)/SIMD  %-24s %6.2f shader cycles per instruction of one wave\n", waves, names[k], h[0] / n);
         }
     }
