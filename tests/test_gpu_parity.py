@@ -1893,3 +1893,18 @@ def test_automatic_plan_is_within_reach_of_the_best_forced_kernel(n, n_seg):
     r = plan_sweep.sweep_point(n, n_seg)
     (ams, aname), (bms, bname, bkey) = r["auto"], r["best"]
     assert ams <= 1.07 * bms, f"{n} x {n_seg}: auto {aname} {ams:.3f} ms, forced {bname} {bkey} {bms:.3f} ms"
+
+
+@pytest.mark.parametrize("n,n_seg", [(65536, 128), (16384, 128), (4096, 400), (32768, 400), (16384, 200)])
+def test_automatic_plan_in_the_float64_typing_is_within_reach_of_the_best_forced_kernel(n, n_seg):
+    """The same for `stencil_dtype="float64"` (kernels 3, 7, 8: profiles/r4/plan_sweep_f64.txt)."""
+    import sys
+
+    from pathlib import Path
+
+    sys.path.insert(0, str(Path(__file__).resolve().parents[1] / "tools"))
+    import plan_sweep
+
+    r = plan_sweep.sweep_point(n, n_seg, stencil_dtype="float64")
+    (ams, aname), (bms, bname, bkey) = r["auto"], r["best"]
+    assert ams <= 1.07 * bms, f"{n} x {n_seg}: auto {aname} {ams:.3f} ms, forced {bname} {bkey} {bms:.3f} ms"

@@ -112,6 +112,7 @@ ktrace kt5 rocprofv3_kernel_stats_config5.csv --steps 20 --warmup 2 --workload c
 
 echo "[profile] launch plan sweep, served kernel A/B and stamps"; date +%T
 python tools/plan_sweep.py > $S/plan_sweep.txt 2> $OUT/plan_sweep.err || { echo "[profile] plan sweep failed"; tail -3 $OUT/plan_sweep.err; exit 1; }
+python tools/plan_sweep.py --f64 > $S/plan_sweep_f64.txt 2> $OUT/plan_sweep_f64.err || { echo "[profile] float64 plan sweep failed"; tail -3 $OUT/plan_sweep_f64.err; exit 1; }
 bash tools/ab_served.sh > $S/ab_served.txt 2>&1 || { echo "[profile] ab_served failed"; tail -3 $S/ab_served.txt; }
 if [ -f build/ablate/libwedm_SVSTAMPS.so ]; then
   for n in 8192 32768; do WEDM_HIP_LIB=build/ablate/libwedm_SVSTAMPS.so python tools/stamps_served.py 8 $n 2>/dev/null; done > $S/stamps_served.txt
