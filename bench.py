@@ -498,7 +498,7 @@ def main():
 
         h, d, mode = config5_draws(world * n_local, rank * n_local, (rank + 1) * n_local)
         env = WireEDMEnv(num_envs=n_local, device=device, wire_params=wire, env_id_offset=rank * n_local,
-                         workpiece_height=h, wire_diameter=d,
+                         workpiece_height=h, wire_diameter=d, stencil_dtype=args.stencil_dtype,
                          config=EnvironmentConfig(target_cutting_distance=5000.0))
     else:
         mode = 5

@@ -409,7 +409,7 @@ int64_t wedm_trace_samples(wedm_ctx* ctx);
  * maxima cross through LDS; uniform geometry, float32 stencil, freeze-on-termination; launches with a trace sample take
  * kernel 4), 10 = kernel 2's cell-by-cell form by name (since round 4 kernel 2 itself is the packed form -- two virtual
  * chunks per lane advanced in float2 registers, per-cell coefficients from the lane's own indices -- wherever the stencil is
- * float32; the cell-by-cell form remains for stencil_mode 1 and for A/B timing), 11 = the served form of kernel 2 (its walk
+ * float32, and the same walk with float64-typed cells under stencil_mode 1; the cell-by-cell form remains for A/B timing), 11 = the served form of kernel 2 (its walk
  * on three waves of a block, the scalar physics on the fourth, as kernel 9; by name only: not faster at BASELINE configs[4]),
  * 12 = the served form of kernel 7 (two walker waves with the wire in registers + a scalar wave with all 64 lanes busy; by name
  * only: 1.666e10 against kernel 7's 1.674e10 at the headline batch, spills; at most 128 segments, no trace sample).

@@ -74,6 +74,8 @@ using namespace wedm;
 #define WEDM_LANES_PK_LIST(X) X(1, false) X(1, true) X(2, false) X(2, true) X(4, false) X(4, true) X(8, false) X(8, true) X(16, false) X(16, true)
 #define WEDM_INST_LANES_PK(L, tr) template __global__ void wedm_step_lanes_pk<L, tr>(const KArgs);
 #define WEDM_EXT_LANES_PK(L, tr) extern template __global__ void wedm_step_lanes_pk<L, tr>(const KArgs);
+#define WEDM_INST_LANES_PK_F64(L, tr) template __global__ void wedm_step_lanes_pk<L, tr, true>(const KArgs);
+#define WEDM_EXT_LANES_PK_F64(L, tr) extern template __global__ void wedm_step_lanes_pk<L, tr, true>(const KArgs);
 #define WEDM_LANES_SERVED_LIST(X) X(4) X(8) X(16)
 #define WEDM_INST_LANES_SERVED(L) template __global__ void wedm_step_lanes_served<L>(const KArgs);
 #define WEDM_EXT_LANES_SERVED(L) extern template __global__ void wedm_step_lanes_served<L>(const KArgs);
@@ -105,6 +107,7 @@ WEDM_LANES_SERVED_LIST(WEDM_INST_LANES_SERVED)
 #elif defined(WEDM_PART) && WEDM_PART == 4
 WEDM_REGS_F64_LIST(WEDM_INST_REGS_F64)
 WEDM_WIDE_F64_LIST(WEDM_INST_WIDE_F64)
+WEDM_LANES_PK_LIST(WEDM_INST_LANES_PK_F64)
 #else
 #if defined(WEDM_PART)
 WEDM_PACKED_LIST(WEDM_EXT_PACKED)
@@ -115,6 +118,7 @@ WEDM_EXT_REGS_SERVED
 WEDM_REGS_F64_LIST(WEDM_EXT_REGS_F64)
 WEDM_WIDE_F64_LIST(WEDM_EXT_WIDE_F64)
 WEDM_LANES_PK_LIST(WEDM_EXT_LANES_PK)
+WEDM_LANES_PK_LIST(WEDM_EXT_LANES_PK_F64)
 WEDM_LANES_SERVED_LIST(WEDM_EXT_LANES_SERVED)
 #endif
 
@@ -396,13 +400,13 @@ template <bool TR, bool FZ> static const void* pick_packed(int L, bool extra) {
     return extra ? pick_packed<TR, FZ, true>(L) : pick_packed<TR, FZ, false>(L);
 }
 
-template <bool TR> static const void* pick_lanes_pk(int L) {
+template <bool TR, bool F64 = false> static const void* pick_lanes_pk(int L) {
     switch (L) {
-        case 1: return (const void*)wedm_step_lanes_pk<1, TR>;
-        case 2: return (const void*)wedm_step_lanes_pk<2, TR>;
-        case 4: return (const void*)wedm_step_lanes_pk<4, TR>;
-        case 8: return (const void*)wedm_step_lanes_pk<8, TR>;
-        default: return (const void*)wedm_step_lanes_pk<16, TR>;
+        case 1: return (const void*)wedm_step_lanes_pk<1, TR, F64>;
+        case 2: return (const void*)wedm_step_lanes_pk<2, TR, F64>;
+        case 4: return (const void*)wedm_step_lanes_pk<4, TR, F64>;
+        case 8: return (const void*)wedm_step_lanes_pk<8, TR, F64>;
+        default: return (const void*)wedm_step_lanes_pk<16, TR, F64>;
     }
 }
 static const void* pick_served(int L, bool extra) {
@@ -564,9 +568,9 @@ static int32_t plan_launch(wedm_ctx* ctx, bool single, bool tr, bool frozen_ok, 
     // form, no stream / split kernel
     if (f64 && variant != 0 && variant != 1 && variant != 2 && variant != 3 && variant != 7 && variant != 8 && variant != 10)
         return fail(ctx, WEDM_ERR_UNSUPPORTED, "wedm_step: stencil_mode 1 (float64 stencil expressions) runs on kernels 1, 2 (10), 3, 7 and 8 only");
-    // kernel 2 is the packed form where it applies (float32 stencil, no injected variates); kernel 10 names the cell-by-cell
-    // form explicitly (A/B timing, tests), which also serves stencil_mode 1
-    const bool use_pk = !f64 && !ctx->replay && lanes_pk_ok;
+    // kernel 2 is the packed form where it applies (no injected variates; under stencil_mode 1 the same walk with float64-typed
+    // cells); kernel 10 names the cell-by-cell form explicitly (A/B timing, tests)
+    const bool use_pk = !ctx->replay && lanes_pk_ok;  // (both typings of the stencil)
     // kernel 8 (wide register kernel): 4, 8 or 16 lanes per environment (the fewest that hold the wire), 32 cells each in
     // registers; uniform geometry, float32 stencil, at most 512 segments.  Chosen by itself for a batch
     // that one round of blocks covers at one wave per
@@ -642,7 +646,7 @@ static int32_t plan_launch(wedm_ctx* ctx, bool single, bool tr, bool frozen_ok, 
         // single-microsecond launches: the stream kernel where one round of blocks covers the batch with chunks of
         // at most 64 cells (measured: 27.5 vs 30.3 us at 65 536 x 128, 20.5 vs 24.9 us at 4 096 x 400), else the
         // split global-memory kernel (32.7 vs 48.9 us at 32 768 x 400, where the stream kernel needs two rounds)
-        if (f64) variant = (!single && fused_ok) ? 3 : (lanes_ok ? 2 : 1);
+        if (f64) variant = (!single && fused_ok) ? 3 : ((lanes_ok || use_pk) ? 2 : 1);
         else if (single) variant = (stream_ok && stream_auto) ? 6 : 5;
         else if (packed_ok && (ctx->auto_prefers_packed || !fused_ok)) variant = 4;
         else if (fused_ok) variant = 3;
@@ -721,8 +725,9 @@ static int32_t plan_launch(wedm_ctx* ctx, bool single, bool tr, bool frozen_ok, 
     } else if ((variant == 2 || variant == 11) && use_pk) {
         grid = (ctx->num_envs + 256 / pklanes - 1) / (256 / pklanes);
         fl = (2 * (size_t)((ctx->n_seg_max + 2 * pklanes - 1) / (2 * pklanes)) + 2) * 1024;
-        fn = tr ? pick_lanes_pk<true>(pklanes) : pick_lanes_pk<false>(pklanes);
-        std::snprintf(out.name, sizeof(out.name), "wedm_step_lanes_pk<%d><<<%d,256,%zuB>>>", pklanes, grid, fl);
+        fn = f64 ? (tr ? pick_lanes_pk<true, true>(pklanes) : pick_lanes_pk<false, true>(pklanes))
+                 : (tr ? pick_lanes_pk<true>(pklanes) : pick_lanes_pk<false>(pklanes));
+        std::snprintf(out.name, sizeof(out.name), "wedm_step_lanes_pk<%d>%s<<<%d,256,%zuB>>>", pklanes, f64 ? "[f64 stencil]" : "", grid, fl);
     } else if (variant == 2 || variant == 10) {
         grid = (ctx->num_envs + 256 / glanes - 1) / (256 / glanes);
         fl = (size_t)((ctx->n_seg_max + glanes - 1) / glanes) * 1024;

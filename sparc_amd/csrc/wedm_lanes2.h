@@ -11,7 +11,8 @@
 // environment's last cell, a plasma cell) are computed by the predicated formula from OLD values before the walk and written
 // after it, exactly as wedm_step_lanes does.  Cells past an environment's wire keep their value (the write-back copies all
 // n_seg_max rows).  A wave with a negative plasma heat walks cell by cell on the predicated formula (same results).
-// float32 stencil only (stencil_mode 1 stays on wedm_step_lanes).
+// F64 (round 4): the same walk with every interior cell in Numba's typing of wire.py:58-123 (cell_f64 of wedm_k_regs.h: 18 float64
+// operations per cell, the two cells of a pair one after the other) -- stencil_mode 1 on per-environment geometry.
 #pragma once
 
 // One microsecond of the packed any-geometry walk for this lane's two virtual chunks (LDS rows of NT floats); returns the
@@ -22,9 +23,10 @@ struct LanesPkGeom {   // per lane, fixed for the launch
     uint32_t zs, zw, cbot, cw, span;
     bool has_inner;
 };
-template <int L, int NT>
+template <int L, int NT, bool F64 = false>
 __device__ __forceinline__ float lanes_pk_step(float* col, const LanesPkGeom& q, bool keep, const Geom& g, const Coef& cf, const Persist& ps,
-                                               float spool, float tref, float alpha, float tdiel) {
+                                               float spool, float tref, float alpha, float tdiel,
+                                               const StencilF64& h64 = StencilF64{0.0, 0.0, 0.0}, float h_base = 0.0f, float h_zone = 0.0f) {
     const int c = q.c, Cv = q.Cv, R = q.R, n = q.n, baseA = q.baseA, baseB = q.baseB, own_last = q.own_last;
     const uint32_t zs = q.zs, zw = q.zw, cbot = q.cbot, cw = q.cw, span = q.span;
     const bool has_inner = q.has_inner;
@@ -50,7 +52,7 @@ __device__ __forceinline__ float lanes_pk_step(float* col, const LanesPkGeom& q,
             float tm = r > 0 ? left : (v ? a_last : halo_l);
             if (i == 1) tm = spool;
             const float tp = last ? 0.0f : col[(row + 2) * NT];
-            return stencil_cell(i, n, tm, col[row * NT], tp, g, cf, ps, tref, alpha, tdiel);
+            return rw_cell<F64>(i, n, tm, col[row * NT], tp, g, cf, ps, tref, alpha, tdiel, h64, h_base, h_zone);
         };
         const int own_pl = (keep && cf.pidx >= 1 && cf.pidx < n) ? owner(cf.pidx) : 0;
         float tpl = 0.0f, tlast = 0.0f;
@@ -59,9 +61,10 @@ __device__ __forceinline__ float lanes_pk_step(float* col, const LanesPkGeom& q,
         }
         if (own_last && keep) tlast = patch_value(n - 1, own_last, true);
 
-        const float jf_lane = (cf.joule_on && keep) ? cf.jf : 0.0f;
+        // (float64 typing: the Joule entry is a flag, the factor is cf.jf64; the convection entries are the float32 h_eff themselves)
+        const float jf_lane = (cf.joule_on && keep) ? (F64 ? 1.0f : cf.jf) : 0.0f;
         const bool joule_wave = __any(jf_lane != 0.0f);
-        const float cz = ps.conv_zone, cb = ps.conv_base;
+        const float cz = F64 ? h_zone : ps.conv_zone, cb = F64 ? h_base : ps.conv_base;
         f2 tm1 = {halo_l, a_last};
         f2 tc = {col[0], col[NT]};
         for (int r0 = 0; r0 < Cv; r0 += 8) {
@@ -95,8 +98,26 @@ __device__ __forceinline__ float lanes_pk_step(float* col, const LanesPkGeom& q,
                     cv[u] = f2{(ia - zs < zw) ? cz : cb, (ib - zs < zw) ? cz : cb};
                     jv[u] = f2{(ia - cbot < cw) ? jf_lane : 0.0f, (ib - cbot < cw) ? jf_lane : 0.0f};
                 }
-                if (joule_wave) tile_staged<f2, true, true, W>(old, tn, o, g.k, g.tuf, cv, tdiel, ps.adv, jv, alpha, tref);
-                else tile_staged<f2, false, true, W>(old, tn, o, g.k, g.tuf, cv, tdiel, ps.adv, jv, alpha, tref);
+                if (F64) {
+#pragma unroll
+                    for (int u = o; u < o + W; ++u) {
+                        const double cA = (double)cv[u].x * g.a64, cB = (double)cv[u].y * g.a64;
+                        if (joule_wave) {
+                            tn[u].x = cell_f64<true>(old[u].x, old[u + 1].x, old[u + 2].x, g.k64, g.tuf64, cA, h64.tdiel, ps.adv64,
+                                                     jv[u].x != 0.0f ? cf.jf64 : 0.0, h64.alpha, h64.tref);
+                            tn[u].y = cell_f64<true>(old[u].y, old[u + 1].y, old[u + 2].y, g.k64, g.tuf64, cB, h64.tdiel, ps.adv64,
+                                                     jv[u].y != 0.0f ? cf.jf64 : 0.0, h64.alpha, h64.tref);
+                        } else {
+                            tn[u].x = cell_f64<false>(old[u].x, old[u + 1].x, old[u + 2].x, g.k64, g.tuf64, cA, h64.tdiel, ps.adv64, 0.0, h64.alpha, h64.tref);
+                            tn[u].y = cell_f64<false>(old[u].y, old[u + 1].y, old[u + 2].y, g.k64, g.tuf64, cB, h64.tdiel, ps.adv64, 0.0, h64.alpha, h64.tref);
+                        }
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+                } else if (joule_wave) {
+                    tile_staged<f2, true, true, W>(old, tn, o, g.k, g.tuf, cv, tdiel, ps.adv, jv, alpha, tref);
+                } else {
+                    tile_staged<f2, false, true, W>(old, tn, o, g.k, g.tuf, cv, tdiel, ps.adv, jv, alpha, tref);
+                }
             }
             // ONE predicate per cell for store and maximum: interior (1 <= i <= n - 2) and this environment live.  Wire cell
             // 0 and the last cell are written after the walk anyway (spool temperature, the patched value), cells past the
@@ -146,7 +167,7 @@ __device__ __forceinline__ float lanes_pk_step(float* col, const LanesPkGeom& q,
                 const int i = cbase + r;
                 if (i < n && keep) {
                     float tn = spool;
-                    if (i >= 1) tn = stencil_cell(i, n, (i == 1) ? spool : tm1, tc, nx, g, cf, ps, tref, alpha, tdiel);
+                    if (i >= 1) tn = rw_cell<F64>(i, n, (i == 1) ? spool : tm1, tc, nx, g, cf, ps, tref, alpha, tdiel, h64, h_base, h_zone);
                     col[(2 * r + v) * NT] = tn;
                     tmax = fmax_gt(tmax, tn);
                 }
@@ -158,7 +179,7 @@ __device__ __forceinline__ float lanes_pk_step(float* col, const LanesPkGeom& q,
     return tmax;
 }
 
-template <int L, bool TRACE>
+template <int L, bool TRACE, bool F64 = false>
 __global__ void __launch_bounds__(256, 2) wedm_step_lanes_pk(const KArgs k) {
     const ColdRef cold = kernarg_cold();
     Hot hv = k.hot;
@@ -184,6 +205,8 @@ __global__ void __launch_bounds__(256, 2) wedm_step_lanes_pk(const KArgs k) {
     Geom g;
     Persist ps{0.0f, 0.0f, 0.0f, 0};
     load_geom(k.hot, cold, live ? e : 0, g);
+    StencilF64 f64c{0.0, 0.0, 0.0};
+    if (F64) { const wedm_params* pp = cold->p; f64c = StencilF64{pp->temp_ref, pp->alpha_rho, pp->dielectric_temperature}; }
     if (live) load_env(cold, e, s);
     else { s.done = WEDM_DEAD_LANE; s.unwind = 0.0; s.h_base = 0.0f; s.h_zone = 0.0f; }
     float* col = lds + tid;
@@ -230,7 +253,7 @@ __global__ void __launch_bounds__(256, 2) wedm_step_lanes_pk(const KArgs k) {
         freeze_wire(s);
         const bool keep = !s.done;
 
-        float tmax = lanes_pk_step<L, 256>(col, pkg, keep, g, cf, ps, spool, tref, alpha, tdiel);
+        float tmax = lanes_pk_step<L, 256, F64>(col, pkg, keep, g, cf, ps, spool, tref, alpha, tdiel, f64c, s.h_base, s.h_zone);
         tmax = max_over_env_lanes<L>(tmax);
         unfreeze_wire(hv, s);
         if (!s.done) {

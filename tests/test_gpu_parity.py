@@ -1549,7 +1549,8 @@ def test_float64_stencil_mode_matches_oracle_bit_for_bit(shape):
     gpu, cpu = make_pair(n, **kw)
     both((gpu, cpu), lambda e: (e.reset(seed=77), close_gap(e, 24.0, 10.0)))
     # (kernel 3, the tile walk: uniform geometry; kernel 7, the register walk: at most 128 segments)
-    variants = ((0, 0), (2, 0), (1, 0)) if shape == "per_env" else ((0, 0), (3, 0), (2, 0), (1, 0))
+    # (kernel 2: the packed any-geometry walk with float64-typed cells; kernel 10: its cell-by-cell form)
+    variants = ((0, 0), (2, 0), (2, 4), (2, 16), (10, 0), (1, 0)) if shape == "per_env" else ((0, 0), (3, 0), (2, 0), (10, 0), (1, 0))
     if shape == "config3":
         variants += ((7, 1), (7, 2), (8, 4))
     if shape == "default400":
@@ -1564,11 +1565,19 @@ def test_float64_stencil_mode_matches_oracle_bit_for_bit(shape):
         assert "[f64 stencil]" in gpu._backend.last_kernel()
         check(gpu, cpu, n)
     assert int(gpu.state.spark_count.sum()) > 100
+    # a launch with trace samples (the TRACE instantiation of whatever the plan takes for this shape and typing)
+    gpu.set_kernel(0, 0)
+    gpu.bind_trace(["voltage"], every=7, capacity=64, wire_temperature=True)
+    for env in (gpu, cpu):
+        env.step_many(env.make_action(0.1, 80.0, 17, 3.0, 40.0), 300)
+    assert "[f64 stencil]" in gpu._backend.last_kernel()
+    check(gpu, cpu, n)
+    gpu.unbind_trace()
     # and it really is another arithmetic: the float32 typing differs in the last bits of T
     f32 = WireEDMEnv(num_envs=n, device="cuda:0", **{k: v for k, v in kw.items() if k != "stencil_dtype"})
     f32.reset(seed=77)
     close_gap(f32, 24.0, 10.0)
-    f32.step_many(f32.make_action(0.1, 80.0, 17, 3.0, 40.0), 903 * len(variants))
+    f32.step_many(f32.make_action(0.1, 80.0, 17, 3.0, 40.0), 903 * len(variants) + 300)
     d = (f32.state.T[:, :n] - gpu.state.T[:, :n]).abs().max().item()
     assert 0.0 < d < 1e-3
     from sparc_amd._lib import WedmError

@@ -13,4 +13,7 @@ run "configs[2] fused (kernel 3)" "" --kernel 3
 run "configs[1] auto" "" --workload config2
 run "configs[1] fused (kernel 3)" "" --workload config2 --kernel 3
 run "configs[3] shard auto" "" --workload config4
+run "configs[3] shard fused (kernel 3)" "" --workload config4 --kernel 3
+run "configs[4] shard auto" "" --workload config5
+run "configs[4] shard cell by cell (kernel 10)" "" --workload config5 --kernel 10
 for t in "$@"; do run "$t configs[2] auto" build/ablate/libwedm_$t.so; run "$t configs[1] auto" build/ablate/libwedm_$t.so --workload config2; done
