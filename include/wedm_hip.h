@@ -413,7 +413,8 @@ int64_t wedm_trace_samples(wedm_ctx* ctx);
  * on three waves of a block, the scalar physics on the fourth, as kernel 9; by name only: not faster at BASELINE configs[4]),
  * 12 = the served form of kernel 7 (two walker waves with the wire in registers + a scalar wave with all 64 lanes busy; by name
  * only: 1.666e10 against kernel 7's 1.674e10 at the headline batch, spills; at most 128 segments, no trace sample).
- * All variants produce bit-identical results.  With wedm_params.stencil_mode 1 only 0, 1, 2 (= 10), 3, 7 and 8 are accepted (7 / 8: the
+ * All variants produce bit-identical results.  With wedm_params.stencil_mode 1 only 0, 1, 2 (= 10), 3, 6 (launches of one microsecond
+ * without a trace sample, chunks of at most 64 cells), 7 and 8 are accepted (7 / 8: the
  * register walks with every interior cell in Numba's typing -- 18 float64 operations per cell -- and, for kernel 8, a
  * 256-register instantiation at two blocks per CU for batches beyond one wave per SIMD; 3: the tile walk with per-cell
  * coefficients; no packed, served or single-microsecond form -- 0 takes kernel 7 from 20 480 environments of at most 128

@@ -34,72 +34,6 @@ __device__ __forceinline__ float max3_raw(float a, float b, float c) {
 }
 
 
-#ifndef WEDM_REGS_F64_FENCE
-#define WEDM_REGS_F64_FENCE 1  // pairs between scheduling fences in quad_f64 (A/B: 0: 7.9e9, 1: 8.3e9, 2: 7.9e9 at 65 536 x 128)
-#endif
-// ---- stencil_mode 1 (the stencil as Numba types wire.py:58-123) in the register walk.
-// An interior cell of that typing: stencil_cell_f64's sequence of float64 expressions and float32 roundings with the
-// coefficients handed in; the Joule block only in the tiles that have current in this microsecond (JOULE), as the reference
-// skips it (wire.py:96-100) -- 18 float64 operations per cell without it (8 of them conversions), 25 with it, against 5.5 of
-// the packed float32 form.
-template <bool JOULE>
-__device__ __forceinline__ float cell_f64(float tm1, float tc, float tp1, double k64, double tuf64, double conv64, double tdiel64,
-                                          double adv64, double jfe64, double alpha64, double tref64) {
-    const double m = (double)tm1, t = (double)tc;
-    // (m - 2.0 * t: 2 t is exact, so the difference rounds once -- one fused operation instead of t + t and a subtraction)
-    float d = (float)(k64 * (__builtin_fma(-2.0, t, m) + (double)tp1));
-    if (JOULE) {
-        const double rho_T = 1.0 + alpha64 * (t - tref64);
-        d = (float)((double)d + jfe64 * rho_T);
-    }
-    d = (float)((double)d - conv64 * (t - tdiel64));
-    d = (float)((double)d + adv64 * (m - t));
-    return (float)(t + (double)d * tuf64);
-}
-
-// Four pairs of a tile in that typing.  `hc`: the float32 convection entries h_eff of the two halves (wire.py:205; the
-// coefficient is (double)h * A), per pair where PERCELL; `jfl`: non-zero where a cell lies between the contacts of a lane
-// that carries current.
-template <bool JOULE, bool PERCELL>
-__device__ __forceinline__ void quad_f64(const f2 (&tm)[4], const f2 (&tc)[4], const f2 (&tp)[4], f2 (&tn)[4], const Geom& g,
-                                         const f2 (&hc)[4], const Persist& ps, const f2 (&jfl)[4], const StencilF64& h, double jf64) {
-    double cA = (double)hc[0].x * g.a64, cB = (double)hc[0].y * g.a64;
-    double jA = (JOULE && jfl[0].x != 0.0f) ? jf64 : 0.0, jB = (JOULE && jfl[0].y != 0.0f) ? jf64 : 0.0;
-#pragma unroll
-    for (int u = 0; u < 4; ++u) {
-        if (PERCELL && u > 0) {
-            cA = (double)hc[u].x * g.a64; cB = (double)hc[u].y * g.a64;
-            jA = (JOULE && jfl[u].x != 0.0f) ? jf64 : 0.0; jB = (JOULE && jfl[u].y != 0.0f) ? jf64 : 0.0;
-        }
-        tn[u].x = cell_f64<JOULE>(tm[u].x, tc[u].x, tp[u].x, g.k64, g.tuf64, cA, h.tdiel, ps.adv64, jA, h.alpha, h.tref);
-#if WEDM_REGS_F64_FENCE < 0
-        __builtin_amdgcn_sched_barrier(0);
-#endif
-        tn[u].y = cell_f64<JOULE>(tm[u].y, tc[u].y, tp[u].y, g.k64, g.tuf64, cB, h.tdiel, ps.adv64, jB, h.alpha, h.tref);
-#if WEDM_REGS_F64_FENCE < 0
-        __builtin_amdgcn_sched_barrier(0);
-#elif WEDM_REGS_F64_FENCE > 0
-        if ((u + 1) % WEDM_REGS_F64_FENCE == 0) __builtin_amdgcn_sched_barrier(0);  // (cells in flight: 2 per pair between fences)
-#endif
-    }
-}
-
-// what wedm_regs_walk.inc calls: the packed float32 quad / the predicated float32 cell, or their float64-typed forms
-template <bool F64, bool JOULE, bool PERCELL, int SW>
-__device__ __forceinline__ void rw_quad(const f2 (&tm)[4], const f2 (&tc)[4], const f2 (&tp)[4], f2 (&tn)[4], const Geom& g,
-                                        const f2 (&conv)[4], float tdiel, const Persist& ps, const f2 (&jfe)[4], float alpha,
-                                        float tref, const StencilF64& h, const Coef& cf) {
-    if (F64) quad_f64<JOULE, PERCELL>(tm, tc, tp, tn, g, conv, ps, jfe, h, cf.jf64);
-    else quad_staged<JOULE, PERCELL, SW>(tm, tc, tp, tn, g.k, g.tuf, conv, tdiel, ps.adv, jfe, alpha, tref);
-}
-template <bool F64>
-__device__ __forceinline__ float rw_cell(int i, int n_seg, float tm1, float tc, float tp1, const Geom& g, const Coef& cf,
-                                         const Persist& ps, float tref, float alpha, float tdiel, const StencilF64& h,
-                                         float h_base, float h_zone) {
-    if (F64) return stencil_cell_f64(i, n_seg, tm1, tc, tp1, g, cf, ps, h, h_base, h_zone);
-    return stencil_cell(i, n_seg, tm1, tc, tp1, g, cf, ps, tref, alpha, tdiel);
-}
-
 #ifndef WEDM_REGS_DENSE
 #define WEDM_REGS_DENSE WEDM_PACKED_DENSE  // the quiet line also carries sparks that keep burning or end (see WEDM_PACKED_DENSE)
 #endif

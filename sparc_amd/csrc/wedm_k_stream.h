@@ -30,8 +30,12 @@
 #define WEDM_GLOBAL __attribute__((address_space(1)))
 // ONE: the instantiation for launches of exactly one microsecond (the host picks it; no loop over further microseconds,
 // and a walk out of registers for the waves that can take it: rest_single below)
-template <int L, bool TRACE, int CMAX, bool ONE = false>
+// F64 (with ONE only): stencil_mode 1 -- the register walk in Numba's typing of wire.py:58-123 (cell_f64 / rw_quad of
+// wedm_common.h); a wave that cannot take the register walk (a frozen environment, a negative plasma heat, a tile with several
+// flag changes) walks every cell of its chunk on the per-cell code in that typing.
+template <int L, bool TRACE, int CMAX, bool ONE = false, bool F64 = false>
 __global__ void __launch_bounds__(256, 2) wedm_step_stream(const KArgs k) {
+    static_assert(!F64 || (ONE && !TRACE), "the float64 typing exists for the single-microsecond instantiation only");
     const ColdRef cold = kernarg_cold();
     Hot hv = k.hot;
     extern __shared__ __attribute__((aligned(16))) float lds[];
@@ -64,6 +68,8 @@ __global__ void __launch_bounds__(256, 2) wedm_step_stream(const KArgs k) {
     Geom g;
     Persist ps{0.0f, 0.0f, 0.0f, 0};
     load_geom(k.hot, cold, live ? e : 0, g);
+    StencilF64 f64c{0.0, 0.0, 0.0};
+    if (F64) { const auto pp = opaque_const(cold->p); f64c = StencilF64{pp->temp_ref, pp->alpha_rho, pp->dielectric_temperature}; }
     WEDM_S2_STAMP(11);  // geometry constants here (two dependent scalar loads)
     double h64[2] = {0.0, 0.0};  // convection coefficients as loaded; converted after the wire rows are requested
     // with an even number of lanes per environment the two lanes of a pair each request ONE row of a pair of rows
@@ -202,9 +208,9 @@ __global__ void __launch_bounds__(256, 2) wedm_step_stream(const KArgs k) {
         // a wave with a frozen environment (or a negative plasma heat) walks every cell on the
         // predicated path; results are identical, only slower
         const bool all_slow = __any(cf.q < 0.0f) || __any(s.done);
-        const uint32_t slow_now = all_slow ? 0xffffffffu : kind_s;
+        const uint32_t slow_now = (all_slow || F64) ? 0xffffffffu : kind_s;  // (F64: this path is the rare one, every tile cell by cell)
         // regular tiles of THIS microsecond: a contact-flag change inside a tile only matters while current flows
-        const uint32_t n_now = (kind_n | kind_ne | (__any(cf.joule_on && !s.done && cf.jf != 0.0f) ? 0u : kind_nj)) & ~(all_slow ? 0xffffffffu : 0u);
+        const uint32_t n_now = (kind_n | kind_ne | (__any(cf.joule_on && !s.done && cf.jf != 0.0f) ? 0u : kind_nj)) & ~((all_slow || F64) ? 0xffffffffu : 0u);
 
         // ---- patched cells: the plasma cell and the wire's last cell are computed with the
         // full predicated formula from OLD values now and written after the walk
@@ -217,14 +223,14 @@ __global__ void __launch_bounds__(256, 2) wedm_step_stream(const KArgs k) {
                 if (cf.pidx == 1) tm = spool;
                 const float tcc = col[jp * 256];
                 const float tp = jp < C - 1 ? col[(jp + 1) * 256] : halo_r;
-                tpl = stencil_cell(cf.pidx, n, tm, tcc, tp, g, cf, ps, tref, alpha, tdiel);
+                tpl = rw_cell<F64>(cf.pidx, n, tm, tcc, tp, g, cf, ps, tref, alpha, tdiel, f64c, s.h_base, s.h_zone);
             }
         }
         if (owns_last && !s.done) {
             const int jl = n - 1 - cbase;
             float tm = jl > 0 ? col[(jl - 1) * 256] : halo_l;
             if (n - 1 == 1) tm = spool;
-            tlast = stencil_cell(n - 1, n, tm, col[jl * 256], 0.0f, g, cf, ps, tref, alpha, tdiel);
+            tlast = rw_cell<F64>(n - 1, n, tm, col[jl * 256], 0.0f, g, cf, ps, tref, alpha, tdiel, f64c, s.h_base, s.h_zone);
         }
 
         float tmax = spool;
@@ -279,7 +285,7 @@ __global__ void __launch_bounds__(256, 2) wedm_step_stream(const KArgs k) {
                     tmax = fmax_gt(tmax, fmax_gt(m0, m1));
                     tm1 = cur[6];
                     tc = cur[7];
-                } else if (!((slow_now >> t) & 1u)) {
+                } else if (!F64 && !((slow_now >> t) & 1u)) {
                     // TILE_B: interior formula everywhere, one flag change at `split`, boundary and
                     // out-of-wire cells excluded from the max (they are patched / never read)
                     const int split = (int)((split_pack[t >> 3] >> ((t & 7) * 4)) & 15u);
@@ -331,10 +337,15 @@ __global__ void __launch_bounds__(256, 2) wedm_step_stream(const KArgs k) {
                         const float conv = zbit ? ps.conv_zone : ps.conv_base;
                         const float jfe = jbit ? jf_lane : 0.0f;
                         const float tp1 = cur[0];
-                        float tn = interior_cell<true>(tm1, tc, tp1, g.k, g.tuf, conv, tdiel, ps.adv, jfe, alpha, tref);
+                        float tn;
+                        if (F64)
+                            tn = cell_f64<true>(tm1, tc, tp1, g.k64, g.tuf64, (double)(zbit ? s.h_zone : s.h_base) * g.a64, f64c.tdiel, ps.adv64,
+                                                (jbit && jf_lane != 0.0f) ? cf.jf64 : 0.0, f64c.alpha, f64c.tref);
+                        else
+                            tn = interior_cell<true>(tm1, tc, tp1, g.k, g.tuf, conv, tdiel, ps.adv, jfe, alpha, tref);
                         if (!inter && valid) {  // boundary cells and irregular waves: predicated formula
                             const int i = cbase + jj;
-                            tn = (i >= 1) ? stencil_cell(i, n, (i == 1) ? spool : tm1, tc, tp1, g, cf, ps, tref, alpha, tdiel)
+                            tn = (i >= 1) ? rw_cell<F64>(i, n, (i == 1) ? spool : tm1, tc, tp1, g, cf, ps, tref, alpha, tdiel, f64c, s.h_base, s.h_zone)
                                           : spool;
                         }
                         if (valid) {
@@ -410,7 +421,7 @@ __global__ void __launch_bounds__(256, 2) wedm_step_stream(const KArgs k) {
         const float halo_l = (c > 0) ? old_at(C - 1, -1) : spool;
         const float halo_r = (c < L - 1) ? old_at(0, 1) : 0.0f;
         // regular tiles of THIS microsecond: a contact-flag change inside a tile only matters while current flows
-        const uint32_t n_now = kind_n | kind_ne | (__any(cf.joule_on && cf.jf != 0.0f) ? 0u : kind_nj);
+        const uint32_t n_now = kind_n | kind_ne | (__any(cf.joule_on && (F64 || cf.jf != 0.0f)) ? 0u : kind_nj);
         // ---- patched cells: full predicated formula from OLD values, stored after the walk
         const bool owns_pl = cf.pidx >= 1 && cf.pidx >= cbase && cf.pidx < cbase + C;
         float tpl = 0.0f, tlast = 0.0f;
@@ -420,17 +431,19 @@ __global__ void __launch_bounds__(256, 2) wedm_step_stream(const KArgs k) {
                 float tm = jp > 0 ? old_at(jp - 1, 0) : halo_l;
                 if (cf.pidx == 1) tm = spool;
                 const float tp = jp < C - 1 ? old_at(jp + 1, 0) : halo_r;
-                tpl = stencil_cell(cf.pidx, n, tm, old_at(jp, 0), tp, g, cf, ps, tref, alpha, tdiel);
+                tpl = rw_cell<F64>(cf.pidx, n, tm, old_at(jp, 0), tp, g, cf, ps, tref, alpha, tdiel, f64c, s.h_base, s.h_zone);
             }
         }
         if (owns_last) {
             const int jl = n - 1 - cbase;
             float tm = jl > 0 ? old_at(jl - 1, 0) : halo_l;
             if (n - 1 == 1) tm = spool;
-            tlast = stencil_cell(n - 1, n, tm, old_at(jl, 0), 0.0f, g, cf, ps, tref, alpha, tdiel);
+            tlast = rw_cell<F64>(n - 1, n, tm, old_at(jl, 0), 0.0f, g, cf, ps, tref, alpha, tdiel, f64c, s.h_base, s.h_zone);
         }
         float tmax = spool;
-        const float jf_lane = cf.joule_on ? cf.jf : 0.0f;
+        // (float64 typing: the Joule entry is a flag -- the factor is cf.jf64 -- and the convection entries are the float32 h_eff)
+        const float jf_lane = cf.joule_on ? (F64 ? 1.0f : cf.jf) : 0.0f;
+        const float czone = F64 ? s.h_zone : ps.conv_zone, cbase_cv = F64 ? s.h_base : ps.conv_base;
         const bool joule_wave = __any(jf_lane != 0.0f);
         char* const Tw = (char*)cold->s.T;
 #pragma unroll
@@ -451,15 +464,15 @@ __global__ void __launch_bounds__(256, 2) wedm_step_stream(const KArgs k) {
                     tc[m] = f2{o[2 * m + 1], o[2 * m + 2]};
                     tp[m] = f2{o[2 * m + 2], o[2 * m + 3]};
                 }
-                const float conv_lo = ((zone_lo >> t) & 1u) ? ps.conv_zone : ps.conv_base;
+                const float conv_lo = ((zone_lo >> t) & 1u) ? czone : cbase_cv;
                 const float jfe_lo = ((joule_lo >> t) & 1u) ? jf_lane : 0.0f;
                 const uint32_t off = offc + (uint32_t)(j >> 2) * rowb;
                 if ((n_now >> t) & 1u) {
                     cv[0] = f2{conv_lo, conv_lo}; jv[0] = f2{jfe_lo, jfe_lo};
                     if (joule_wave && __any(jfe_lo != 0.0f))
-                        quad_staged<true, false>(tm, tc, tp, tn, g.k, g.tuf, cv, tdiel, ps.adv, jv, alpha, tref);
+                        rw_quad<F64, true, false, WEDM_QUAD_STAGE_W>(tm, tc, tp, tn, g, cv, tdiel, ps, jv, alpha, tref, f64c, cf);
                     else
-                        quad_staged<false, false>(tm, tc, tp, tn, g.k, g.tuf, cv, tdiel, ps.adv, jv, alpha, tref);
+                        rw_quad<F64, false, false, WEDM_QUAD_STAGE_W>(tm, tc, tp, tn, g, cv, tdiel, ps, jv, alpha, tref, f64c, cf);
                     // the wire's end cells, where a regular tile holds one (kind_ne / kind_nj): cell 0 stays at the spool
                     // temperature; the last cell is kept out of the maximum here and patched after the walk
                     tn[0].x = (c == 0 && t == 0) ? spool : tn[0].x;
@@ -475,7 +488,7 @@ __global__ void __launch_bounds__(256, 2) wedm_step_stream(const KArgs k) {
                     // stay out of the maximum (patched after the walk / never stored)
                     const int split = (int)((split_pack[t >> 3] >> ((t & 7) * 4)) & 15u);
                     const int cnt = (C - j) < 8 ? (C - j) : 8;
-                    const float conv_hi = ((zone_hi >> t) & 1u) ? ps.conv_zone : ps.conv_base;
+                    const float conv_hi = ((zone_hi >> t) & 1u) ? czone : cbase_cv;
                     const float jfe_hi = ((joule_hi >> t) & 1u) ? jf_lane : 0.0f;
                     const uint32_t im1 = (uint32_t)(cbase + j - 1);  // (i - 1) of the tile's first cell
                     const uint32_t span = (uint32_t)(n - 3);         // interior <=> (i - 1) <= n - 3 (unsigned)
@@ -484,8 +497,8 @@ __global__ void __launch_bounds__(256, 2) wedm_step_stream(const KArgs k) {
                         cv[m] = f2{2 * m < split ? conv_lo : conv_hi, 2 * m + 1 < split ? conv_lo : conv_hi};
                         jv[m] = f2{2 * m < split ? jfe_lo : jfe_hi, 2 * m + 1 < split ? jfe_lo : jfe_hi};
                     }
-                    if (joule_wave) quad_staged<true, true>(tm, tc, tp, tn, g.k, g.tuf, cv, tdiel, ps.adv, jv, alpha, tref);
-                    else quad_staged<false, true>(tm, tc, tp, tn, g.k, g.tuf, cv, tdiel, ps.adv, jv, alpha, tref);
+                    if (joule_wave) rw_quad<F64, true, true, WEDM_QUAD_STAGE_W>(tm, tc, tp, tn, g, cv, tdiel, ps, jv, alpha, tref, f64c, cf);
+                    else rw_quad<F64, false, true, WEDM_QUAD_STAGE_W>(tm, tc, tp, tn, g, cv, tdiel, ps, jv, alpha, tref, f64c, cf);
                     float tnv[8];
 #pragma unroll
                     for (int m = 0; m < 4; ++m) { tnv[2 * m] = tn[m].x; tnv[2 * m + 1] = tn[m].y; }

@@ -76,6 +76,10 @@ using namespace wedm;
 #define WEDM_EXT_LANES_PK(L, tr) extern template __global__ void wedm_step_lanes_pk<L, tr>(const KArgs);
 #define WEDM_INST_LANES_PK_F64(L, tr) template __global__ void wedm_step_lanes_pk<L, tr, true>(const KArgs);
 #define WEDM_EXT_LANES_PK_F64(L, tr) extern template __global__ void wedm_step_lanes_pk<L, tr, true>(const KArgs);
+// stencil_mode 1 on the stream kernel: the single-microsecond instantiation <L, false, 64, ONE = true, F64 = true>
+#define WEDM_STREAM_F64_LIST(X) X(1) X(2) X(4) X(8) X(16)
+#define WEDM_INST_STREAM_F64(L) template __global__ void wedm_step_stream<L, false, 64, true, true>(const KArgs);
+#define WEDM_EXT_STREAM_F64(L) extern template __global__ void wedm_step_stream<L, false, 64, true, true>(const KArgs);
 #define WEDM_LANES_SERVED_LIST(X) X(4) X(8) X(16)
 #define WEDM_INST_LANES_SERVED(L) template __global__ void wedm_step_lanes_served<L>(const KArgs);
 #define WEDM_EXT_LANES_SERVED(L) extern template __global__ void wedm_step_lanes_served<L>(const KArgs);
@@ -108,6 +112,7 @@ WEDM_LANES_SERVED_LIST(WEDM_INST_LANES_SERVED)
 WEDM_REGS_F64_LIST(WEDM_INST_REGS_F64)
 WEDM_WIDE_F64_LIST(WEDM_INST_WIDE_F64)
 WEDM_LANES_PK_LIST(WEDM_INST_LANES_PK_F64)
+WEDM_STREAM_F64_LIST(WEDM_INST_STREAM_F64)
 #else
 #if defined(WEDM_PART)
 WEDM_PACKED_LIST(WEDM_EXT_PACKED)
@@ -119,6 +124,7 @@ WEDM_REGS_F64_LIST(WEDM_EXT_REGS_F64)
 WEDM_WIDE_F64_LIST(WEDM_EXT_WIDE_F64)
 WEDM_LANES_PK_LIST(WEDM_EXT_LANES_PK)
 WEDM_LANES_PK_LIST(WEDM_EXT_LANES_PK_F64)
+WEDM_STREAM_F64_LIST(WEDM_EXT_STREAM_F64)
 WEDM_LANES_SERVED_LIST(WEDM_EXT_LANES_SERVED)
 #endif
 
@@ -246,6 +252,7 @@ struct wedm_ctx {
     bool walk4_ok[5] = {false, false, false, false, false};
     bool walk_regs_ok = false;
     int32_t walk4_C[5] = {0, 0, 0, 0, 0};
+    uint32_t walk4_kind_s[5] = {0u, 0u, 0u, 0u, 0u};  // tiles with several flag changes (the stream kernel's register walk has no code for them)
     uint32_t walk_n1z = 0;             // bit i: table i has a one-change tile with a zone change (see WalkTable::kind_n1_mask)
     // signal trace (wedm_bind_trace): descriptor, microseconds stepped and samples written since the bind
     const double* replay = nullptr;    // wedm_bind_rng_replay
@@ -379,13 +386,13 @@ template <bool TR> static const void* pick_fused_f64(int L) {
     }
 }
 // rows a lane of the stream kernel holds in registers: 64 (128 segments over 2 lanes, 400 over 8) or 104 (400 over 4)
-template <bool TR, int CMAX, bool ONE = false> static const void* pick_stream(int L) {
+template <bool TR, int CMAX, bool ONE = false, bool F64 = false> static const void* pick_stream(int L) {
     switch (L) {
-        case 1: return (const void*)wedm_step_stream<1, TR, CMAX, ONE>;
-        case 2: return (const void*)wedm_step_stream<2, TR, CMAX, ONE>;
-        case 4: return (const void*)wedm_step_stream<4, TR, CMAX, ONE>;
-        case 8: return (const void*)wedm_step_stream<8, TR, CMAX, ONE>;
-        default: return (const void*)wedm_step_stream<16, TR, CMAX, ONE>;
+        case 1: return (const void*)wedm_step_stream<1, TR, CMAX, ONE, F64>;
+        case 2: return (const void*)wedm_step_stream<2, TR, CMAX, ONE, F64>;
+        case 4: return (const void*)wedm_step_stream<4, TR, CMAX, ONE, F64>;
+        case 8: return (const void*)wedm_step_stream<8, TR, CMAX, ONE, F64>;
+        default: return (const void*)wedm_step_stream<16, TR, CMAX, ONE, F64>;
     }
 }
 template <bool TR, bool FZ, bool EX> static const void* pick_packed(int L) {
@@ -566,8 +573,14 @@ static int32_t plan_launch(wedm_ctx* ctx, bool single, bool tr, bool frozen_ok, 
     // Numba's typing of the stencil: the register kernels (uniform geometry; at most 128 / 512 segments), the fused tile walk
     // (uniform geometry), the predicated LDS kernel (any geometry), or in place in global memory; no packed LDS form, no served
     // form, no stream / split kernel
-    if (f64 && variant != 0 && variant != 1 && variant != 2 && variant != 3 && variant != 7 && variant != 8 && variant != 10)
-        return fail(ctx, WEDM_ERR_UNSUPPORTED, "wedm_step: stencil_mode 1 (float64 stencil expressions) runs on kernels 1, 2 (10), 3, 7 and 8 only");
+    if (f64 && variant != 0 && variant != 1 && variant != 2 && variant != 3 && variant != 6 && variant != 7 && variant != 8 && variant != 10)
+        return fail(ctx, WEDM_ERR_UNSUPPORTED, "wedm_step: stencil_mode 1 (float64 stencil expressions) runs on kernels 1, 2 (10), 3, 6 (single microseconds without a trace sample), 7 and 8 only");
+    // the stream kernel in that typing: its single-microsecond instantiation only (chunks of at most 64 cells, no trace sample)
+    const bool stream_f64_ok = stream_ok && single && !tr && WEDM_STREAM_REGWALK && ctx->walk4_C[lanes_index(slanes)] <= 64;
+    if (f64 && variant == 6 && !stream_f64_ok)
+        return fail(ctx, WEDM_ERR_UNSUPPORTED, "wedm_step: under stencil_mode 1 the stream kernel runs launches of one microsecond without a trace sample, chunks of at most 64 cells");
+    // (by itself where the float32 launch takes it too and every tile of the table has register-walk code)
+    if (f64 && variant == 0 && stream_f64_ok && stream_auto && ctx->walk4_kind_s[lanes_index(slanes)] == 0u) variant = 6;
     // kernel 2 is the packed form where it applies (no injected variates; under stencil_mode 1 the same walk with float64-typed
     // cells); kernel 10 names the cell-by-cell form explicitly (A/B timing, tests)
     const bool use_pk = !ctx->replay && lanes_pk_ok;  // (both typings of the stencil)
@@ -713,10 +726,11 @@ static int32_t plan_launch(wedm_ctx* ctx, bool single, bool tr, bool frozen_ok, 
         out.walk = ctx->walk_dev + 5 + sli;
         // launches of one microsecond without a trace sample, chunks of at most 64 cells: the instantiation without the loop
         const bool one = WEDM_STREAM_REGWALK && single && !tr && ctx->walk4_C[sli] <= 64;
-        fn = one ? pick_stream<false, 64, true>(slanes)
+        fn = f64 ? pick_stream<false, 64, true, true>(slanes)
+           : one ? pick_stream<false, 64, true>(slanes)
            : ctx->walk4_C[sli] <= 64 ? (tr ? pick_stream<true, 64>(slanes) : pick_stream<false, 64>(slanes))
                                      : (tr ? pick_stream<true, 104>(slanes) : pick_stream<false, 104>(slanes));
-        std::snprintf(out.name, sizeof(out.name), "wedm_step_stream<%d><<<%d,256,%zuB>>>", slanes, grid, fl);
+        std::snprintf(out.name, sizeof(out.name), "wedm_step_stream<%d>%s<<<%d,256,%zuB>>>", slanes, f64 ? "[f64 stencil]" : "", grid, fl);
     } else if (lanes_sv_ok && variant == 11) {  // (by name only: at 16 384 environments x <= 450 segments it measures 2.39e9 against the packed form's 2.48e9 - 2.62e9)
         grid = (ctx->num_envs + 192 / svgl - 1) / (192 / svgl);
         fl = (2 * (size_t)((ctx->n_seg_max + 2 * svgl - 1) / (2 * svgl)) + 2) * 768 + (svgl == 4 ? sizeof(ServedBox<48>) : svgl == 8 ? sizeof(ServedBox<24>) : sizeof(ServedBox<12>));
@@ -898,6 +912,7 @@ int32_t wedm_create(const wedm_params* params, int32_t num_envs, int32_t n_seg_m
             if (ctx->walk_ok[i] && (host_tabs[i].kind_n1_mask & 0x80000000u)) ctx->walk_n1z |= 1u << i;
             ctx->walk4_ok[i] = build_walk(*params, Ls[i], host_tabs[5 + i], 4);
             ctx->walk4_C[i] = host_tabs[5 + i].C;
+            ctx->walk4_kind_s[i] = host_tabs[5 + i].kind_s_mask;
             if (i == 0) ctx->walk_regs_ok = params->n_seg <= 128 && build_walk(*params, 2, host_tabs[10], 64) && host_tabs[10].C == 64 &&
                                             build_walk(*params, 4, host_tabs[11], 32) && host_tabs[11].C == 32;
         }

@@ -11,7 +11,7 @@
 // environment's last cell, a plasma cell) are computed by the predicated formula from OLD values before the walk and written
 // after it, exactly as wedm_step_lanes does.  Cells past an environment's wire keep their value (the write-back copies all
 // n_seg_max rows).  A wave with a negative plasma heat walks cell by cell on the predicated formula (same results).
-// F64 (round 4): the same walk with every interior cell in Numba's typing of wire.py:58-123 (cell_f64 of wedm_k_regs.h: 18 float64
+// F64 (round 4): the same walk with every interior cell in Numba's typing of wire.py:58-123 (cell_f64 of wedm_common.h: 18 float64
 // operations per cell, the two cells of a pair one after the other) -- stencil_mode 1 on per-environment geometry.
 #pragma once
 

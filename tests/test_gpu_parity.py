@@ -1012,6 +1012,49 @@ def test_float64_stencil_on_the_register_kernels_over_wire_lengths_and_lane_coun
     assert ran >= (44 if variant == 7 else 50)
 
 
+def test_float64_stencil_on_the_stream_kernel_single_microseconds():
+    """`stencil_dtype="float64"` on kernel 6 (launches of one microsecond: the register walk of the single-microsecond
+    instantiation in Numba's typing; waves with a frozen environment on its per-cell code): wire lengths x lane counts, sparks,
+    current, a broken wire and hot cells == the oracle's STENCIL_F64, every byte; fused launches in between run the plan's kernel."""
+    from sparc_amd._lib import WedmError
+
+    n_envs, ran = 96, 0
+    for n_seg in (16, 33, 64, 100, 128, 200, 400):
+        gpu, cpu = make_pair(n_envs, stencil_dtype="float64", wire_params=WireModuleParameters(segment_len=80.0 / (n_seg + 0.5)),
+                             config=EnvironmentConfig(target_cutting_distance=5000.0))
+
+        def scenario(env):
+            env.reset(seed=700 + n_seg)
+            close_gap(env, 21.0, 10.0)
+            hot = env.state.wire_temperature
+            hot[5, n_seg // 2] = 1600.0
+            hot[70, n_seg - 1] = 900.0
+            hot[71, 1] = 900.0
+            return env.make_action(0.1, 80.0, 17, 3.0, 20.0)
+
+        act = scenario(cpu)
+        for k in (200, 1, 1, 1, 100, 1, 1):
+            cpu.step_many(act, k)
+        want = cpu.state.clone_blocks()
+        for lanes in (1, 2, 4, 8, 16):
+            act = scenario(gpu)
+            try:
+                for k in (200, 1, 1, 1, 100, 1, 1):
+                    gpu.set_kernel(6 if k == 1 else 0, lanes if k == 1 else 0)
+                    gpu.step_many(act, k)
+                    if k == 1:
+                        assert f"wedm_step_stream<{lanes}>[f64 stencil]" in gpu._backend.last_kernel(), gpu._backend.last_kernel()
+            except WedmError as exc:   # (a chunk of more than 64 cells for this lane count)
+                assert "UNSUPPORTED" in str(exc)
+                continue
+            torch.cuda.synchronize()
+            diffs = block_diffs(gpu.state.clone_blocks(), want, n_envs)
+            assert not diffs, f"n_seg {n_seg}, lanes {lanes}:\n" + "\n".join(diffs[:10])
+            ran += 1
+        gpu.close()
+    assert ran >= 20
+
+
 @pytest.mark.parametrize("n_seg", [400, 450, 129])
 def test_float64_stencil_on_the_wide_register_kernel_at_two_blocks_per_cu(n_seg):
     """A batch of more than one wave per SIMD in the float64 typing runs the wide register kernel's 256-register instantiation
