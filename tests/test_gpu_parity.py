@@ -793,6 +793,18 @@ def test_randomized_configurations_all_kernels_bit_exact(case):
     """Fuzz: random parameters in every module, random batch size / control mode / action / kernel
     variant (and per-environment geometry in a third of the cases): GPU == oracle on every byte.
     (64 cases in the default run; `WEDM_FUZZ_CASES=400` widens the hunt: 400 cases passed on the final builds of rounds 2 and 3.)"""
+    _fuzz_case(case, False)
+
+
+@pytest.mark.parametrize("case", range(int(os.environ.get("WEDM_FUZZ_F64_CASES", "40"))))
+def test_randomized_configurations_float64_typing_bit_exact(case):
+    """The same fuzz with the stencil in Numba's typing (`stencil_dtype="float64"`) over the kernels that carry it: the register
+    kernels, the tile walk, the packed and the cell-by-cell any-geometry kernels, the stream kernel (single microseconds) and the
+    global-memory kernel."""
+    _fuzz_case(case, True)
+
+
+def _fuzz_case(case, f64):
     from sparc_amd import DielectricModuleParameters, MaterialModuleParameters
     from sparc_amd._lib import WedmError
 
@@ -831,6 +843,8 @@ def test_randomized_configurations_all_kernels_bit_exact(case):
     compat = case % 5 in (3, 4)
     if compat:
         kw.update(reset_semantics="reference", freeze_terminated=(case % 5 == 3))
+    if f64:
+        kw["stencil_dtype"] = "float64"
     gpu, cpu = make_pair(n, **kw)
     seed = int(rng.integers(1, 1 << 40))
     gaps, debris = rng.uniform(6, 30, n), rng.uniform(0, 0.01, n)
@@ -845,17 +859,22 @@ def test_randomized_configurations_all_kernels_bit_exact(case):
         env.state.target_position = torch.as_tensor(np.where(np.arange(n) % 7 == 3, 10.0 + gaps + 0.01, 5000.0)) if extreme else 5000.0
         env.state.debris_volume = torch.as_tensor(debris) if (case % 2 or extreme) else 0.0
     variants = [(0, 0), (1, 0), (5, 0), (2, 4), (2, 8), (10, 4), (2, 2), (2, 16), (11, 4), (11, 8), (11, 16)] if per_env else KERNELS + [(0, 0), (7, 0), (8, 0)]
+    if f64:   # (kernel 6: launches of one microsecond only -- any other draw of k is refused and skipped)
+        variants = [(0, 0), (1, 0), (2, 4), (2, 8), (10, 4), (2, 2), (2, 16)] if per_env else \
+            [(0, 0), (1, 0), (3, 0), (3, 8), (7, 0), (7, 1), (8, 0), (8, 16), (2, 4), (10, 4), (6, 0), (6, 4)]
     servo = rng.uniform(50, 300, n) if kw["mechanics_control_mode"] == "velocity" else rng.uniform(-0.05, 0.3, n)
     if extreme:
         servo = servo * rng.choice([1.0, 1.0, 20.0, -3.0], n)
     modes = rng.choice([15, 17] if extreme else [1, 3, 5, 7, 9, 11, 13, 15, 17], n).astype(np.int32)
     ran = 0
     drawn = [variants[i] for i in rng.permutation(len(variants))[:4]]
-    if not per_env:   # every uniform-geometry case also runs a served kernel, last (the draws of the earlier rounds stay as they were)
+    if not per_env and not f64:   # every uniform-geometry case also runs a served kernel, last (the draws of the earlier rounds stay as they were)
         drawn.append(SERVED[case % 2])
     for variant, lanes in drawn:
         gpu.set_kernel(variant, lanes)
         k = int(rng.choice([1, 7, 400, 1300]))
+        if f64 and variant == 6:
+            k = 1
         if ran == 0:
             volt, on, off = float(u(60, 120)), float(rng.choice([1.5, 2.0, 3.0])), float(u(10, 60))
             acts = [env.make_action(servo, volt, modes, on, off) for env in (gpu, cpu)]
@@ -869,6 +888,7 @@ def test_randomized_configurations_all_kernels_bit_exact(case):
         diffs = block_diffs(gpu.state.clone_blocks(), cpu.state.clone_blocks(), n)
         assert not diffs, f"case {case}: kernel {gpu._backend.last_kernel()} after {k} us (n={n}, S={gpu.n_segments}):\n" + \
             "\n".join(diffs[:12])
+        assert not f64 or "[f64 stencil]" in gpu._backend.last_kernel()
         if gpu.state.crater_log is not None:
             G, Cc = gpu.state.crater_log[:, :n].cpu(), cpu.state.crater_log[:, :n]
             cnt = gpu.state.spark_count.cpu()[None, :]   # slots written so far (a ring: all of them once the count passes the capacity)
