@@ -396,21 +396,24 @@ def make_workload_env(name, device, rank=0, world=1, n_override=0, **kw):
     return env, mode, n_local, label
 
 
-def other_config_lines(device):
+def other_config_lines(device, stencil_dtype="float32"):
     """The other single-GPU BASELINE workloads, timed in the SAME driver run as the headline (their published numbers
     used to exist only as builder runs): configs[1] (4 096 x 400), the per-GPU shard of configs[3] (32 768 x 400) and the
     per-GPU shard of configs[4] (16 384 environments with per-environment geometry), fused 1000-us launches, each with its
-    own `roofline` block priced from the profiles/ rows of this build."""
+    own `roofline` block priced from the profiles/ rows of this build.  ``stencil_dtype="float64"``: the same workloads, and
+    configs[2] itself, with the stencil as Numba types the reference's @njit kernel (wire.py:58-123)."""
     import torch
 
     out = []
-    for name, steps in (("config2", 10), ("config4", 6), ("config5", 6)):
-        env, mode, n_local, label = make_workload_env(name, device)
+    f64 = stencil_dtype != "float32"
+    for name, steps in ((("config3", 5),) if f64 else ()) + (("config2", 10), ("config4", 4 if f64 else 6), ("config5", 4 if f64 else 6)):
+        env, mode, n_local, label = make_workload_env(name, device, stencil_dtype=stencil_dtype)
         env.reset(seed=1234)
         act = env.make_action(0.1, 80.0, mode, 3.0, 80.0)
         sec, kname = time_launches(env, act, 1000, steps, 2)
-        line = {"name": f"{label}: num_envs={n_local}, n_segments={env.n_segments}, fresh reset(seed=1234), fused 1000-us launches",
-                "workload": name, "value": n_local * 1000 / sec, "unit": "env-steps/s", "kernel": kname, "kernel_ms": sec * 1e3,
+        typing = "; stencil_dtype=float64 (float64 expressions rounded at each float32 store, as Numba types wire.py:58-123)" if f64 else ""
+        line = {"name": f"{label}: num_envs={n_local}, n_segments={env.n_segments}, fresh reset(seed=1234), fused 1000-us launches{typing}",
+                "workload": name + ("_f64" if f64 else ""), "value": n_local * 1000 / sec, "unit": "env-steps/s", "kernel": kname, "kernel_ms": sec * 1e3,
                 "steps": steps, "occupancy_blocks_per_cu": env._backend.last_occupancy(),
                 "roofline": roofline_block(kname, sec * 1e3, n_local, 1000, env.n_segments, resident_cap=resident_waves_cap(env._backend)),
                 "check": {"envs_done": int(env.state.done.sum().item()), "sparks": int(env.state.spark_count.sum().item())}}
@@ -618,6 +621,7 @@ def main():
             out["side"] = side_measurements(n_local, wire, S, device)
             out["side"].append(policy_in_the_loop_line(n_local, wire, device))
             out["side"] += other_config_lines(device)
+            out["side"] += other_config_lines(device, "float64")
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(wire, n_local, n_sub, args.cpu_seconds)
             out["cpu_baseline"]["reference_python"] = (

@@ -166,6 +166,10 @@ def test_driver_line_times_the_other_baseline_workloads_and_a_policy_in_the_loop
         assert rf["bound"] == "valu-issue" and rf["frac"] is not None and 0.0 < rf["frac"] <= 1.0
         assert rf["achieved"] == pytest.approx(rf["valu_insts_per_env_step"] * line["value"], rel=0.02)
         assert recorded("valu.json", line["kernel"])["build_id"] == b["config"]["build_id"]
+    # the same workloads and configs[2] itself with the stencil in Numba's typing: on the register / packed any-geometry kernels
+    for w, kernel, floor in (("config3_f64", "wedm_step_regs<2>[f64 stencil]", 8.0e9), ("config2_f64", "wedm_step_regs_wide<16>[f64 stencil]", 1.3e9),
+                             ("config4_f64", "wedm_step_regs_wide<16>[f64 stencil]", 1.7e9), ("config5_f64", "wedm_step_lanes_pk<8>[f64 stencil]", 1.35e9)):
+        assert kernel in side[w]["kernel"] and side[w]["value"] >= floor, (w, side[w]["kernel"], side[w]["value"])
     policy = next(s for s in b["side"] if s["name"].startswith("policy in the loop"))
     autoreset = b["side"][3]
     assert policy["value"] >= 0.97 * autoreset["value"] and "sync-debug" in policy["timing"]
