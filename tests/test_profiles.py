@@ -69,8 +69,9 @@ def test_headline_roofline_recomputes_from_profiles():
     # registers around the scalar phases) leak past the L2: ~25 MB, 0.1 % of HBM time
     assert traffic["hbm_bytes_per_launch"] < 1.3 * 102e6
     assert b["cpu_baseline"]["kind"] == "port" and b["cpu_baseline"]["cores"] >= 1
-    # five side lines of the headline batch + the policy in the loop + the three other single-GPU BASELINE workloads (round 4)
-    assert len(b["side"]) == 9 and b["side"][3]["resets_per_env_per_launch"] > 0.05
+    # five side lines of the headline batch + the policy in the loop + the three other single-GPU BASELINE workloads + the four
+    # workloads in the float64 typing (round 4)
+    assert len(b["side"]) == 13 and b["side"][3]["resets_per_env_per_launch"] > 0.05
     # a handle WITHOUT autoreset whose batch holds terminated (frozen) environments: its launches take no longer than the
     # quiet headline's (the register kernel walks under the mask of the live lanes; a wave of frozen lanes only skips work)
     frozen = b["side"][4]
