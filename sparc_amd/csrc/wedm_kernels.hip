@@ -593,7 +593,10 @@ static int32_t plan_launch(wedm_ctx* ctx, bool single, bool tr, bool frozen_ok, 
     const int wl = (ctx->lanes == 4 || ctx->lanes == 8 || ctx->lanes == 16) ? ctx->lanes : wl_min;
     const bool wide_ok = uniform && P.n_seg >= 9 && P.n_seg <= 512 && !ctx->replay &&
                          (ctx->lanes == 0 || (wl == ctx->lanes && wl >= wl_min));
-    if (variant == 0 && !single && wide_ok && ctx->lanes == 0 &&
+    // (stencil_mode 1, a short wire in a tiny batch: 256 waves of this kernel over 4 lanes against 1 024 of the tile walk over 16 --
+    // 2.81 against 2.47 ms at 4 096 x 128, profiles/r4/plan_sweep_f64.txt)
+    const bool f64_tiny = f64 && P.n_seg <= 128 && ctx->num_envs <= 4096;
+    if (variant == 0 && !single && wide_ok && !f64_tiny && ctx->lanes == 0 &&
         (int64_t)ctx->num_envs * wl <= (int64_t)WEDM_WIDE_AUTO_MAX_LANES)
         variant = 8;
     if (variant == 8 && !wide_ok)
@@ -611,7 +614,7 @@ static int32_t plan_launch(wedm_ctx* ctx, bool single, bool tr, bool frozen_ok, 
         // stencil_mode 1, longer wires, any batch: the wide register kernel (two blocks per CU beyond one wave per SIMD) -- 18 - 20
         // float64 operations per cell leave the LDS round trips of the tile walk nothing to hide behind (32 768 x 400: 1.93e9
         // against the fused kernel's 1.49e9; 8 192 x 400: 1.5e9 against 1.2e9 already at one block per CU)
-        if (variant == 0 && f64 && !single && wide_ok && ctx->lanes == 0) variant = 8;
+        if (variant == 0 && f64 && !single && wide_ok && !f64_tiny && ctx->lanes == 0) variant = 8;
     }
     // kernel 9 (served packed kernel, wedm_served.h): the packed walk on three waves of a block, the scalar physics on the fourth;
     // 4 or 8 lanes per environment; no trace point and no keep_stepping_terminated (such launches stay on kernel 4).

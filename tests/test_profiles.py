@@ -239,11 +239,11 @@ def test_numba_typed_stencil_runs_on_the_register_kernels_with_counters():
 
 
 def test_plan_sweep_in_the_float64_typing():
-    """profiles/r4/plan_sweep_f64.txt: one cliff is known and stated (4 096 x 128: the fused kernel over 16 lanes beats the wide
-    register kernel over 4 by 14 %: a batch of 256 waves)."""
+    """profiles/r4/plan_sweep_f64.txt: the plan in the float64 typing against every forced kernel over 20 shapes (the one cliff the
+    first sweep found -- 4 096 x 128: the tile walk over 16 lanes beats the wide register kernel over 4 by 13 % -- has a rule)."""
     txt = (R / "plan_sweep_f64.txt").read_text()
     assert bench("bench_config3.json")["config"]["build_id"] in txt.splitlines()[0] and "float64" in txt.splitlines()[0]
     rows = [l.split() for l in txt.splitlines() if l.startswith("  ") and not l.startswith("      ")]
     assert len(rows) == 20
-    bad = [(int(r[0]), int(r[1])) for r in rows if r[-1] == "cliff"]
-    assert bad in ([], [(4096, 128)])
+    ratios = [float(r[-1] if r[-1] != "cliff" else r[-3]) for r in rows]
+    assert max(ratios) <= 1.07
