@@ -1414,19 +1414,24 @@ def _shards_in_turn_equal_one_batch(n_shard, world, make_env, action_of, T_rows_
     return sparks, kernels
 
 
-def test_config4_at_full_size_all_eight_shards_in_turn_equal_one_batch():
-    """BASELINE configs[3]: 262 144 environments x 400 segments as ONE batch == its 8 shards of 32 768."""
+@pytest.mark.parametrize("stencil_dtype", ["float32", "float64"])
+def test_config4_at_full_size_all_eight_shards_in_turn_equal_one_batch(stencil_dtype):
+    """BASELINE configs[3]: 262 144 environments x 400 segments as ONE batch == its 8 shards of 32 768, in both typings of the
+    stencil (float64: the wide register kernel at two blocks per CU)."""
     sparks, kernels = _shards_in_turn_equal_one_batch(
-        32768, 8, lambda n, off, lo, hi: WireEDMEnv(num_envs=n, device="cuda:0", env_id_offset=off),
+        32768, 8, lambda n, off, lo, hi: WireEDMEnv(num_envs=n, device="cuda:0", env_id_offset=off, stencil_dtype=stencil_dtype),
         lambda env, lo, hi: env.make_action(0.1, 80.0, 5, 3.0, 80.0))
     assert sparks > 400000, sparks
     assert any("<<<" in k for k in kernels)
+    assert stencil_dtype == "float32" or all("[f64 stencil]" in k for k in kernels), kernels
 
 
-def test_config5_at_full_size_all_eight_shards_in_turn_equal_one_batch():
+@pytest.mark.parametrize("stencil_dtype", ["float32", "float64"])
+def test_config5_at_full_size_all_eight_shards_in_turn_equal_one_batch(stencil_dtype):
     """BASELINE configs[4]: 131 072 environments with per-environment workpiece height / wire diameter / current mode
-    (bench.config5_draws: numpy.default_rng(2024)) as ONE batch == its 8 shards of 16 384.  The full batch
-    and the shards run different lane counts of the per-environment-geometry kernel (the plan follows the batch size)."""
+    (bench.config5_draws: numpy.default_rng(2024)) as ONE batch == its 8 shards of 16 384, in both typings of the
+    stencil.  The full batch and the shards run different lane counts of the per-environment-geometry kernel (the plan follows
+    the batch size)."""
     import bench
 
     world, n = 8, 16384
@@ -1434,7 +1439,7 @@ def test_config5_at_full_size_all_eight_shards_in_turn_equal_one_batch():
 
     def make_env(num, off, lo, hi):
         return WireEDMEnv(num_envs=num, device="cuda:0", env_id_offset=off, workpiece_height=H[lo:hi], wire_diameter=D[lo:hi],
-                          config=EnvironmentConfig(target_cutting_distance=5000.0))
+                          stencil_dtype=stencil_dtype, config=EnvironmentConfig(target_cutting_distance=5000.0))
 
     sparks, kernels = _shards_in_turn_equal_one_batch(
         n, world, make_env, lambda env, lo, hi: env.make_action(0.1, 80.0, M[lo:hi], 3.0, 80.0),
