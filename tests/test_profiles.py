@@ -171,6 +171,9 @@ def test_driver_line_times_the_other_baseline_workloads_and_a_policy_in_the_loop
     for w, kernel, floor in (("config3_f64", "wedm_step_regs<2>[f64 stencil]", 8.0e9), ("config2_f64", "wedm_step_regs_wide<16>[f64 stencil]", 1.3e9),
                              ("config4_f64", "wedm_step_regs_wide<16>[f64 stencil]", 1.7e9), ("config5_f64", "wedm_step_lanes_pk<8>[f64 stencil]", 1.35e9)):
         assert kernel in side[w]["kernel"] and side[w]["value"] >= floor, (w, side[w]["kernel"], side[w]["value"])
+        rf = side[w]["roofline"]   # (their own counter rows of this build: a non-null fraction, the pipe busy above 0.7)
+        assert rf["frac"] is not None and 0.0 < rf["frac"] < 1.0 and rf["valu_pipe_busy"]["frac"] > 0.7
+        assert recorded("valu.json", side[w]["kernel"])["build_id"] == b["config"]["build_id"]
     policy = next(s for s in b["side"] if s["name"].startswith("policy in the loop"))
     autoreset = b["side"][3]
     assert policy["value"] >= 0.97 * autoreset["value"] and "sync-debug" in policy["timing"]
@@ -234,6 +237,8 @@ def test_numba_typed_stencil_runs_on_the_register_kernels_with_counters():
     assert recorded("traffic.json", b["config"]["kernel"]) is not None
     c2 = bench("bench_config2_f64.json")
     assert c2["config"]["kernel"].startswith("wedm_step_regs_wide<16>[f64 stencil]") and c2["value"] >= 1.3e9
+    for name, kernel in (("bench_config4_f64.json", "wedm_step_regs_wide<16>[f64 stencil]"), ("bench_config5_f64.json", "wedm_step_lanes_pk<8>[f64 stencil]")):
+        assert bench(name)["config"]["kernel"].startswith(kernel) and bench(name)["roofline"]["frac"] is not None
     one = bench("bench_config3_f64_1us.json")
     assert "[f64 stencil]" in one["config"]["kernel"] and one["roofline"]["kernel_ms"] < 0.040
 

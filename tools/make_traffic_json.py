@@ -19,7 +19,8 @@ d = Path(sys.argv[1])
 label = sys.argv[2] if len(sys.argv) > 2 else str(d)
 traffic, valu = [], []
 CASES = (("config3", "bench_config3.json"), ("config4", "bench_config4_shard.json"), ("config2", "bench_config2.json"),
-         ("config5", "bench_config5_shard.json"), ("config3_1us", "bench_config3_1us.json"), ("config3_f64", "bench_config3_f64.json"))
+         ("config5", "bench_config5_shard.json"), ("config3_1us", "bench_config3_1us.json"), ("config3_f64", "bench_config3_f64.json"),
+         ("config2_f64", "bench_config2_f64.json"), ("config4_f64", "bench_config4_f64.json"), ("config5_f64", "bench_config5_f64.json"))
 
 
 def table(path):

@@ -41,6 +41,9 @@ bench_lines() {  # $1: extra flags of the headline run ("" = with the CPU baseli
   bench bench_config4_1us --steps 2000 --warmup 100 --substeps 1 --workload config4 --no-cpu-baseline
   bench bench_config2_1us --steps 2000 --warmup 100 --substeps 1 --workload config2 --no-cpu-baseline
   bench bench_config3_f64 --steps 5 --warmup 1 --stencil-dtype float64 --no-cpu-baseline --no-side
+  bench bench_config2_f64 --steps 5 --warmup 1 --stencil-dtype float64 --workload config2 --no-cpu-baseline
+  bench bench_config4_f64 --steps 4 --warmup 1 --stencil-dtype float64 --workload config4 --no-cpu-baseline
+  bench bench_config5_f64 --steps 4 --warmup 1 --stencil-dtype float64 --workload config5 --no-cpu-baseline
 }
 echo "[profile] bench lines, first pass (kernel names and units per launch for the PMC tables)"; date +%T
 bench_lines "--no-cpu-baseline --no-side"
@@ -67,6 +70,13 @@ pmc write_config3_f64 WRITE_SIZE -- --steps 4 --warmup 1 --stencil-dtype float64
 pmc sq_config3_f64 SQ_WAVES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_VALU SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS -- --steps 4 --warmup 1 --stencil-dtype float64
 python tools/pmc_summary.py $OUT/pmc_fetch_config3_f64 $OUT/pmc_write_config3_f64 > $S/rocprofv3_pmc_hbm_config3_f64.txt
 python tools/pmc_summary.py $OUT/pmc_sq_config3_f64 > $S/rocprofv3_pmc_sq_config3_f64.txt
+for w in config2 config4 config5; do   # ... and on the wide register kernel (one / two blocks per CU) and the packed any-geometry kernel
+  pmc fetch_${w}_f64 FETCH_SIZE -- --steps 4 --warmup 1 --workload $w --stencil-dtype float64
+  pmc write_${w}_f64 WRITE_SIZE -- --steps 4 --warmup 1 --workload $w --stencil-dtype float64
+  pmc sq_${w}_f64 SQ_WAVES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_VALU SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS -- --steps 4 --warmup 1 --workload $w --stencil-dtype float64
+  python tools/pmc_summary.py $OUT/pmc_fetch_${w}_f64 $OUT/pmc_write_${w}_f64 > $S/rocprofv3_pmc_hbm_${w}_f64.txt
+  python tools/pmc_summary.py $OUT/pmc_sq_${w}_f64 > $S/rocprofv3_pmc_sq_${w}_f64.txt
+done
 # the kernel the served kernel replaced at 32 768 x 400, same counters (what the served form saves)
 pmc sq_config4_packed SQ_WAVES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_VALU SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS -- --steps 4 --warmup 1 --workload config4 --kernel 4 --lanes 8
 python tools/pmc_summary.py $OUT/pmc_sq_config4_packed > $S/rocprofv3_pmc_sq_config4_packed.txt
@@ -84,7 +94,6 @@ cp profiles/traffic.json profiles/valu.json $S/
 echo "[profile] bench lines, final pass (roofline objects use the counters just recorded)"; date +%T
 bench_lines ""
 bench bench_config3_f64_1us --steps 2000 --warmup 100 --substeps 1 --stencil-dtype float64 --no-cpu-baseline --no-side
-bench bench_config2_f64 --steps 5 --warmup 1 --stencil-dtype float64 --workload config2 --no-cpu-baseline
 bench bench_config3_trace_voltage --steps 5 --warmup 1 --trace voltage --no-cpu-baseline
 bench bench_config3_trace_signals --steps 5 --warmup 1 --trace signals --no-cpu-baseline
 WEDM_BENCH_FORCE_DIST=1 MASTER_ADDR=127.0.0.1 MASTER_PORT=29533 RANK=0 WORLD_SIZE=1 LOCAL_RANK=0 \
