@@ -398,10 +398,10 @@ int64_t wedm_trace_samples(wedm_ctx* ctx);
  * chunk of a lane requested up front, tile walk in LDS, no barrier; the automatic choice for
  * n_substeps == 1 where one round of blocks covers the batch), 7 = register kernel (one environment per
  * lane with its whole wire in registers: no LDS, the scalar physics once per environment; uniform geometry,
- * at most 128 segments, float32 stencil; own instantiation for launches with a trace sample),
+ * at most 128 segments, either typing of the stencil; own instantiation for launches with a trace sample),
  * 8 = wide register kernel (4, 8 or 16 lanes per environment -- the fewest that hold the wire at 32 cells per lane --
  * with the wire in their registers and per-cell zone / contact coefficients: no LDS, no tile table; uniform geometry,
- * 9 to 512 segments, float32 stencil; the automatic choice for fused launches of a batch that one round of blocks
+ * 9 to 512 segments, either typing of the stencil; the automatic choice for fused launches of a batch that one round of blocks
  * covers: environments x lanes <= 65 536; own instantiations for wires whose length is not a multiple of 8 and for
  * launches with a trace sample), 9 = served kernel (kernel 4's walk -- 4 or 8 lanes per environment, the wire in LDS --
  * with the float64 scalar physics of a block's environments on a FIFTH wave of the block, one lane per environment, one

@@ -5,7 +5,7 @@
 #pragma once
 
 // ============================================ register kernel: one environment per lane, the whole wire in VGPRs
-// Wires of at most CELLS (128) segments, uniform geometry, float32 stencil, launches without a trace sample.
+// Wires of at most CELLS (128) segments, uniform geometry; the float32 stencil or (F64) its float64 typing; a TRACE instantiation.
 // A lane owns ONE environment and keeps its whole wire in registers from the launch's first microsecond to its last: no
 // LDS, no halo exchange, no barrier, and the float64 scalar physics runs once per environment (the LDS kernels run it in
 // every lane that shares an environment: 2 at 65 536 x 128).  One wave per SIMD at a 512-register budget.
@@ -240,7 +240,7 @@ __global__ void __launch_bounds__(256, L) wedm_step_regs(const KArgs k) {
 
 
 // ============================================ wide register kernel: long wires of a SMALL batch in registers
-// Wires of up to 2 H L (512) segments, uniform geometry, float32 stencil.
+// Wires of up to 2 H L (512) segments, uniform geometry; the float32 stencil or (F64) its float64 typing.
 // The case it is for is 4 096 x 400: a batch that gives the chip one wave per SIMD whatever the kernel, so a launch's
 // time is the dependent chain of ONE wave per microsecond, and what shortens the chain is fewer cells per lane and no
 // LDS round trip inside it.  L = 16 lanes -- one DPP row -- own an environment; a lane holds 2 H = 32 cells as H = 16

@@ -510,7 +510,7 @@ static int32_t plan_launch(wedm_ctx* ctx, bool single, bool tr, bool frozen_ok, 
         }
     }
     const bool lanes_ok = glanes > 0;
-    // ... and its packed form (wedm_step_lanes_pk, float32 stencil): two virtual chunks of ceil(n_seg_max / 2L) cells per lane
+    // ... and its packed form (wedm_step_lanes_pk, either typing of the stencil): two virtual chunks of ceil(n_seg_max / 2L) cells per lane
     int pklanes = 0;
     {
         const int Ls[5] = {1, 2, 4, 8, 16};
@@ -585,7 +585,7 @@ static int32_t plan_launch(wedm_ctx* ctx, bool single, bool tr, bool frozen_ok, 
     // cells); kernel 10 names the cell-by-cell form explicitly (A/B timing, tests)
     const bool use_pk = !ctx->replay && lanes_pk_ok;  // (both typings of the stencil)
     // kernel 8 (wide register kernel): 4, 8 or 16 lanes per environment (the fewest that hold the wire), 32 cells each in
-    // registers; uniform geometry, float32 stencil, at most 512 segments.  Chosen by itself for a batch
+    // registers; uniform geometry, either typing of the stencil, at most 512 segments.  Chosen by itself for a batch
     // that one round of blocks covers at one wave per
     // SIMD: such a launch is one wave's dependent chain per microsecond whatever the kernel, and this one's is the
     // shortest (measured, 4 096 x 400 and 16 384 x 128: DESIGN.md 4.1b)
@@ -602,7 +602,7 @@ static int32_t plan_launch(wedm_ctx* ctx, bool single, bool tr, bool frozen_ok, 
     if (variant == 8 && !wide_ok)
         return fail(ctx, WEDM_ERR_UNSUPPORTED, "wedm_step: wide register kernel needs uniform geometry, 9 to 512 segments and lanes 0, 4, 8 or 16 with 32 cells per lane covering the wire");
     // kernel 7 (register kernel): one or two lanes per environment with the wire in their registers; wires of at most 128
-    // segments, uniform geometry, float32 stencil; a launch with a trace sample runs its TRACE instantiation
+    // segments, uniform geometry, either typing of the stencil; a launch with a trace sample runs its TRACE instantiation
     const bool regs_ok = uniform && ctx->walk_regs_ok && ctx->n_seg_max <= 128 && !ctx->replay;
     if (variant == 0) {
         // fused launches of a batch that gives most CUs a block of the register kernel (measured, 128 segments, two lanes

@@ -428,7 +428,8 @@ class WireEDMEnv:
         of its own, one microsecond ahead of the walking waves: 4 or 8 lanes per environment, uniform geometry);
         10 = kernel 2's cell-by-cell form by name (kernel 2 is its packed form wherever the stencil is float32), 11 = the served
         form of kernel 2, 12 = the served form of kernel 7; ``lanes`` lanes per environment for 2/3/4/6/8/9/10/11 (0 = auto).
-        All variants are bit-identical."""
+        All variants are bit-identical.  With ``stencil_dtype="float64"`` kernels 1, 2 / 10, 3, 6 (single microseconds without a
+        trace sample), 7 and 8 accept the launch (the others raise ``WEDM_ERR_UNSUPPORTED``)."""
         self._backend.set_kernel(variant)
         if hasattr(self._backend, "set_lanes"):
             self._backend.set_lanes(lanes)
